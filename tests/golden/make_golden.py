@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by RUNNING the reference (julbean/describealign v2.0.8).
+
+Runs only in the build container, where the reference is mounted read-only at
+/root/reference; nothing from the reference is copied - it is imported, driven on
+deterministic synthetic PCM (tests/golden/cases.py) and its inputs/outputs/intermediate
+values are recorded.  Intermediates are read from the live `align` frame with a
+`sys.settrace` line hook keyed on v2.0.8 line numbers (describealign.py:635, :674, :726,
+:860, :946 and the return event).
+
+  python tests/golden/make_golden.py [case ...]
+
+Outputs tests/golden/*.npz (+ report text for e180) and tests/golden/index.json.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+for _m in ("ffmpeg", "static_ffmpeg", "natsort"):   # I/O-only imports of the reference, absent here
+  sys.modules.setdefault(_m, types.ModuleType(_m))
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+import describealign as ref  # noqa: E402
+
+import cases  # noqa: E402
+
+assert ref.__version__ == "2.0.8", ref.__version__
+REF_FILE = os.path.abspath(ref.__file__)
+
+
+def ref_features(pcm_i16: np.ndarray):
+  arr = pcm_i16.astype(np.float16)                  # describealign.py:156
+  return [ref.get_energy(arr), ref.get_zero_crossings(arr)] + ref.get_freq_bands(arr)
+
+
+def gen_features():
+  out = {}
+  meta = {}
+  for name in cases.FEATURE_CLIPS:
+    pcm = cases.feature_clip(name)
+    feats = ref_features(pcm)
+    for k, f in enumerate(feats):
+      out[f"{name}.f{k}"] = np.asarray(f)            # keep the reference's dtype (f32 / f64 for band 2)
+    meta[name] = dict(sha1=cases.sha1_of(pcm), shape=list(pcm.shape),
+                      lengths=[int(len(f)) for f in feats], dtypes=[str(f.dtype) for f in feats])
+  np.savez_compressed(os.path.join(HERE, "features.npz"), **out)
+  return meta
+
+
+class AlignProbe:
+  """Line hook on the reference's align() frame (v2.0.8 line numbers)."""
+
+  def __init__(self):
+    self.cap = {}
+    self.cand_i, self.cand_v = [], []
+    self.m_i, self.m_v, self.m_q = [], [], []
+
+  def _global(self, frame, event, arg):
+    if event == "call" and frame.f_code.co_name == "align" and frame.f_code.co_filename == REF_FILE:
+      return self._local
+    return None
+
+  def _local(self, frame, event, arg):
+    L = frame.f_locals
+    if event == "line":
+      ln = frame.f_lineno
+      if ln == 674:                                   # candidates voted + verified for audio frame i
+        i = L["i"]
+        for v in sorted(L["common"]):
+          self.cand_i.append(i); self.cand_v.append(v)
+        for v, q in sorted(L["match_points"]):
+          self.m_i.append(i); self.m_v.append(v); self.m_q.append(q)
+      elif ln == 635 and "ms_v" not in self.cap:
+        self.cap["ms_v"] = np.array(L["video_features_mean_sub"][0:5], dtype=object)
+        self.cap["ms_v"] = [np.array(a, dtype=np.float64) for a in L["video_features_mean_sub"]]
+        self.cap["ms_a"] = [np.array(a, dtype=np.float64) for a in L["audio_desc_features_mean_sub"]]
+        self.cap["nrm_v"] = [np.array(a, dtype=np.float64) for a in L["video_uniform_norms"]]
+        self.cap["nrm_a"] = [np.array(a, dtype=np.float64) for a in L["audio_desc_uniform_norms"]]
+      elif ln == 726 and "p1_x" not in self.cap:
+        self.cap["p1_x"] = np.array(L["x"]); self.cap["p1_y"] = np.array(L["y"])
+      elif ln == 860 and "lp_x" not in self.cap:
+        self.cap["lp_x"] = np.array(L["x"], dtype=np.float64)
+        self.cap["lp_y"] = np.array(L["y"], dtype=np.float64)
+        self.cap["lp_sol"] = np.array(L["fit"].x)
+        self.cap["lp_fun"] = float(L["fit"].fun)
+        self.cap["lp_c"] = np.array(L["c"])
+        A = L["A_eq"].tocsc(); A.sort_indices()
+        self.cap["lp_A_data"], self.cap["lp_A_indices"], self.cap["lp_A_indptr"] = A.data, A.indices, A.indptr
+        self.cap["lp_A_shape"] = np.array(A.shape)
+        self.cap["lp_b"] = np.array(L["b_eq"])
+        self.cap["lp_cont_err"] = np.array(L["continuity_err"])
+        self.cap["fit_err"] = np.array(L["fit_err"])
+        self.cap["slopes"] = np.array(L["slopes"])
+        self.cap["median_slope"] = float(L["median_slope"])
+        self.cap["smooth_path"] = np.array(L["smooth_path"], dtype=np.float64)
+        self.cap["a_scaled"] = np.array(L["audio_desc_features_scaled"], dtype=np.float64)
+        self.cap["v_scaled"] = np.array(L["video_features_scaled"], dtype=np.float64)
+      elif ln == 946 and "cl_offset" not in self.cap:
+        lc = L["line_clusters"]
+        self.cap["cl_x0"] = np.array([c[0][0] for c in lc], dtype=np.float64)
+        self.cap["cl_x1"] = np.array([c[0][-1] for c in lc], dtype=np.float64)
+        self.cap["cl_offset"] = np.array([c[1] for c in lc], dtype=np.float64)
+        self.cap["cl_slope"] = np.array([c[2] for c in lc], dtype=np.float64)
+        pi, pj, pc, pq = [], [], [], []
+        for i, pts in enumerate(L["points"]):
+          for (j, c, q) in pts:
+            pi.append(i); pj.append(j); pc.append(c); pq.append(q)
+        self.cap["pt_i"] = np.array(pi, dtype=np.int64); self.cap["pt_j"] = np.array(pj, dtype=np.float64)
+        self.cap["pt_c"] = np.array(pc, dtype=np.int64); self.cap["pt_q"] = np.array(pq, dtype=np.float64)
+    elif event == "return":
+      if "path" in L and isinstance(L["path"], np.ndarray):
+        self.cap["path2"] = np.array(L["path"])       # already divided by 210 (describealign.py:1026)
+    return self._local
+
+  def run(self, vf, af):
+    sys.settrace(self._global)
+    try:
+      res = ref.align(vf, af, vf[0], af[0])
+    finally:
+      sys.settrace(None)
+    c = self.cap
+    for k in ("ms_v", "ms_a", "nrm_v", "nrm_a"):
+      for j, a in enumerate(c.pop(k)):
+        c[f"{k}{j}"] = a
+    c["cand_i"] = np.array(self.cand_i, dtype=np.int32); c["cand_v"] = np.array(self.cand_v, dtype=np.int32)
+    c["m_i"] = np.array(self.m_i, dtype=np.int32); c["m_v"] = np.array(self.m_v, dtype=np.int32)
+    c["m_q"] = np.array(self.m_q, dtype=np.float64)
+    return res, c
+
+
+def gen_align(name: str, deep: bool):
+  t0 = time.time()
+  if name == "mismatch":
+    pair = cases.align_case(name)
+    vf, af = ref_features(pair.video), ref_features(pair.audio)
+    try:
+      ref.align(vf, af, vf[0], af[0])
+      err = None
+    except RuntimeError as e:
+      err = str(e)
+    print(f"[{name}] error={err!r}")
+    return dict(sha1=pair.sha1(), error=err), None
+  pair = cases.align_case(name)
+  vf, af = ref_features(pair.video), ref_features(pair.audio)
+  cap = {}
+  if deep:
+    (x, y, sim, path, med), cap = AlignProbe().run(vf, af)
+  else:
+    x, y, sim, path, med = ref.align(vf, af, vf[0], af[0])
+  cap.update(dict(x=x, y=y, sim=np.float64(sim), med=np.float64(med),
+                  path_rows=np.int64(len(path)), path20=np.array(path[::20])))
+  for k, f in enumerate(vf):
+    cap[f"vf{k}"] = np.asarray(f, dtype=np.float32 if k < 4 else np.float64)
+  if name in ("a40",):
+    for k, f in enumerate(af):
+      cap[f"af{k}"] = np.asarray(f, dtype=np.float32 if k < 4 else np.float64)
+  meta = dict(sha1=pair.sha1(), video_shape=list(pair.video.shape), audio_shape=list(pair.audio.shape),
+              jump_video_times=pair.jump_video_times, jump_lengths=pair.jump_lengths,
+              rate_change=pair.rate_change, n_nodes=int(len(x)), sim=float(sim), med=float(med),
+              seconds_reference_align=None)
+  if name == "e180":
+    # text report + setts expression (describealign.py:159-227, :419-435)
+    with tempfile.TemporaryDirectory() as td:
+      stem = os.path.join(td, "e180")
+      video_offset = y[0] - x[0]
+      setts = ref.encode_fit_as_ffmpeg_expr(x, y, video_offset)
+      ref.plot_alignment(stem, path.copy(), x, y, sim, med, False, False, "<ffmpeg command>")
+      with open(stem + ".txt") as f:
+        meta["report_txt"] = f.read()
+      meta["setts"] = setts
+      meta["png_bytes"] = os.path.getsize(stem + ".png")
+  np.savez_compressed(os.path.join(HERE, f"align_{name}.npz"), **cap)
+  meta["seconds_reference_total"] = round(time.time() - t0, 2)
+  print(f"[{name}] nodes x={np.round(x, 4)} y={np.round(y, 4)} sim={sim:.3f} med={med:.6f} "
+        f"rows={len(path)} ({meta['seconds_reference_total']} s)")
+  return meta, cap
+
+
+def main(argv):
+  idx_path = os.path.join(HERE, "index.json")
+  index = json.load(open(idx_path)) if os.path.exists(idx_path) else {}
+  want = argv or ["features", "a40", "e180", "e180s", "e600", "rate2", "mismatch", "e1320"]
+  index["reference_version"] = ref.__version__
+  index["numpy"] = np.__version__
+  import scipy
+  index["scipy"] = scipy.__version__
+  for name in want:
+    if name == "features":
+      index["features"] = gen_features()
+      print("[features] done")
+    else:
+      meta, _ = gen_align(name, deep=(name == "a40"))
+      index.setdefault("align", {})[name] = meta
+    json.dump(index, open(idx_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+  main(sys.argv[1:])
