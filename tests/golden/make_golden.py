@@ -161,11 +161,10 @@ def gen_align(name: str, deep: bool):
     x, y, sim, path, med = ref.align(vf, af, vf[0], af[0])
   cap.update(dict(x=x, y=y, sim=np.float64(sim), med=np.float64(med),
                   path_rows=np.int64(len(path)), path20=np.array(path[::20])))
-  for k, f in enumerate(vf):
-    cap[f"vf{k}"] = np.asarray(f, dtype=np.float32 if k < 4 else np.float64)
-  if name in ("a40",):
-    for k, f in enumerate(af):
-      cap[f"af{k}"] = np.asarray(f, dtype=np.float32 if k < 4 else np.float64)
+  if deep:      # the reference's own feature rows, so align stages can be pinned independently of features
+    for k, (fv, fa) in enumerate(zip(vf, af)):
+      cap[f"vf{k}"] = np.asarray(fv, dtype=np.float32 if k < 4 else np.float64)
+      cap[f"af{k}"] = np.asarray(fa, dtype=np.float32 if k < 4 else np.float64)
   meta = dict(sha1=pair.sha1(), video_shape=list(pair.video.shape), audio_shape=list(pair.audio.shape),
               jump_video_times=pair.jump_video_times, jump_lengths=pair.jump_lengths,
               rate_change=pair.rate_change, n_nodes=int(len(x)), sim=float(sim), med=float(med),
