@@ -1,0 +1,231 @@
+"""ctypes binding of libdalign.so (C ABI: include/dalign.h).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device is usable,
+creating a Context raises.  Build the library with `python -c "import __graft_entry__ as g;
+g.build()"` or `make -C describealign_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdalign.so")
+ABI_VERSION = 1
+
+PREC_F32, PREC_BF16 = 0, 1
+SIDE_VIDEO, SIDE_AUDIO = 0, 1
+MATCH_HASHED, MATCH_DENSE = 0, 1
+
+ERR_CAPACITY = -3
+ERR_MISMATCH = -4
+
+EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm_upload",
+           "da_features_resident", "da_features", "da_match", "da_match_corr", "da_chain",
+           "da_refine", "da_stats"]
+
+
+class Stats(C.Structure):
+  _fields_ = [(n, C.c_double) for n in (
+      "features_ms", "features_bytes", "prep_ms", "gemm_ms", "gemm_pairs", "gemm_flops", "verify_ms",
+      "survivors", "matches", "chain_ms", "refine_kernel_ms", "refine_dp_ms", "refine_points", "h2d_ms")]
+
+  def as_dict(self):
+    return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def build(verbose: bool = False) -> str:
+  """Compile libdalign.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+  cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+  res = subprocess.run(cmd, capture_output=True, text=True)
+  if verbose or res.returncode != 0:
+    print(res.stdout[-4000:])
+    print(res.stderr[-4000:])
+  if res.returncode != 0 or not os.path.exists(LIB_PATH):
+    raise RuntimeError("building libdalign.so failed")
+  return LIB_PATH
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load():
+  global _lib
+  with _lib_lock:
+    if _lib is not None:
+      return _lib
+    if not os.path.exists(LIB_PATH):
+      raise ImportError(f"{LIB_PATH} is missing: the HIP extension has not been built "
+                        "(run __graft_entry__.build()); describealign_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    P = C.POINTER
+    lib.da_abi_version.restype = i32
+    lib.da_create.argtypes = [i32, i32, P(vp)]
+    lib.da_destroy.argtypes = [vp]; lib.da_destroy.restype = None
+    lib.da_last_error.argtypes = [vp]; lib.da_last_error.restype = C.c_char_p
+    lib.da_pcm_upload.argtypes = [vp, i32, vp, i64, i32, i32]
+    lib.da_features_resident.argtypes = [vp, i32, vp, i64, P(i64)]
+    lib.da_features.argtypes = [vp, vp, i64, i32, i32, vp, i64, P(i64)]
+    lib.da_match.argtypes = [vp, vp, i64, P(i64), vp, i64, P(i64), i32, i64, i64, vp, vp, vp, P(i64)]
+    lib.da_match_corr.argtypes = [vp, vp, vp, i64, vp]
+    lib.da_chain.argtypes = [vp, vp, vp, vp, i64, C.c_double, vp, vp, P(i64)]
+    lib.da_refine.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, vp, i32, C.c_double, vp, P(i64), P(i64)]
+    lib.da_stats.argtypes = [vp, P(Stats)]
+    if lib.da_abi_version() != ABI_VERSION:
+      raise ImportError("libdalign.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray):
+  return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+  """One da_ctx: one GPU, one HIP stream.  Not thread-safe; use one per thread."""
+
+  def __init__(self, device: int = 0, precision: int = PREC_F32):
+    self._lib = load()
+    self._h = C.c_void_p()
+    rc = self._lib.da_create(int(device), int(precision), C.byref(self._h))
+    if rc != 0:
+      raise RuntimeError(f"da_create(device={device}) failed with code {rc}: no usable gfx950 (MI355X) device; "
+                         "describealign_amd has no CPU fallback")
+    self.precision = precision
+    self.device = device
+    self._n = {}
+
+  def close(self):
+    if getattr(self, "_h", None) is not None and self._h:
+      self._lib.da_destroy(self._h)
+      self._h = C.c_void_p()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    self.close()
+
+  def _check(self, rc):
+    if rc != 0:
+      msg = self._lib.da_last_error(self._h).decode("utf-8", "replace")
+      raise RuntimeError(msg if msg else f"libdalign error {rc}")
+
+  # ---- features ----------------------------------------------------------------------------
+  def pcm_upload(self, side: int, pcm: np.ndarray):
+    """pcm: int16 (C, N) planar (the reference's array layout) or (N, C) interleaved if
+    given as a C-contiguous (N, C) array with C in {1, 2} and N > 2."""
+    pcm = np.asarray(pcm)
+    if pcm.dtype != np.int16 or pcm.ndim != 2:
+      raise ValueError("PCM must be a 2-D int16 array")
+    planar = 1
+    if pcm.shape[0] in (1, 2):
+      channels, n = pcm.shape
+    elif pcm.shape[1] in (1, 2):
+      n, channels = pcm.shape
+      planar = 0
+    else:
+      raise ValueError("PCM must have 1 or 2 channels")
+    pcm = np.ascontiguousarray(pcm)
+    self._check(self._lib.da_pcm_upload(self._h, side, _ptr(pcm), n, channels, planar))
+    self._n[side] = n
+    return n, channels
+
+  def features_resident(self, side: int, download: bool = True):
+    """Run the fused feature kernel on the PCM already resident for `side`.
+    Returns the five rows (describealign.py:1101-1104) as float32 arrays, or None."""
+    lengths = (C.c_int64 * 2)()
+    if not download:
+      self._check(self._lib.da_features_resident(self._h, side, None, 0, lengths))
+      return None
+    le = ((self._n[side] // 105) + 1) // 2
+    out = np.zeros((5, max(le, 1)), dtype=np.float32)
+    self._check(self._lib.da_features_resident(self._h, side, _ptr(out), out.shape[1], lengths))
+    le, lo = lengths[0], lengths[1]
+    return [out[0, :le].copy()] + [out[k, :lo].copy() for k in range(1, 5)]
+
+  def features(self, pcm: np.ndarray, side: int = SIDE_VIDEO):
+    """Upload + feature kernel: the five feature rows as a list of float32 arrays."""
+    self.pcm_upload(side, pcm)
+    return self.features_resident(side)
+
+  # ---- matching ----------------------------------------------------------------------------
+  @staticmethod
+  def _pack_rows(feats):
+    le = len(feats[0]); lo = len(feats[1])
+    if any(len(f) != lo for f in feats[1:]) or not (le == lo or le == lo + 1):
+      raise ValueError("feature rows must have lengths (L or L+1, L, L, L, L)")
+    rows = np.zeros((5, max(le, 1)), dtype=np.float32)
+    for k, f in enumerate(feats):
+      rows[k, :len(f)] = f
+    return rows, (C.c_int64 * 2)(le, lo)
+
+  def match(self, video_features, audio_features, mode: int = MATCH_HASHED, rows=None, capacity=None):
+    """Verified matches (i, v, qual) sorted by (i, v) -- describealign.py:595-673."""
+    vrows, vlen = self._pack_rows(video_features)
+    arows, alen = self._pack_rows(audio_features)
+    rb, re = (0, -1) if rows is None else rows
+    cap = int(capacity or max(1 << 20, int(3e-4 * vlen[0] * alen[0] / 4) + (1 << 16)))
+    for _ in range(2):
+      oi = np.empty(cap, dtype=np.int32); ov = np.empty(cap, dtype=np.int32); oq = np.empty(cap, dtype=np.float64)
+      n = C.c_int64(cap)
+      rc = self._lib.da_match(self._h, _ptr(vrows), vrows.shape[1], vlen, _ptr(arows), arows.shape[1], alen,
+                              mode, rb, re, _ptr(oi), _ptr(ov), _ptr(oq), C.byref(n))
+      if rc == ERR_CAPACITY:
+        cap = int(n.value) + 1024
+        continue
+      self._check(rc)
+      k = n.value
+      return oi[:k].copy(), ov[:k].copy(), oq[:k].copy()
+    raise RuntimeError("da_match: capacity negotiation failed")
+
+  def match_corr(self, i, v):
+    i = np.ascontiguousarray(i, dtype=np.int32); v = np.ascontiguousarray(v, dtype=np.int32)
+    out = np.empty((len(i), 3), dtype=np.float32)
+    self._check(self._lib.da_match_corr(self._h, _ptr(i), _ptr(v), len(i), _ptr(out)))
+    return out
+
+  def chain(self, i, v, q, min_len: float = 0.0):
+    """Heaviest non-decreasing chain -- describealign.py:654-698.  Returns (path_i, path_v)."""
+    i = np.ascontiguousarray(i, dtype=np.int32); v = np.ascontiguousarray(v, dtype=np.int32)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    n = len(i)
+    pi = np.empty(max(n, 1), dtype=np.int32); pv = np.empty(max(n, 1), dtype=np.int32)
+    m = C.c_int64(n)
+    self._check(self._lib.da_chain(self._h, _ptr(i), _ptr(v), _ptr(q), n, float(min_len), _ptr(pi), _ptr(pv), C.byref(m)))
+    return pi[:m.value].copy(), pv[:m.value].copy()
+
+  def refine(self, a_scaled, v_scaled, cl_x0, cl_x1, cl_offset, cl_slope, min_len: float = 0.0):
+    """Banded line extension + second DP -- describealign.py:895-993.  Returns (path[M,5], n_points)."""
+    a = np.ascontiguousarray(a_scaled, dtype=np.float64); v = np.ascontiguousarray(v_scaled, dtype=np.float64)
+    x0 = np.ascontiguousarray(cl_x0, dtype=np.float64); x1 = np.ascontiguousarray(cl_x1, dtype=np.float64)
+    off = np.ascontiguousarray(cl_offset, dtype=np.float64); sl = np.ascontiguousarray(cl_slope, dtype=np.float64)
+    cap = len(a) + len(v) + 16
+    for _ in range(2):
+      path = np.empty((cap, 5), dtype=np.float64)
+      rows = C.c_int64(cap); npts = C.c_int64(0)
+      rc = self._lib.da_refine(self._h, _ptr(a), len(a), _ptr(v), len(v), _ptr(x0), _ptr(x1), _ptr(off),
+                               _ptr(sl), len(x0), float(min_len), _ptr(path), C.byref(rows), C.byref(npts))
+      if rc == ERR_CAPACITY:
+        cap = rows.value + 16
+        continue
+      self._check(rc)
+      return path[:rows.value].copy(), npts.value
+    raise RuntimeError("da_refine: capacity negotiation failed")
+
+  def stats(self) -> dict:
+    s = Stats()
+    self._check(self._lib.da_stats(self._h, C.byref(s)))
+    return s.as_dict()

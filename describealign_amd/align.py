@@ -1,0 +1,310 @@
+"""Host side of the MI355X alignment path: the drop-in for describealign's `align()`.
+
+    align(video_features, audio_desc_features, video_energy, audio_desc_energy)
+        -> (audio_desc_times, video_times, similarity_percent, path, median_slope)
+
+is the seam `combine()` calls (reference describealign.py:1121-1122).  The quadratic and
+data-parallel stages run in HIP behind the C ABI (include/dalign.h):
+
+  stage 1+2  mean-sub / norms / hash digits, similarity GEMM on MFMA, exact verification  da_match
+  stage 2    heaviest-chain DP over the verified matches                                    da_chain
+  stage 4    banded line extension + second DP                                              da_refine
+
+and this module does what the reference keeps on the host: the pass-1 continuity filter,
+per-feature scaling and path compression (:701-767), the L1 trend-fit LP through
+scipy.optimize.linprog exactly as the reference poses it (:769-858), the line clustering
+(:861-893) and the node / similarity extraction (:993-1027).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import scipy.optimize
+import scipy.sparse
+from scipy.signal.windows import hann as _hann
+
+from . import _native
+
+FRAMES_PER_SECOND = 210
+NODE_FRAMES = 21                      # 210 // TIMESTEPS_PER_SECOND (:29, :596)
+MISMATCH_MSG = "Alignment failed, are the input files mismatched?"
+LP_FAIL_MSG = "Smooth Alignment L1-Min Optimization Failed!"
+
+_W41 = _hann(2 * NODE_FRAMES + 1)[1:-1]
+_W41N = _W41 / np.sum(_W41)
+
+
+def min_path_length(n_video: int, n_audio: int) -> float:
+  """Shorter paths mean mismatched inputs (:698, :991)."""
+  return max(min(n_video, n_audio) / 500.0, 5 * FRAMES_PER_SECOND)
+
+
+# ------------------------------------------------------------------------------------ stage 3
+def _smooth_same(a):
+  return np.convolve(_W41N, a, mode="same")[:len(a)]
+
+
+def continuity_error(x, y, deriv=False):
+  """How far each path point is from lines through smoothed neighbours ahead/behind (:702-724)."""
+  taps = _W41N[:NODE_FRAMES - 1]
+  taps = taps / taps.sum()
+  lag = NODE_FRAMES // 2
+  delay = NODE_FRAMES + lag - 2
+  x = np.asarray(x, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
+
+  def line_through(kernel):
+    xs = np.convolve(x, kernel, mode="valid"); ys = np.convolve(y, kernel, mode="valid")
+    slope = (ys[lag:] - ys[:-lag]) / (xs[lag:] - xs[:-lag])
+    return xs, ys, slope
+
+  xs, ys, sf = line_through(taps)
+  ahead = np.abs(sf * x[:-delay] + (ys[:-lag] - xs[:-lag] * sf) - y[:-delay])
+  xs, ys, sp = line_through(taps[::-1])
+  behind = np.abs(sp * x[delay:] + (ys[lag:] - xs[lag:] * sp) - y[delay:])
+  shift = delay - (1 if deriv else 0)
+  err = np.full(len(x) - (1 if deriv else 0), np.inf)
+  err[:len(err) - shift] = ahead
+  err[shift:] = np.minimum(err[shift:], behind)
+  return err
+
+
+def scale_feature_stacks(video_features, audio_features, x, y):
+  """(L,3) stacks of the first three features in units of the audio feature's std, the video
+  side additionally scaled by its least-squares gain onto the audio at the path (:733-741)."""
+  a_cols, v_cols = [], []
+  for vf, af in list(zip(video_features, audio_features))[:3]:
+    vf = np.asarray(vf); af = np.asarray(af)
+    sd = np.std(af)
+    gain = np.linalg.lstsq(vf[y][:, None], af[x], rcond=None)[0]
+    a_cols.append(af / sd)
+    v_cols.append(vf * gain / sd)
+  na = min(map(len, a_cols)); nv = min(map(len, v_cols))
+  a = np.empty((na, 3)); v = np.empty((nv, 3))
+  for k in range(3):
+    a[:, k] = a_cols[k][:na]; v[:, k] = v_cols[k][:nv]
+  return a, v
+
+
+def compress_path(x, y, run=70, tol=3):
+  """Replace straight runs of `run` path points by their mean; merge equal-x points (:743-767)."""
+  sx, sy = _smooth_same(x), _smooth_same(y)
+  with np.errstate(divide="ignore", invalid="ignore"):
+    slope = np.diff(sy) / np.diff(sx)
+    dev = np.abs(slope * x[:-1] + (sy[:-1] - sx[:-1] * slope) - y[:-1])
+  starts = np.arange(10, len(x) - 80, run)
+  if len(starts) == 0:
+    raise RuntimeError(MISMATCH_MSG)
+  ok = dev < tol
+  # all(ok[s:s+run]) per run via a prefix count (NaN deviations compare False, as in numpy)
+  csum = np.concatenate([[0], np.cumsum(ok)])
+  ends = np.minimum(starts + run, len(dev))
+  straight = (csum[ends] - csum[starts]) == (ends - starts)
+  px, py = [np.asarray(x[:10], dtype=np.float64)], [np.asarray(y[:10], dtype=np.float64)]
+  for s, flat in zip(starts.tolist(), straight.tolist()):
+    if flat:
+      px.append(np.array([np.mean(x[s:s + run])])); py.append(np.array([np.mean(y[s:s + run])]))
+    else:
+      px.append(np.asarray(x[s:s + run], dtype=np.float64)); py.append(np.asarray(y[s:s + run], dtype=np.float64))
+  tail = int(starts[-1]) + run
+  px.append(np.asarray(x[tail:tail + run], dtype=np.float64)); py.append(np.asarray(y[tail:tail + run], dtype=np.float64))
+  fx, fy = np.concatenate(px), np.concatenate(py)
+  # consecutive duplicates of x collapse to the mean of their y's (x is non-decreasing)
+  first = np.concatenate([[True], fx[1:] != fx[:-1]])
+  idx = np.flatnonzero(first)
+  counts = np.diff(np.concatenate([idx, [len(fx)]]))
+  ux = fx[idx]
+  uy = np.array([np.mean(fy[i:i + c]) for i, c in zip(idx.tolist(), counts.tolist())])
+  return ux, uy
+
+
+def build_trend_lp(x, y):
+  """The reference's L1 trend-filter LP (:773-840; variable layout SURVEY appendix A.6),
+  assembled directly as COO triplets.  Returns (c, A_eq csc, b_eq, bounds)."""
+  n = len(x)
+  dx = np.diff(x); dy = np.diff(y)
+  inv = 1.0 / dx
+  jump_cost = np.full(n - 1, 10.0) / np.maximum(1, np.sqrt(continuity_error(x, y, deriv=True) / 3.0))
+  c = np.concatenate([np.ones(2 * n), jump_cost, jump_cost, np.full(2 * n, 0.01), np.full(2 * n - 2, 3.0),
+                      np.full(2 * n - 2, 0.001), np.full(2 * n - 4, 10.0 * 4000), [0.0]])
+  o_fe_p, o_fe_m = 0, n
+  o_j_p, o_j_m = 2 * n, 3 * n - 1
+  o_s_p, o_s_m = 4 * n - 2, 5 * n - 2
+  o_sj_p, o_sj_m = 6 * n - 2, 7 * n - 3
+  o_rj_p, o_rj_m = 8 * n - 4, 9 * n - 5
+  o_rc_p, o_rc_m = 10 * n - 6, 11 * n - 8
+  o_med = 12 * n - 10
+  r1 = np.arange(n - 1)
+  r2 = np.arange(n - 2)
+  rows, cols, vals = [], [], []
+
+  def put(r, col, v):
+    rows.append(r); cols.append(col); vals.append(np.broadcast_to(v, r.shape))
+
+  # block 1: slope of every segment
+  put(r1, o_fe_p + r1, -inv); put(r1, o_fe_p + r1 + 1, inv)
+  put(r1, o_fe_m + r1, inv); put(r1, o_fe_m + r1 + 1, -inv)
+  for op, om in ((o_j_p, o_j_m), (o_sj_p, o_sj_m), (o_rj_p, o_rj_m)):
+    put(r1, op + r1, inv); put(r1, om + r1, -inv)
+  put(r1, np.full(n - 1, o_med), 1.0)
+  # block 2: shot-noise differences
+  b2 = (n - 1) + r1
+  put(b2, o_s_p + r1, -1.0); put(b2, o_s_p + r1 + 1, 1.0)
+  put(b2, o_s_m + r1, 1.0); put(b2, o_s_m + r1 + 1, -1.0)
+  put(b2, o_sj_p + r1, -1.0); put(b2, o_sj_m + r1, 1.0)
+  # block 3: changes of the rate-jump slope
+  b3 = (2 * n - 2) + r2
+  put(b3, o_rj_p + r2, -inv[:-1]); put(b3, o_rj_p + r2 + 1, inv[1:])
+  put(b3, o_rj_m + r2, inv[:-1]); put(b3, o_rj_m + r2 + 1, -inv[1:])
+  put(b3, o_rc_p + r2, -1.0); put(b3, o_rc_m + r2, 1.0)
+  A = scipy.sparse.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                              shape=(3 * n - 4, 12 * n - 9))
+  A.sort_indices()
+  b = np.concatenate([dy / dx, np.zeros(2 * n - 3)])
+  bounds = [[0, None]] * (4 * n - 2) + [[0, 2.0]] * (2 * n) + [[0, None]] * (6 * n - 8) + [[None, None]]
+  return c, A, b, bounds
+
+
+def solve_trend_lp(x, y):
+  """scipy.optimize.linprog exactly as the reference calls it (:841-858)."""
+  c, A, b, bounds = build_trend_lp(x, y)
+  fit = scipy.optimize.linprog(c, A_eq=A, b_eq=b, bounds=bounds, method="highs-ds")
+  if not fit.success and fit.status == 4:
+    fit = scipy.optimize.linprog(c, A_eq=A, b_eq=b, bounds=bounds, method="highs-ipm")
+  if not fit.success:
+    print(fit)
+    raise RuntimeError(LP_FAIL_MSG)
+  n = len(x)
+  s = fit.x
+  fit_err = s[:n] - s[n:2 * n]
+  rate_jump = s[8 * n - 4:9 * n - 5] - s[9 * n - 5:10 * n - 6]
+  median_slope = s[-1]
+  slopes = median_slope + rate_jump / np.diff(x)
+  return dict(solution=s, fit_err=fit_err, slopes=slopes, median_slope=median_slope,
+              smooth_x=np.asarray(x, dtype=np.float64), smooth_y=np.asarray(y) - fit_err)
+
+
+# ------------------------------------------------------------------------------------ stage 4
+def cluster_lines(sx, sy, slopes):
+  """Colinear clustering of the smooth path (:861-893).  Returns arrays (x_first, x_last,
+  offset, slope), one entry per kept line cluster, in the reference's order."""
+  s_ext = np.concatenate([slopes[:1], slopes, slopes[-1:]])
+  s_round = np.round(s_ext, 6)
+  buckets = {}
+  for k in range(len(sx)):
+    px, py = sx[k], sy[k]
+    for t in (k, k + 1):
+      s = s_ext[t]
+      if s < 0.1 or s > 10:
+        continue
+      key = (s_round[t], int(np.round(py - s * px, 0)))
+      buckets.setdefault(key, []).append((px, py))
+  order = sorted(buckets.items(), key=lambda kv: -len(kv[1]))      # stable: ties keep insertion order
+  taken = set()
+  merged = []
+  for key, pts in order:
+    if key in taken:
+      continue
+    s, o = key
+    taken.add(key)
+    del buckets[key]
+    for key2 in list(buckets.keys()):
+      p2 = buckets[key2]
+      if abs(p2[0][1] - (p2[0][0] * s + o)) < 3 and abs(p2[-1][1] - (p2[-1][0] * s + o)) < 3:
+        pts.extend(p2)
+        taken.add(key2)
+        del buckets[key2]
+    merged.append(pts)
+  x0, x1, off, slo = [], [], [], []
+  for pts in merged:
+    pts = sorted(pts)
+    if not (abs(pts[0][0] - pts[-1][0]) > 10 and len(pts) > 5):
+      continue
+    cx, cy = np.array(pts).T
+    sol = np.linalg.lstsq(np.stack([np.ones(len(cx)), cx], axis=1), cy, rcond=None)[0]
+    x0.append(cx[0]); x1.append(cx[-1]); off.append(sol[0]); slo.append(sol[1])
+  return (np.array(x0, dtype=np.float64), np.array(x1, dtype=np.float64),
+          np.array(off, dtype=np.float64), np.array(slo, dtype=np.float64))
+
+
+def nodes_and_similarity(path, n_audio_scaled, n_video_scaled, n_audio_energy, n_video_energy):
+  """Similarity percentage and piecewise-linear nodes in seconds (:993-1027)."""
+  vj, ai, cl, q = path[:, 0], path[:, 1], path[:, 2], path[:, 3]
+  solid = (q == 0) | (q > 0.3)
+  sim = 100 * max(len(np.unique(ai[solid])) / n_audio_scaled, len(np.unique(vj[solid])) / n_video_scaled)
+  change = np.flatnonzero(cl[:-1] != cl[1:])
+  nx, ny = [], []
+  if cl[0] == cl[1]:
+    nx.append(ai[0]); ny.append(vj[0])
+  for k in change.tolist():
+    nx += [ai[k] - 0.1, ai[k + 1] + 0.1]
+    ny += [vj[k] - 0.1, vj[k + 1] + 0.1]
+  if cl[-2] == cl[-1]:
+    nx.append(ai[-1]); ny.append(vj[-1])
+  nx = np.array(nx) / float(FRAMES_PER_SECOND); ny = np.array(ny) / float(FRAMES_PER_SECOND)
+  if nx[1] - nx[0] > 2:
+    s = (ny[1] - ny[0]) / (nx[1] - nx[0])
+    nx[0] = 0
+    ny[0] = ny[1] - nx[1] * s
+    if ny[0] < 0:
+      nx[0] = nx[1] - ny[1] / s
+      ny[0] = 0
+  if nx[-1] - nx[-2] > 2:
+    s = (ny[-1] - ny[-2]) / (nx[-1] - nx[-2])
+    nx[-1] = (n_audio_energy - 1) / float(FRAMES_PER_SECOND)
+    ny[-1] = ny[-2] + (nx[-1] - nx[-2]) * s
+    v_end = (n_video_energy - 1) / float(FRAMES_PER_SECOND)
+    if ny[-1] > v_end:
+      ny[-1] = v_end
+      nx[-1] = nx[-2] + (ny[-1] - ny[-2]) / s
+  return nx, ny, sim
+
+
+# ------------------------------------------------------------------------------------ align()
+_default_ctx = None
+
+
+def default_context(device: int = 0, precision: int = _native.PREC_F32) -> "_native.Context":
+  global _default_ctx
+  if _default_ctx is None or _default_ctx.precision != precision or _default_ctx.device != device:
+    _default_ctx = _native.Context(device, precision)
+  return _default_ctx
+
+
+def align(video_features, audio_desc_features, video_energy, audio_desc_energy, ctx=None, timings=None,
+          mode=_native.MATCH_HASHED):
+  """Drop-in for describealign.align (:595-1027); same arguments, same return tuple."""
+  ctx = ctx or default_context()
+  tm = timings if timings is not None else {}
+  t0 = time.perf_counter()
+  n_ve, n_ae = len(video_energy), len(audio_desc_energy)
+  print("  memorizing video...        \r", end='')
+  print("  matching audio...  \r", end='')
+  mi, mv, mq = ctx.match(video_features, audio_desc_features, mode=mode)
+  t1 = time.perf_counter()
+  px, py = ctx.chain(mi, mv, mq, min_len=min_path_length(n_ve, n_ae))      # raises the mismatch error
+  t2 = time.perf_counter()
+  x = px.astype(np.int64); y = py.astype(np.int64)
+
+  print("  refining match: pass 1 of 2...\r", end='')
+  keep = continuity_error(x, y) < 3
+  x, y = x[keep], y[keep]
+  a_scaled, v_scaled = scale_feature_stacks(video_features, audio_desc_features, x, y)
+  fx, fy = compress_path(x, y)
+  t3 = time.perf_counter()
+  lp = solve_trend_lp(fx, fy)
+  t4 = time.perf_counter()
+
+  print("  refining match: pass 2 of 2...\r", end='')
+  x0, x1, off, slo = cluster_lines(lp["smooth_x"], lp["smooth_y"], lp["slopes"])
+  t5 = time.perf_counter()
+  path, n_points = ctx.refine(a_scaled, v_scaled, x0, x1, off, slo, min_len=min_path_length(n_ve, n_ae))
+  t6 = time.perf_counter()
+  nx, ny, sim = nodes_and_similarity(path, len(a_scaled), len(v_scaled), n_ae, n_ve)
+  path[:, :2] /= float(FRAMES_PER_SECOND)
+  t7 = time.perf_counter()
+  tm.update(match_s=t1 - t0, chain_s=t2 - t1, pass1_host_s=t3 - t2, lp_s=t4 - t3, cluster_s=t5 - t4,
+            refine_s=t6 - t5, nodes_s=t7 - t6, total_s=t7 - t0, n_matches=len(mi), n_path1=len(px),
+            n_fit_points=len(fx), n_clusters=len(x0), n_points=n_points, n_path2=len(path))
+  tm["device"] = ctx.stats()
+  return nx, ny, sim, path, lp["median_slope"]

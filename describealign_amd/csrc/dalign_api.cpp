@@ -1,0 +1,685 @@
+// C-ABI host layer of libdalign.so (see include/dalign.h).  Owns the HIP context state, the
+// device buffers, the two host-side dynamic programmes (sequential by nature) and the glue
+// between the kernels.  Compiled with hipcc for gfx950; there is no CPU compute backend.
+#include "../../include/dalign.h"
+#include "dalign_common.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+using namespace da;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    cap = want;
+    return hipSuccess;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Side {
+  DevBuf pcm;  int64_t n = 0; int channels = 0; int planar = 1;
+  DevBuf feat; int64_t feat_stride = 0; int64_t len[2] = {0, 0};
+  // match-prep buffers
+  DevBuf mfeat;                  // 5 rows uploaded by da_match
+  DevBuf ms[5], nrm[5], dig[5], flg[5], ms32[3], inv32[3], bfe[3], bfo[3];
+  int64_t mlen[5] = {0, 0, 0, 0, 0}; int64_t lmax = 0;
+};
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct da_ctx {
+  int device = 0;
+  int precision = DA_PREC_F32;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  Side side[2];
+  DevBuf tables, hann41;
+  DevBuf vlist, alist, surv, counters, keys0, keys1, q0, q1, sort_tmp;
+  DevBuf pair_i, pair_v, pair_c;
+  DevBuf ascaled, vscaled, band_y, band_q, band_part;
+  bool match_ready = false;
+  MatchArgs last_match{};
+  da_stats_t st{};
+};
+
+namespace {
+
+int fail(da_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+
+#define HIP_TRY(c, call)                                                                        \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail((c), DA_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+void hann_inner(int m, std::vector<double>& w) {       // scipy.signal.windows.hann(m+2)[1:-1]
+  w.resize(m);
+  const double pi = 3.14159265358979323846;
+  for (int u = 0; u < m; ++u) w[u] = 0.5 - 0.5 * std::cos(2.0 * pi * (u + 1) / (m + 1));
+}
+
+void norm_f32(int m, float* out) {                     // float32 window / float32 sum (:551-552)
+  std::vector<double> w; hann_inner(m, w);
+  std::vector<float> f(m);
+  float s = 0.f;
+  for (int u = 0; u < m; ++u) { f[u] = (float)w[u]; }
+  // numpy's float32 pairwise sum on <= 21 elements is a plain left-to-right sum of 8-wide
+  // partials; the difference to a double sum is below float32 resolution after the divide.
+  double sd = 0; for (int u = 0; u < m; ++u) sd += (double)f[u];
+  s = (float)sd;
+  for (int u = 0; u < m; ++u) out[u] = f[u] / s;
+}
+
+void build_tables(FeatTables& T) {
+  norm_f32(13, T.w13); norm_f32(15, T.w15); norm_f32(21, T.w21);
+  const double pi = 3.14159265358979323846;
+  auto sep = [&](int d, int blur, double& A, double* ci, double* si, double* ck, double* sk) {
+    const int m = d * blur;
+    const double phi = 2.0 * pi / (m + 1);
+    // the reference normalises the float32 window by its float32 sum; mirror the float32 taps
+    double sum = 0;
+    for (int u = 0; u < m; ++u) sum += (double)(float)(0.5 - 0.5 * std::cos(phi * (u + 1)));
+    A = 0.5 / sum;
+    for (int i = 0; i < d; ++i) { ci[i] = std::cos(phi * (i + 1)); si[i] = std::sin(phi * (i + 1)); }
+    for (int k = 0; k < blur; ++k) { ck[k] = std::cos(phi * d * k); sk[k] = std::sin(phi * d * k); }
+  };
+  sep(42, 15, T.a1, T.cos1, T.sin1, T.ck1, T.sk1);
+  sep(6, 15, T.a2, T.cos2, T.sin2, T.ck2, T.sk2);
+}
+
+}  // namespace
+
+extern "C" {
+
+int da_abi_version(void) { return 1; }
+
+const char* da_last_error(const da_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int da_create(int device_id, int precision, da_ctx** out) {
+  if (!out) return DA_ERR_ARG;
+  *out = nullptr;
+  if (precision != DA_PREC_F32 && precision != DA_PREC_BF16) return DA_ERR_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return DA_ERR_DEVICE;
+  da_ctx* c = new da_ctx();
+  c->device = device_id;
+  c->precision = precision;
+  if (hipSetDevice(device_id) != hipSuccess) { delete c; return DA_ERR_DEVICE; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete c; return DA_ERR_DEVICE; }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return DA_ERR_DEVICE; }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DA_ERR_DEVICE; }
+  (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
+  FeatTables T; build_tables(T);
+  if (c->tables.ensure(sizeof T) != hipSuccess ||
+      hipMemcpy(c->tables.p, &T, sizeof T, hipMemcpyHostToDevice) != hipSuccess) { da_destroy(c); return DA_ERR_DEVICE; }
+  std::vector<double> w; hann_inner(kWin, w);
+  double s = 0; for (double x : w) s += x;
+  for (double& x : w) x /= s;
+  if (c->hann41.ensure(sizeof(double) * kWin) != hipSuccess ||
+      hipMemcpy(c->hann41.p, w.data(), sizeof(double) * kWin, hipMemcpyHostToDevice) != hipSuccess) { da_destroy(c); return DA_ERR_DEVICE; }
+  if (c->counters.ensure(64) != hipSuccess) { da_destroy(c); return DA_ERR_DEVICE; }
+  *out = c;
+  return DA_OK;
+}
+
+void da_destroy(da_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (Side& s : c->side) {
+    s.pcm.release(); s.feat.release(); s.mfeat.release();
+    for (int j = 0; j < 5; ++j) { s.ms[j].release(); s.nrm[j].release(); s.dig[j].release(); s.flg[j].release(); }
+    for (int j = 0; j < 3; ++j) { s.ms32[j].release(); s.inv32[j].release(); s.bfe[j].release(); s.bfo[j].release(); }
+  }
+  DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->counters, &c->keys0, &c->keys1,
+                   &c->q0, &c->q1, &c->sort_tmp, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
+                   &c->band_y, &c->band_q, &c->band_part};
+  for (DevBuf* b : all) b->release();
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int da_stats(const da_ctx* c, da_stats_t* out) {
+  if (!c || !out) return DA_ERR_ARG;
+  *out = c->st;
+  return DA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ PCM
+int da_pcm_upload(da_ctx* c, int side, const int16_t* pcm, int64_t n, int channels, int planar) {
+  if (!c) return DA_ERR_ARG;
+  if (side < 0 || side > 1 || !pcm || n < 0 || (channels != 1 && channels != 2))
+    return fail(c, DA_ERR_ARG, "da_pcm_upload: bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  Side& s = c->side[side];
+  const size_t bytes = sizeof(int16_t) * (size_t)n * channels;
+  HIP_TRY(c, s.pcm.ensure(bytes + 64));
+  const double t0 = now_ms();
+  if (bytes) HIP_TRY(c, hipMemcpyAsync(s.pcm.p, pcm, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->st.h2d_ms = now_ms() - t0;
+  s.n = n; s.channels = channels; s.planar = planar ? 1 : 0;
+  s.len[0] = s.len[1] = 0;
+  return DA_OK;
+}
+
+// ------------------------------------------------------------------------------------- features
+int da_features_resident(da_ctx* c, int side, float* feats, int64_t row_stride, int64_t lengths[2]) {
+  if (!c) return DA_ERR_ARG;
+  if (side < 0 || side > 1 || !lengths) return fail(c, DA_ERR_ARG, "da_features_resident: bad argument");
+  Side& s = c->side[side];
+  if (s.channels == 0) return fail(c, DA_ERR_STATE, "da_features_resident: no PCM uploaded for side %d", side);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t nb = s.n / 105;
+  const int64_t le = (nb + 1) / 2, lo = s.n / 210;
+  lengths[0] = le; lengths[1] = lo;
+  if (feats && row_stride < le) return fail(c, DA_ERR_CAPACITY, "da_features_resident: row_stride %lld < %lld", (long long)row_stride, (long long)le);
+  const int64_t dstride = ((le + 63) / 64) * 64 + 64;
+  HIP_TRY(c, s.feat.ensure(sizeof(float) * 5 * (size_t)dstride));
+  s.feat_stride = dstride; s.len[0] = le; s.len[1] = lo;
+  FeatArgs a{};
+  a.pcm = s.pcm.as<int16_t>(); a.n = s.n;
+  if (s.planar) { a.stride_c = s.n; a.stride_n = 1; } else { a.stride_c = 1; a.stride_n = s.channels; }
+  a.n_energy = 105 * nb; a.n_band = 210 * lo; a.len_energy = le; a.len_other = lo;
+  a.out = s.feat.as<float>(); a.row_stride = dstride;
+  HIP_TRY(c, hipMemsetAsync(s.feat.p, 0, sizeof(float) * 5 * (size_t)dstride, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  launch_features(a, s.channels, c->tables.as<FeatTables>(), c->stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  if (feats && le > 0)
+    HIP_TRY(c, hipMemcpy2DAsync(feats, sizeof(float) * row_stride, s.feat.p, sizeof(float) * dstride,
+                                sizeof(float) * le, 5, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  c->st.features_ms = ms;
+  c->st.features_bytes = 2.0 * s.channels * (double)s.n + 5.0 * 4.0 * (double)lo;
+  return DA_OK;
+}
+
+int da_features(da_ctx* c, const int16_t* pcm, int64_t n, int channels, int planar, float* feats,
+                int64_t row_stride, int64_t lengths[2]) {
+  int rc = da_pcm_upload(c, DA_SIDE_VIDEO, pcm, n, channels, planar);
+  if (rc != DA_OK) return rc;
+  return da_features_resident(c, DA_SIDE_VIDEO, feats, row_stride, lengths);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------- matching
+namespace {
+
+int upload_and_prep(da_ctx* c, Side& s, const float* feat, int64_t stride, const int64_t lengths[2], int is_video) {
+  const int64_t le = lengths[0], lo = lengths[1];
+  const int64_t lmax = std::max(le, lo);
+  s.lmax = lmax;
+  s.mlen[0] = le; for (int j = 1; j < 5; ++j) s.mlen[j] = lo;
+  const int64_t dstride = lmax + kPad;
+  HIP_TRY(c, s.mfeat.ensure(sizeof(float) * 5 * (size_t)dstride));
+  HIP_TRY(c, hipMemsetAsync(s.mfeat.p, 0, sizeof(float) * 5 * (size_t)dstride, c->stream));
+  for (int j = 0; j < 5; ++j) {
+    const int64_t L = s.mlen[j];
+    if (L > 0)
+      HIP_TRY(c, hipMemcpyAsync(s.mfeat.as<float>() + (size_t)j * dstride, feat + (size_t)j * stride, sizeof(float) * L,
+                                hipMemcpyHostToDevice, c->stream));
+  }
+  PrepArgs p{};
+  p.feat = s.mfeat.as<float>(); p.row_stride = dstride; p.lmax = lmax; p.is_video = is_video;
+  const size_t n = (size_t)dstride;
+  for (int j = 0; j < 5; ++j) {
+    p.len[j] = s.mlen[j];
+    HIP_TRY(c, s.ms[j].ensure(sizeof(double) * n)); p.ms[j] = s.ms[j].as<double>();
+    HIP_TRY(c, s.nrm[j].ensure(sizeof(double) * n)); p.nrm[j] = s.nrm[j].as<double>();
+    HIP_TRY(c, s.dig[j].ensure(sizeof(uint32_t) * n)); p.digits[j] = s.dig[j].as<uint32_t>();
+    HIP_TRY(c, s.flg[j].ensure(sizeof(uint32_t) * n)); p.flags[j] = s.flg[j].as<uint32_t>();
+  }
+  for (int j = 0; j < 3; ++j) {
+    HIP_TRY(c, s.ms32[j].ensure(sizeof(float) * n)); p.ms32[j] = s.ms32[j].as<float>();
+    HIP_TRY(c, s.inv32[j].ensure(sizeof(float) * n)); p.inv32[j] = s.inv32[j].as<float>();
+    HIP_TRY(c, s.bfe[j].ensure(sizeof(uint16_t) * n + 64)); p.bf_even[j] = s.bfe[j].as<uint16_t>();
+    HIP_TRY(c, s.bfo[j].ensure(sizeof(uint16_t) * n + 64)); p.bf_odd[j] = s.bfo[j].as<uint16_t>();
+  }
+  launch_prep(p, c->hann41.as<double>(), c->stream);
+  HIP_TRY(c, hipGetLastError());
+  return DA_OK;
+}
+
+}  // namespace
+
+extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const int64_t v_lengths[2],
+                        const float* afeat, int64_t a_stride, const int64_t a_lengths[2], int mode,
+                        int64_t row_begin, int64_t row_end, int32_t* out_i, int32_t* out_v, double* out_q,
+                        int64_t* n_out) {
+  if (!c) return DA_ERR_ARG;
+  if (!vfeat || !afeat || !v_lengths || !a_lengths || !n_out || (mode != 0 && mode != 1))
+    return fail(c, DA_ERR_ARG, "da_match: bad argument");
+  if (v_lengths[0] > v_stride || a_lengths[0] > a_stride || v_lengths[1] > v_lengths[0] || a_lengths[1] > a_lengths[0])
+    return fail(c, DA_ERR_ARG, "da_match: inconsistent lengths");
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->match_ready = false;
+  Side& V = c->side[0]; Side& A = c->side[1];
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  int rc = upload_and_prep(c, V, vfeat, v_stride, v_lengths, 1); if (rc) return rc;
+  rc = upload_and_prep(c, A, afeat, a_stride, a_lengths, 0); if (rc) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+
+  // row lists from the energy rows (describealign.py:629-630, :657-658)
+  std::vector<int32_t> vlist, alist;
+  {
+    const int64_t nv = v_lengths[0] - kWin;
+    int64_t k = 0;
+    for (int64_t i = 0; i < nv; ++i)
+      if (vfeat[i] > 0.5f) { if ((k & 3) == 0) vlist.push_back((int32_t)i); ++k; }
+    const int64_t na = a_lengths[0] - kWin;
+    const int64_t b = std::max<int64_t>(0, row_begin), e = (row_end < 0) ? na : std::min(na, row_end);
+    for (int64_t i = b; i < e; ++i)
+      if (afeat[i] > 0.5f) alist.push_back((int32_t)i);
+  }
+  const int64_t n_v = (int64_t)vlist.size(), n_a = (int64_t)alist.size();
+  c->st.gemm_pairs = (double)n_v * (double)n_a;
+  c->st.gemm_flops = 246.0 * c->st.gemm_pairs;
+  c->st.survivors = 0; c->st.matches = 0; c->st.gemm_ms = 0; c->st.verify_ms = 0;
+  HIP_TRY(c, c->vlist.ensure(sizeof(int32_t) * (size_t)std::max<int64_t>(1, n_v)));
+  HIP_TRY(c, c->alist.ensure(sizeof(int32_t) * (size_t)std::max<int64_t>(1, n_a)));
+  if (n_v) HIP_TRY(c, hipMemcpyAsync(c->vlist.p, vlist.data(), sizeof(int32_t) * n_v, hipMemcpyHostToDevice, c->stream));
+  if (n_a) HIP_TRY(c, hipMemcpyAsync(c->alist.p, alist.data(), sizeof(int32_t) * n_a, hipMemcpyHostToDevice, c->stream));
+
+  MatchArgs m{};
+  for (int j = 0; j < 3; ++j) {
+    m.ms_v[j] = V.ms32[j].as<float>(); m.ms_a[j] = A.ms32[j].as<float>();
+    m.inv_v[j] = V.inv32[j].as<float>(); m.inv_a[j] = A.inv32[j].as<float>();
+    m.bfa_even[j] = A.bfe[j].as<uint16_t>(); m.bfa_odd[j] = A.bfo[j].as<uint16_t>();
+    m.msd_v[j] = V.ms[j].as<double>();
+  }
+  m.vlist = c->vlist.as<int32_t>(); m.n_v = n_v;
+  m.alist = c->alist.as<int32_t>(); m.n_a = n_a;
+  const double thr_exact = std::pow(1e-8, 1.0 / 2.9);
+  // safety margin of the prefilter: f32 MFMA is an exact fmaf chain (error ~1e-7 of |a||b|);
+  // bf16 operands carry 2^-9 relative rounding each, so the product of three (1-corr) terms is
+  // thresholded with a factor-2 margin and everything is re-verified in float64 afterwards.
+  m.thr = (float)(thr_exact * (c->precision == DA_PREC_F32 ? 1.001 : 2.0));
+  // audio chunking: enough blocks to fill the chip several times over
+  {
+    const int64_t vblocks = ((n_v + 31) / 32 + 3) / 4;
+    const int64_t atiles = (n_a + 31) / 32;
+    int64_t want_y = std::max<int64_t>(1, (256 * 16 + vblocks - 1) / std::max<int64_t>(1, vblocks));
+    int64_t tpb = std::max<int64_t>(1, (atiles + want_y - 1) / want_y);
+    if (tpb > 4096) tpb = 4096;
+    if (atiles > 0 && (atiles + tpb - 1) / tpb > 65535) tpb = (atiles + 65534) / 65535;
+    m.audio_tiles_per_block = (int)tpb;
+  }
+  unsigned long long* d_cnt = c->counters.as<unsigned long long>();
+  m.out_count = d_cnt;
+
+  unsigned long long n_surv = 0;
+  size_t cap = (size_t)std::max(1e6, c->st.gemm_pairs * 4e-3);
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    HIP_TRY(c, c->surv.ensure(sizeof(unsigned long long) * cap));
+    m.out = c->surv.as<unsigned long long>(); m.capacity = cap;
+    HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 64, c->stream));
+    hipEvent_t e0, e1; HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    if (c->precision == DA_PREC_F32) launch_match_f32(m, c->stream); else launch_match_bf16(m, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&n_surv, d_cnt, sizeof n_surv, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1); c->st.gemm_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (n_surv <= cap) break;
+    cap = (size_t)(n_surv + n_surv / 16 + 1024);
+    if (attempt == 2) return fail(c, DA_ERR_DEVICE, "da_match: survivor list kept overflowing");
+  }
+  { float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.prep_ms = ms; }
+  c->st.survivors = (double)n_surv;
+  c->last_match = m; c->match_ready = true;
+
+  // exact verification + sort
+  unsigned long long n_match = 0;
+  if (n_surv > 0) {
+    HIP_TRY(c, c->keys0.ensure(sizeof(unsigned long long) * n_surv)); HIP_TRY(c, c->keys1.ensure(sizeof(unsigned long long) * n_surv));
+    HIP_TRY(c, c->q0.ensure(sizeof(double) * n_surv)); HIP_TRY(c, c->q1.ensure(sizeof(double) * n_surv));
+    VerifyArgs v{};
+    v.surv = c->surv.as<unsigned long long>(); v.capacity = cap;
+    for (int j = 0; j < 3; ++j) {
+      v.ms_v[j] = V.ms[j].as<double>(); v.ms_a[j] = A.ms[j].as<double>();
+      v.nrm_v[j] = V.nrm[j].as<double>(); v.nrm_a[j] = A.nrm[j].as<double>();
+    }
+    for (int j = 0; j < 5; ++j) {
+      v.dig_v[j] = V.dig[j].as<uint32_t>(); v.flg_v[j] = V.flg[j].as<uint32_t>(); v.dig_a[j] = A.dig[j].as<uint32_t>();
+    }
+    v.mode = mode;
+    v.keys = c->keys0.as<unsigned long long>(); v.quals = c->q0.as<double>();
+    v.n_out = d_cnt + 1; v.out_capacity = n_surv;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    launch_verify(v, n_surv, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(&n_match, d_cnt + 1, sizeof n_match, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_match > 0) {
+      size_t tmp_bytes = 0;
+      if (sort_pairs(nullptr, nullptr, nullptr, nullptr, (int64_t)n_match, nullptr, &tmp_bytes, c->stream) != 0)
+        return fail(c, DA_ERR_DEVICE, "da_match: sort sizing failed");
+      HIP_TRY(c, c->sort_tmp.ensure(tmp_bytes + 256));
+      if (sort_pairs(c->keys0.as<unsigned long long>(), c->keys1.as<unsigned long long>(), c->q0.as<double>(),
+                     c->q1.as<double>(), (int64_t)n_match, c->sort_tmp.p, &tmp_bytes, c->stream) != 0)
+        return fail(c, DA_ERR_DEVICE, "da_match: device sort failed");
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.verify_ms = ms;
+  }
+  c->st.matches = (double)n_match;
+  const int64_t capacity = *n_out;
+  *n_out = (int64_t)n_match;
+  if ((int64_t)n_match > capacity) return fail(c, DA_ERR_CAPACITY, "da_match: %llu matches exceed the caller's capacity %lld", n_match, (long long)capacity);
+  if (n_match > 0) {
+    if (!out_i || !out_v || !out_q) return fail(c, DA_ERR_ARG, "da_match: null output");
+    std::vector<unsigned long long> keys(n_match);
+    HIP_TRY(c, hipMemcpy(keys.data(), c->keys1.p, sizeof(unsigned long long) * n_match, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out_q, c->q1.p, sizeof(double) * n_match, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < n_match; ++k) { out_i[k] = (int32_t)(keys[k] >> 32); out_v[k] = (int32_t)(keys[k] & 0xffffffffu); }
+  }
+  return DA_OK;
+}
+
+extern "C" int da_match_corr(da_ctx* c, const int32_t* pi, const int32_t* pv, int64_t n, float* corr) {
+  if (!c) return DA_ERR_ARG;
+  if (!c->match_ready) return fail(c, DA_ERR_STATE, "da_match_corr: call da_match first");
+  if (n < 0 || (n > 0 && (!pi || !pv || !corr))) return fail(c, DA_ERR_ARG, "da_match_corr: bad argument");
+  if (n == 0) return DA_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, c->pair_i.ensure(sizeof(int32_t) * n)); HIP_TRY(c, c->pair_v.ensure(sizeof(int32_t) * n));
+  HIP_TRY(c, c->pair_c.ensure(sizeof(float) * 3 * n));
+  HIP_TRY(c, hipMemcpyAsync(c->pair_i.p, pi, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->pair_v.p, pv, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+  CorrArgs a{c->last_match, c->pair_i.as<int32_t>(), c->pair_v.as<int32_t>(), n, c->pair_c.as<float>(), c->precision};
+  launch_corr(a, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(corr, c->pair_c.p, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return DA_OK;
+}
+
+// ------------------------------------------------------------------------------------- chain DP
+// Heaviest chain non-decreasing in both coordinates (describealign.py:654-656, :674-697) as a
+// prefix-max Fenwick tree over the rank of v.  Equal cumulative weights resolve to the point
+// added later, which is what the reference's staircase frontier does (a new entry evicts
+// entries to its right whose weight is not larger, :679-680).
+extern "C" int da_chain(da_ctx* c, const int32_t* pi, const int32_t* pv, const double* pq, int64_t n, double min_len,
+                        int32_t* path_i, int32_t* path_v, int64_t* n_path) {
+  if (!c) return DA_ERR_ARG;
+  if (n < 0 || !n_path || (n > 0 && (!pi || !pv || !pq))) return fail(c, DA_ERR_ARG, "da_chain: bad argument");
+  const double t0 = now_ms();
+  int32_t vmax = -1;
+  for (int64_t k = 0; k < n; ++k) {
+    if (pv[k] < 0) return fail(c, DA_ERR_ARG, "da_chain: negative video index");
+    vmax = std::max(vmax, pv[k]);
+    if (k > 0 && (pi[k] < pi[k - 1] || (pi[k] == pi[k - 1] && pv[k] < pv[k - 1])))
+      return fail(c, DA_ERR_ARG, "da_chain: input not sorted by (i, v)");
+  }
+  std::vector<int32_t> rank((size_t)vmax + 2, 0);
+  for (int64_t k = 0; k < n; ++k) rank[pv[k]] = 1;
+  int32_t nr = 0;
+  for (size_t x = 0; x < rank.size(); ++x) { if (rank[x]) rank[x] = ++nr; }
+  struct Node { double cum; int32_t id; };
+  std::vector<Node> tree((size_t)nr + 1, Node{0.0, -1});
+  std::vector<int32_t> pred((size_t)n);
+  Node best_all{0.0, -1};
+  for (int64_t k = 0; k < n; ++k) {
+    const int32_t r = rank[pv[k]];
+    Node b{0.0, -1};
+    for (int32_t x = r; x > 0; x -= x & -x) {
+      const Node& t = tree[x];
+      if (t.cum > b.cum || (t.cum == b.cum && t.id > b.id)) b = t;
+    }
+    pred[k] = b.id;
+    const Node me{b.cum + pq[k], (int32_t)k};
+    for (int32_t x = r; x <= nr; x += x & -x) {
+      Node& t = tree[x];
+      if (me.cum > t.cum || (me.cum == t.cum && me.id > t.id)) t = me;
+    }
+    if (me.cum > best_all.cum || (me.cum == best_all.cum && me.id > best_all.id)) best_all = me;
+  }
+  std::vector<int32_t> chain;
+  for (int32_t p = best_all.id; p >= 0; p = pred[p]) chain.push_back(p);
+  std::reverse(chain.begin(), chain.end());
+  c->st.chain_ms = now_ms() - t0;
+  const int64_t capacity = *n_path;
+  *n_path = (int64_t)chain.size();
+  if ((double)chain.size() < min_len) return fail(c, DA_ERR_MISMATCH, "Alignment failed, are the input files mismatched?");
+  if ((int64_t)chain.size() > capacity) return fail(c, DA_ERR_CAPACITY, "da_chain: path of %zu exceeds capacity", chain.size());
+  for (size_t k = 0; k < chain.size(); ++k) { path_i[k] = pi[chain[k]]; path_v[k] = pv[chain[k]]; }
+  return DA_OK;
+}
+
+// ------------------------------------------------------------------------------------- refine
+namespace {
+
+struct BandPoint { double j; int32_t i; int32_t cl; double q; };
+
+void x_limits(double x_first, double x_last, double offset, double slope, int64_t La, int64_t Lv, int64_t extend,
+              int64_t& lo, int64_t& hi) {                       // describealign.py:895-900
+  const int64_t margin = 4;
+  lo = std::max<int64_t>((int64_t)x_first - extend, 0);
+  hi = std::min<int64_t>((int64_t)x_last + extend, La - 1);
+  lo = std::max<int64_t>(lo, (int64_t)std::ceil(((double)margin - offset) / slope));
+  hi = std::min<int64_t>(hi, (int64_t)std::floor(((double)(Lv - margin) - offset) / slope));
+}
+
+// Second DP (describealign.py:946-990) over points sorted by (i, j, cluster, qual).
+// Returns rows (j, i, cluster, qual, cum-as-used-by-the-successor).
+void second_dp(const std::vector<BandPoint>& pts, const std::vector<int64_t>& row_start, int64_t La, int64_t Lv,
+               int n_clusters, std::vector<double>& path_rows) {
+  struct Entry { double j; int32_t i; int32_t cl; double q; double cum; int32_t id; };
+  const double NEG = -std::numeric_limits<double>::infinity();
+  std::vector<Entry> frontier;                       // sorted by j, cum strictly increasing
+  frontier.push_back(Entry{0.0, 0, -1, 0.0, 0.0, -1});
+  std::vector<Entry> cl_best((size_t)n_clusters, Entry{0.0, 0, 0, 0.0, -1000.0, -1});
+  std::vector<Entry> cache((size_t)Lv, Entry{NEG, 0, 0, NEG, NEG, -2});     // id -2: empty slot
+  std::vector<double> cache_i((size_t)Lv, NEG);
+  cache[0] = Entry{0.0, 0, -1, 0.0, 0.0, -1}; cache_i[0] = 0.0;
+  const size_t np = pts.size();
+  std::vector<int32_t> pred(np, -1);
+  std::vector<double> pred_cum(np, 0.0);
+  // forward_min[i]: smallest j among rows >= i
+  std::vector<double> fmin((size_t)La + 1, std::numeric_limits<double>::infinity());
+  for (int64_t i = La - 1; i >= 0; --i) {
+    double m = fmin[i + 1];
+    if (row_start[i + 1] > row_start[i]) m = std::min(m, pts[row_start[i]].j);
+    fmin[i] = m;
+  }
+  for (int64_t i = 0; i < La; ++i) {
+    for (int64_t p = row_start[i]; p < row_start[i + 1]; ++p) {
+      const BandPoint& pt = pts[p];
+      const double j = pt.j;
+      // bisect_right on the key j
+      size_t pos = std::upper_bound(frontier.begin(), frontier.end(), j,
+                                    [](double key, const Entry& e) { return key < e.j; }) - frontier.begin();
+      const Entry& fe = frontier[pos - 1];
+      int32_t pid = fe.id; double best = fe.cum;
+      const Entry last = cl_best[pt.cl];
+      if (last.cum >= best) { pid = last.id; best = last.cum; }
+      const int64_t jj = (int64_t)j;
+      for (int64_t t = std::max<int64_t>(0, jj - 2); t <= jj; ++t) {
+        const Entry& nd = cache[t];
+        if (nd.id == -2) continue;                   // -inf slot: every comparison is false
+        double cum = nd.cum;
+        if (pt.cl != nd.cl) {
+          const double skew = (j - nd.j) - ((double)i - (double)nd.i);
+          cum -= 100.0 + 100.0 * skew * skew;
+        }
+        if ((double)nd.i >= (double)(i - 2) && nd.j <= j && cum >= best) { pid = nd.id; best = cum; }
+      }
+      const double cum = best + pt.q;
+      cache[jj] = Entry{j, (int32_t)i, pt.cl, pt.q, cum, (int32_t)p};
+      const double cjump = cum - 1000.0;
+      if (frontier[pos - 1].cum < cjump) {
+        size_t end = pos;
+        while (end < frontier.size() && frontier[end].cum <= cjump) ++end;
+        frontier.erase(frontier.begin() + pos, frontier.begin() + end);
+        frontier.insert(frontier.begin() + pos, Entry{j, (int32_t)i, pt.cl, pt.q, cjump, (int32_t)p});
+      }
+      if (fmin[i] == j && pos > 1) frontier.erase(frontier.begin(), frontier.begin() + (pos - 1));
+      const double ccl = cum - 50.0;
+      if (last.cum < ccl) cl_best[pt.cl] = Entry{j, (int32_t)i, pt.cl, pt.q, ccl, (int32_t)p};
+      pred[p] = pid; pred_cum[p] = best;
+    }
+  }
+  // backtrack from the last frontier entry (:985-989)
+  path_rows.clear();
+  std::vector<std::pair<int32_t, double>> rev;       // (point id, cum as recorded)
+  const Entry& lastf = frontier.back();
+  if (lastf.id >= 0) {
+    rev.emplace_back(lastf.id, lastf.cum);
+    while (true) {
+      const int32_t p = rev.back().first;
+      const int32_t q = pred[p];
+      if (q < 0) break;
+      rev.emplace_back(q, pred_cum[p]);
+    }
+  }
+  path_rows.reserve(rev.size() * 5);
+  for (auto it = rev.rbegin(); it != rev.rend(); ++it) {
+    const BandPoint& pt = pts[it->first];
+    path_rows.push_back(pt.j); path_rows.push_back((double)pt.i); path_rows.push_back((double)pt.cl);
+    path_rows.push_back(pt.q); path_rows.push_back(it->second);
+  }
+}
+
+}  // namespace
+
+extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const double* v_scaled, int64_t Lv,
+                         const double* cl_x0, const double* cl_x1, const double* cl_offset, const double* cl_slope,
+                         int n_clusters, double min_len, double* path, int64_t* n_rows, int64_t* n_points) {
+  if (!c) return DA_ERR_ARG;
+  if (!a_scaled || !v_scaled || La < 2 || Lv < 2 || n_clusters < 0 || !n_rows ||
+      (n_clusters > 0 && (!cl_x0 || !cl_x1 || !cl_offset || !cl_slope)))
+    return fail(c, DA_ERR_ARG, "da_refine: bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, c->ascaled.ensure(sizeof(double) * 3 * La)); HIP_TRY(c, c->vscaled.ensure(sizeof(double) * 3 * Lv));
+  HIP_TRY(c, hipMemcpyAsync(c->ascaled.p, a_scaled, sizeof(double) * 3 * La, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->vscaled.p, v_scaled, sizeof(double) * 3 * Lv, hipMemcpyHostToDevice, c->stream));
+  double a_max = -1e300, v_max = -1e300;                                  // (:908-909)
+  for (int64_t i = 0; i < La; ++i) a_max = std::max(a_max, a_scaled[3 * i]);
+  for (int64_t i = 0; i < Lv; ++i) v_max = std::max(v_max, v_scaled[3 * i]);
+  const int kRefBlocks = 256;
+  HIP_TRY(c, c->band_part.ensure(sizeof(double) * 4 * kRefBlocks));
+  HIP_TRY(c, c->band_y.ensure(sizeof(double) * (size_t)La)); HIP_TRY(c, c->band_q.ensure(sizeof(double) * (size_t)La));
+  std::vector<double> ys((size_t)La), qs((size_t)La), part(4 * kRefBlocks);
+  std::vector<std::vector<BandPoint>> rows((size_t)La);
+  std::unordered_set<uint64_t> seen;
+  double kernel_ms = 0.0;
+  int64_t total_points = 0;
+  const int64_t extend = (int64_t)kFrameRate * 30;
+  for (int ci = 0; ci < n_clusters; ++ci) {
+    double offset = cl_offset[ci];
+    const double slope = cl_slope[ci];
+    double xf = cl_x0[ci], xl = cl_x1[ci];
+    int64_t lo, hi;
+    x_limits(xf, xl, offset, slope, La, Lv, 0, lo, hi);
+    if (hi < lo + 5) continue;                                            // (:914-915)
+    BandArgs b{};
+    b.a_scaled = c->ascaled.as<double>(); b.La = La; b.v_scaled = c->vscaled.as<double>(); b.Lv = Lv;
+    b.slope = slope; b.a_max = a_max; b.v_max = v_max;
+    if (hi > lo + 100) {                                                  // (:916-930)
+      b.offset = offset; b.lo = lo; b.hi = hi;
+      HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+      launch_band_refine(b, c->band_part.as<double>(), kRefBlocks, c->stream);
+      HIP_TRY(c, hipGetLastError());
+      HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(part.data(), c->band_part.p, sizeof(double) * 4 * kRefBlocks, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); kernel_ms += ms;
+      double cnt = 0, sde = 0, sdd = 0, see = 0;
+      for (int k = 0; k < kRefBlocks; ++k) { cnt += part[4 * k]; sde += part[4 * k + 1]; sdd += part[4 * k + 2]; see += part[4 * k + 3]; }
+      if (cnt > 50 && sdd > 0 && see > 0) {
+        const double sol = sde / sdd;
+        const double resid = see - sol * sde;
+        const double explained = 1.0 - resid / see;
+        const double z = std::sqrt(explained * 3.0 * cnt) - 1.0;
+        if (z > 8 && std::fabs(sol) < 2) offset += sol;
+      }
+      xf = (double)lo; xl = (double)(hi - 1);       // the reference rebinds x to arange(lo, hi) here (:917)
+    }
+    x_limits(xf, xl, offset, slope, La, Lv, extend, lo, hi);
+    if (hi <= lo) continue;
+    b.offset = offset; b.lo = lo; b.hi = hi;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    launch_band_quality(b, c->band_y.as<double>(), c->band_q.as<double>(), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    const size_t n = (size_t)(hi - lo);
+    HIP_TRY(c, hipMemcpyAsync(ys.data(), c->band_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(qs.data(), c->band_q.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); kernel_ms += ms;
+    for (size_t k = 0; k < n; ++k) {                                      // (:937-941)
+      const int64_t i = lo + (int64_t)k;
+      const uint64_t key = ((uint64_t)i << 32) | (uint32_t)(int64_t)ys[k];
+      if (seen.insert(key).second) { rows[i].push_back(BandPoint{ys[k], (int32_t)i, ci, qs[k]}); ++total_points; }
+    }
+  }
+  c->st.refine_kernel_ms = kernel_ms;
+  c->st.refine_points = (double)total_points;
+  if (n_points) *n_points = total_points;
+  const double t0 = now_ms();
+  std::vector<BandPoint> pts; pts.reserve((size_t)total_points);
+  std::vector<int64_t> row_start((size_t)La + 1, 0);
+  for (int64_t i = 0; i < La; ++i) {
+    auto& r = rows[i];
+    std::sort(r.begin(), r.end(), [](const BandPoint& x, const BandPoint& y) {
+      if (x.j != y.j) return x.j < y.j;
+      if (x.cl != y.cl) return x.cl < y.cl;
+      return x.q < y.q;
+    });
+    row_start[i] = (int64_t)pts.size();
+    pts.insert(pts.end(), r.begin(), r.end());
+  }
+  row_start[La] = (int64_t)pts.size();
+  std::vector<double> out;
+  second_dp(pts, row_start, La, Lv, n_clusters, out);
+  c->st.refine_dp_ms = now_ms() - t0;
+  const int64_t rows_out = (int64_t)(out.size() / 5);
+  const int64_t capacity = *n_rows;
+  *n_rows = rows_out;
+  if ((double)rows_out < min_len) return fail(c, DA_ERR_MISMATCH, "Alignment failed, are the input files mismatched?");
+  if (rows_out > capacity) return fail(c, DA_ERR_CAPACITY, "da_refine: %lld rows exceed capacity %lld", (long long)rows_out, (long long)capacity);
+  if (rows_out && !path) return fail(c, DA_ERR_ARG, "da_refine: null path");
+  std::memcpy(path, out.data(), sizeof(double) * out.size());
+  return DA_OK;
+}

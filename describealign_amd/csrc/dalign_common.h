@@ -1,0 +1,111 @@
+// Internal declarations shared by the HIP kernel files and the C-ABI host layer (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace da {
+
+constexpr int kFrameRate = 210;     // feature frames / s           (describealign.py:546,559,577)
+constexpr int kWin = 41;            // correlation window, frames   (:596-597)
+constexpr int kTaps = 7;            // hash taps per feature        (:610)
+constexpr int kTapStep = 6;         // (:611)
+constexpr int kTapStart = 2;        // (:613)
+constexpr int kPad = 64;            // zero padding (elements) after every per-frame device row
+
+// ---- feature kernel tables (built on the host in double, see dalign_api.cpp) ----------------
+struct FeatTables {
+  float w13[13];          // hann(15)[1:-1] / sum, float32          (:551-552, :563-564)
+  float w15[15];          // hann(17)[1:-1] / sum  (5x3 low-pass and the 1x15 band-3 blur)
+  float w21[21];          // hann(23)[1:-1] / sum  (7x3 low-pass)
+  // separable form of the 630-tap (42x15) and 90-tap (6x15) Hann blurs:
+  //   W[i + d*k] = A * (1 - cos(phi*(i+1)) * cos(d*phi*k) + sin(phi*(i+1)) * sin(d*phi*k))
+  double a1, cos1[42], sin1[42], ck1[15], sk1[15];
+  double a2, cos2[6], sin2[6], ck2[15], sk2[15];
+};
+
+struct FeatArgs {
+  const int16_t* pcm;
+  int64_t n;              // samples per channel
+  int64_t stride_c;       // element stride between channels
+  int64_t stride_n;       // element stride between consecutive samples of one channel
+  int64_t n_energy;       // 105 * floor(n/105): samples the energy row may see
+  int64_t n_band;         // 210 * floor(n/210): samples the other rows may see
+  int64_t len_energy;     // ceil(floor(n/105)/2)
+  int64_t len_other;      // floor(n/210)
+  float* out;             // 5 rows
+  int64_t row_stride;
+};
+
+void launch_features(const FeatArgs& a, int channels, const FeatTables* d_tables, hipStream_t s);
+
+// ---- per-side preparation for matching -----------------------------------------------------
+struct PrepArgs {
+  const float* feat;      // 5 rows on device
+  int64_t row_stride;
+  int64_t len[5];         // row lengths (energy may be one longer)
+  int64_t lmax;           // max(len)
+  int is_video;
+  double* ms[5];          // mean-subtracted rows, float64, zero padded by kPad
+  double* nrm[5];         // window norms, float64 (len-40 valid entries)
+  uint32_t* digits[5];    // packed base-7 digits, one nibble per tap (audio: | 0x8888888)
+  uint32_t* flags[5];     // video only: ~(probe-next flags at bit 0 of each nibble)
+  float* ms32[3];         // float32 copy of ms (features 0-2), padded
+  float* inv32[3];        // 1/norm as float32
+  uint16_t* bf_even[3];   // bf16 copy of ms: element e at [e]
+  uint16_t* bf_odd[3];    // bf16 copy of ms shifted by one: element e+1 at [e]
+};
+void launch_prep(const PrepArgs& a, const double* d_hann41n, hipStream_t s);
+
+// ---- similarity GEMM -----------------------------------------------------------------------
+struct MatchArgs {
+  const float* ms_v[3]; const float* ms_a[3];
+  const float* inv_v[3]; const float* inv_a[3];
+  const uint16_t* bfa_even[3]; const uint16_t* bfa_odd[3];   // audio side bf16 copies
+  const double* msd_v[3];                                     // for building bf16 A fragments
+  const int32_t* vlist; int64_t n_v;      // every 4th non-quiet video frame (:629-630)
+  const int32_t* alist; int64_t n_a;      // non-quiet audio frames within the requested rows (:657-658)
+  unsigned long long* out;                // survivors: (i << 32) | v
+  unsigned long long* out_count;
+  unsigned long long capacity;
+  float thr;                              // (1e-8)^(1/2.9) times the precision's safety margin
+  int audio_tiles_per_block;
+};
+void launch_match_f32(const MatchArgs& a, hipStream_t s);
+void launch_match_bf16(const MatchArgs& a, hipStream_t s);
+
+struct CorrArgs {   // diagnostics: GEMM-precision correlations for explicit pairs
+  MatchArgs m; const int32_t* pi; const int32_t* pv; int64_t n; float* corr; int precision;
+};
+void launch_corr(const CorrArgs& a, hipStream_t s);
+
+// ---- exact verification --------------------------------------------------------------------
+struct VerifyArgs {
+  const unsigned long long* surv; const unsigned long long* n_surv; unsigned long long capacity;
+  const double* ms_v[3]; const double* ms_a[3];
+  const double* nrm_v[3]; const double* nrm_a[3];
+  const uint32_t* dig_v[5]; const uint32_t* flg_v[5]; const uint32_t* dig_a[5];
+  int mode;
+  unsigned long long* keys; double* quals; unsigned long long* n_out; unsigned long long out_capacity;
+};
+void launch_verify(const VerifyArgs& a, unsigned long long n_surv_host, hipStream_t s);
+
+// device radix sort of (key, qual) pairs (hipCUB); returns 0 on success
+int sort_pairs(unsigned long long* keys_in, unsigned long long* keys_out, double* vals_in, double* vals_out,
+               int64_t n, void* temp, size_t* temp_bytes, hipStream_t s);
+
+// ---- pass 2: banded evaluation -------------------------------------------------------------
+struct BandArgs {
+  const double* a_scaled; int64_t La;     // [La][3]
+  const double* v_scaled; int64_t Lv;     // [Lv][3]
+  double offset, slope;
+  int64_t lo, hi;                         // audio frames [lo, hi)
+  double a_max, v_max;
+};
+// sums for the sub-frame offset refinement (:916-930): per block 6 doubles
+//   [count_valid, sum(dv*err), sum(dv*dv), sum(err*err)] over valid rows
+void launch_band_refine(const BandArgs& a, double* d_partials, int n_blocks, hipStream_t s);
+// quality along the line (:931-936): writes y (video position) and qual for x in [lo, hi)
+void launch_band_quality(const BandArgs& a, double* d_y, double* d_q, hipStream_t s);
+void launch_colmax(const double* d, int64_t n, int stride, double* d_out, hipStream_t s);
+
+}  // namespace da

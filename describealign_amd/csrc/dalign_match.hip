@@ -1,0 +1,488 @@
+// Matching kernels (gfx950): per-side preparation, the similarity GEMM on MFMA, exact
+// verification of the GEMM's survivors, and the pass-2 banded line evaluation.
+//
+// The reference scores a candidate (audio frame i, video frame v) with three 41-tap windowed
+// correlations  corr_j = <A_j[i:i+41], V_j[v:v+41]> / (|A_j|_i |V_j|_v)  and keeps it when
+// (prod_j max(1e-8, 1 - corr_j))^2.9 <= 1e-8  (describealign.py:662-671).  Over all pairs that
+// is a Hankel GEMM with K = 41 per feature.  k_match_* evaluates it densely on the matrix cores
+// for (non-quiet audio frames) x (every 4th non-quiet video frame), thresholds in the epilogue
+// and appends the rare survivors to a list; k_verify then recomputes those pairs exactly in
+// float64, applies the reference's hash vote (:649-660) in its closed form, and emits
+// (i, v, quality).
+#include "dalign_common.h"
+
+namespace da {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------
+// prep: mean subtraction (:598-599, :605-606), window norms (:600-602), hash digits (:623-628,
+// :639-643) and the GEMM operand copies.  One thread per frame.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep_ms(PrepArgs a, const double* __restrict__ w /*41, normalised*/) {
+  const int j = blockIdx.y;
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t L = a.len[j];
+  if (n >= a.lmax + kPad) return;
+  double out = 0.0;
+  if (n < L) {
+    const float* f = a.feat + (int64_t)j * a.row_stride;
+    double acc = 0.0;
+#pragma unroll
+    for (int t = -20; t <= 20; ++t) {
+      const int64_t m = n + t;
+      const double x = (m >= 0 && m < L) ? (double)f[m] : 0.0;
+      acc += w[20 + t] * x;        // same tap order as a direct convolution
+    }
+    out = (double)f[n] - acc;
+  }
+  a.ms[j][n] = out;
+  if (j < 3) {
+    a.ms32[j][n] = (float)out;
+  }
+}
+
+__device__ inline uint16_t f32_to_bf16(float x) {
+  __bf16 b = (__bf16)x;                     // v_cvt_pk_bf16_f32 (round to nearest even)
+  return *reinterpret_cast<uint16_t*>(&b);
+}
+
+__global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
+  const int j = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t L = a.len[j];
+  if (i >= a.lmax + kPad) return;
+  const double* ms = a.ms[j];
+  if (j < 3) {
+    // bf16 copies of the (unnormalised) mean-subtracted row, scaled into range by nothing: values are O(1)
+    a.bf_even[j][i] = f32_to_bf16((float)ms[i]);
+    a.bf_odd[j][i] = f32_to_bf16((i + 1 < a.lmax + kPad) ? (float)ms[i + 1] : 0.f);
+  }
+  const int64_t nv = L - (kWin - 1);
+  if (i >= nv || nv <= 0) {
+    if (i < a.lmax + kPad) {
+      a.nrm[j][i] = 1.0;
+      a.digits[j][i] = 0xFFFFFFFFu;          // never matches
+      if (a.is_video) a.flags[j][i] = 0xFFFFFFFFu;
+      if (j < 3) a.inv32[j][i] = 0.f;
+    }
+    return;
+  }
+  double ss = 0.0;
+#pragma unroll
+  for (int k = 0; k < kWin; ++k) ss += ms[i + k] * ms[i + k];
+  double nr = sqrt(ss);
+  nr = nr < 0.001 ? 0.001 : nr;
+  a.nrm[j][i] = nr;
+  if (j < 3) a.inv32[j][i] = (float)(1.0 / nr);
+  uint32_t dig = 0, flg = 0;
+#pragma unroll
+  for (int b = 0; b < kTaps; ++b) {
+    const double tap = ms[i + kTapStart + kTapStep * b] / nr;
+    if (a.is_video) {
+      double u = 8.0 * tap + 3.3;
+      u = u < 0.0 ? 0.0 : (u > 6.0 ? 6.0 : u);
+      const double fl = floor(u);
+      dig |= (uint32_t)(int)fl << (4 * b);
+      if (u - fl > 0.6) flg |= 1u << (4 * b);
+    } else {
+      double u = floor(8.0 * tap + 3.5);
+      u = u < 0.0 ? 0.0 : (u > 6.0 ? 6.0 : u);
+      dig |= (uint32_t)(int)u << (4 * b);
+    }
+  }
+  if (a.is_video) {
+    a.digits[j][i] = dig;
+    a.flags[j][i] = ~flg;
+  } else {
+    a.digits[j][i] = dig | 0x08888888u;      // guard bit per nibble: no borrows in the packed subtract
+  }
+}
+
+void launch_prep(const PrepArgs& a, const double* d_hann41n, hipStream_t s) {
+  const int64_t n = a.lmax + kPad;
+  dim3 grid((unsigned)((n + 255) / 256), 5);
+  hipLaunchKernelGGL(k_prep_ms, grid, dim3(256), 0, s, a, d_hann41n);
+  hipLaunchKernelGGL(k_prep_norm, grid, dim3(256), 0, s, a);
+}
+
+// hash vote in closed form: feature j "hits" when every audio digit equals
+// the video digit, or the video digit + 1 where the video flag is set.
+__device__ inline bool digit_hit(uint32_t a_guarded, uint32_t v_dig, uint32_t v_notflag) {
+  const uint32_t d = ((a_guarded - v_dig) ^ 0x08888888u);   // per nibble: 0 equal, 1 one above
+  return (d & v_notflag & 0x0FFFFFFFu) == 0u && ((d & 0x0EEEEEEEu) == 0u);
+}
+
+// ------------------------------------------------------------------------------------------
+// similarity GEMM, float32 inputs on v_mfma_f32_32x32x2_f32
+//
+// Tile: one wave owns 32 video rows (MFMA A operand, held in 63 VGPRs for the whole launch,
+// pre-scaled by -1/|V|) and streams 32 audio columns at a time (MFMA B operand: each lane loads
+// A_j[i_c + 2s + h] straight from L1/L2 - lanes of a half-wave read consecutive floats).
+// acc = -<A,V>/|V|;  t_j = 1 + acc * (1/|A|_i) = 1 - corr_j;  survivor when t_0 t_1 t_2 <= thr.
+// ------------------------------------------------------------------------------------------
+constexpr int kWavesPerBlock = 4;
+constexpr int kSurvBuf = 256;          // survivor staging slots per wave (LDS)
+
+struct SurvSink {
+  unsigned long long* s_buf;           // this wave's LDS staging
+  int count;                           // wave-uniform
+};
+
+__device__ inline void sink_flush(SurvSink& sk, const MatchArgs& a, int lane) {
+  if (sk.count == 0) return;
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(a.out_count, (unsigned long long)sk.count);
+  base = __shfl(base, 0);
+  for (int t = lane; t < sk.count; t += 64) {
+    const unsigned long long pos = base + t;
+    if (pos < a.capacity) a.out[pos] = sk.s_buf[t];
+  }
+  sk.count = 0;
+}
+
+__device__ inline void sink_push(SurvSink& sk, const MatchArgs& a, int lane, bool pass, unsigned long long rec) {
+  const unsigned long long m = __ballot(pass);
+  if (m == 0ull) return;
+  const int n = __popcll(m);
+  if (sk.count + n > kSurvBuf) sink_flush(sk, a, lane);
+  if (pass) {
+    const int pos = sk.count + __popcll(m & ((1ull << lane) - 1ull));
+    sk.s_buf[pos] = rec;
+  }
+  sk.count += n;
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_match_f32(MatchArgs a) {
+  __shared__ unsigned long long s_surv[kWavesPerBlock][kSurvBuf];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t vt0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 32;
+  SurvSink sk{s_surv[wave], 0};
+  if (vt0 < a.n_v) {
+    // fixed operand: 32 video rows
+    const int64_t vr = vt0 + r;
+    const bool vok = vr < a.n_v;
+    const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
+    float A[3][21];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float sc = vok ? -a.inv_v[j][v] : 0.f;
+      const float* p = a.ms_v[j] + v + h;
+#pragma unroll
+      for (int s = 0; s < 21; ++s) A[j][s] = (2 * s + h < kWin) ? p[2 * s] * sc : 0.f;
+    }
+    const int64_t a_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block * 32;
+    int64_t a_end = a_begin + (int64_t)a.audio_tiles_per_block * 32;
+    if (a_end > a.n_a) a_end = a.n_a;
+    for (int64_t at = a_begin; at < a_end; at += 32) {
+      const int64_t ia = at + r;
+      const bool aok = ia < a_end;
+      const int32_t ic = a.alist[aok ? ia : a_end - 1];
+      f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0};
+      const float* p0 = a.ms_a[0] + ic + h;
+      const float* p1 = a.ms_a[1] + ic + h;
+      const float* p2 = a.ms_a[2] + ic + h;
+      float B0[21], B1[21], B2[21];
+#pragma unroll
+      for (int s = 0; s < 21; ++s) { B0[s] = p0[2 * s]; B1[s] = p1[2 * s]; B2[s] = p2[2 * s]; }
+#pragma unroll
+      for (int s = 0; s < 21; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][s], B0[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][s], B1[s], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[2][s], B2[s], acc2, 0, 0, 0);
+      }
+      const float i0 = a.inv_a[0][ic], i1 = a.inv_a[1][ic], i2 = a.inv_a[2][ic];
+      bool any = false;
+      bool pass[16];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float t0 = fmaf(acc0[g], i0, 1.0f);
+        const float t1 = fmaf(acc1[g], i1, 1.0f);
+        const float t2 = fmaf(acc2[g], i2, 1.0f);
+        pass[g] = aok && (t0 * t1 * t2 <= a.thr);
+        any |= pass[g];
+      }
+      if (__ballot(any) != 0ull) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
+          const int64_t vrr = vt0 + row;
+          unsigned long long rec = 0;
+          if (pass[g]) rec = ((unsigned long long)(uint32_t)ic << 32) | (uint32_t)a.vlist[vrr < a.n_v ? vrr : a.n_v - 1];
+          sink_push(sk, a, lane, pass[g] && vrr < a.n_v, rec);
+        }
+      }
+    }
+  }
+  sink_flush(sk, a, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// similarity GEMM, bf16 inputs / f32 accumulate on v_mfma_f32_32x32x16_bf16.
+// K = 41 padded to 48 (three K-steps of 16).  A operand: 8 consecutive bf16 of the video row
+// (lane l holds k = 16 s + 8 (l >> 5) + e), built once and pre-scaled by -1/|V|.  B operand: 8
+// consecutive bf16 of the audio row starting at i_c + 16 s + 8 h; a 16-byte load needs 4-byte
+// alignment, so two copies of the row are kept (even / shifted by one element) and each lane
+// picks the one that makes its start even.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_match_bf16(MatchArgs a) {
+  __shared__ unsigned long long s_surv[kWavesPerBlock][kSurvBuf];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t vt0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 32;
+  SurvSink sk{s_surv[wave], 0};
+  if (vt0 < a.n_v) {
+    const int64_t vr = vt0 + r;
+    const bool vok = vr < a.n_v;
+    const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
+    bf16x8 A[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double sc = vok ? -(double)a.inv_v[j][v] : 0.0;
+      const double* p = a.msd_v[j] + v;
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 16 * s + 8 * h + e;
+          const float x = (k < kWin) ? (float)(p[k] * sc) : 0.f;
+          A[j][s][e] = (short)f32_to_bf16(x);
+        }
+    }
+    const int64_t a_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block * 32;
+    int64_t a_end = a_begin + (int64_t)a.audio_tiles_per_block * 32;
+    if (a_end > a.n_a) a_end = a.n_a;
+    for (int64_t at = a_begin; at < a_end; at += 32) {
+      const int64_t ia = at + r;
+      const bool aok = ia < a_end;
+      const int32_t ic = a.alist[aok ? ia : a_end - 1];
+      const int32_t st = ic + 8 * h;                 // first element of this lane's K-step-0 fragment
+      const bool odd = st & 1;
+      const int32_t ev = st - (odd ? 1 : 0);         // even element index into the chosen copy
+      f32x16 acc[3] = {{0}, {0}, {0}};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const uint16_t* base = (odd ? a.bfa_odd[j] : a.bfa_even[j]) + ev;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const uint4 w = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(base) + 8 * s);
+          bf16x8 b;
+          *reinterpret_cast<uint4*>(&b) = w;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][s], b, acc[j], 0, 0, 0);
+        }
+      }
+      const float i0 = a.inv_a[0][ic], i1 = a.inv_a[1][ic], i2 = a.inv_a[2][ic];
+      bool any = false;
+      bool pass[16];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float t0 = fmaf(acc[0][g], i0, 1.0f);
+        const float t1 = fmaf(acc[1][g], i1, 1.0f);
+        const float t2 = fmaf(acc[2][g], i2, 1.0f);
+        pass[g] = aok && (t0 * t1 * t2 <= a.thr);
+        any |= pass[g];
+      }
+      if (__ballot(any) != 0ull) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
+          const int64_t vrr = vt0 + row;
+          unsigned long long rec = 0;
+          if (pass[g]) rec = ((unsigned long long)(uint32_t)ic << 32) | (uint32_t)a.vlist[vrr < a.n_v ? vrr : a.n_v - 1];
+          sink_push(sk, a, lane, pass[g] && vrr < a.n_v, rec);
+        }
+      }
+    }
+  }
+  sink_flush(sk, a, lane);
+}
+
+static dim3 match_grid(const MatchArgs& a) {
+  const int64_t vtiles = (a.n_v + 31) / 32;
+  const int64_t bx = (vtiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t atiles = (a.n_a + 31) / 32;
+  const int64_t by = (atiles + a.audio_tiles_per_block - 1) / a.audio_tiles_per_block;
+  return dim3((unsigned)bx, (unsigned)by);
+}
+
+void launch_match_f32(const MatchArgs& a, hipStream_t s) {
+  if (a.n_v <= 0 || a.n_a <= 0) return;
+  hipLaunchKernelGGL(k_match_f32, match_grid(a), dim3(64 * kWavesPerBlock), 0, s, a);
+}
+void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
+  if (a.n_v <= 0 || a.n_a <= 0) return;
+  hipLaunchKernelGGL(k_match_bf16, match_grid(a), dim3(64 * kWavesPerBlock), 0, s, a);
+}
+
+// diagnostics: the correlations exactly as the GEMM precision forms them, for explicit pairs.
+// One wave per 32 pairs would be the MFMA way; this path is test-only, so it uses plain FMAs on
+// identically rounded operands (f32: same k-ordered fmaf chain as the MFMA; bf16: same rounding
+// of both operands, f32 accumulation).
+__global__ void k_corr(CorrArgs c) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= c.n) return;
+  const int32_t i = c.pi[p], v = c.pv[p];
+  for (int j = 0; j < 3; ++j) {
+    float acc = 0.f;
+    if (c.precision == 0) {
+      const float sc = -c.m.inv_v[j][v];
+      for (int k = 0; k < kWin; ++k) acc = fmaf(c.m.ms_v[j][v + k] * sc, c.m.ms_a[j][i + k], acc);
+    } else {
+      const double sc = -(double)c.m.inv_v[j][v];
+      for (int k = 0; k < kWin; ++k) {
+        const uint16_t ab = f32_to_bf16((float)(c.m.msd_v[j][v + k] * sc));
+        const uint16_t bb = c.m.bfa_even[j][i + k];
+        const float af = __uint_as_float((uint32_t)ab << 16), bf = __uint_as_float((uint32_t)bb << 16);
+        acc = fmaf(af, bf, acc);
+      }
+    }
+    c.corr[3 * p + j] = -acc * c.m.inv_a[j][i];
+  }
+}
+void launch_corr(const CorrArgs& a, hipStream_t s) {
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(k_corr, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// exact verification of survivors (float64), hash vote, quality (:649-673)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_verify(VerifyArgs a, unsigned long long n_surv) {
+  const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_surv) return;
+  const unsigned long long rec = a.surv[p];
+  const int32_t i = (int32_t)(rec >> 32), v = (int32_t)(rec & 0xffffffffu);
+  if (a.mode == 0) {
+    int hits012 = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) hits012 += digit_hit(a.dig_a[j][i], a.dig_v[j][v], a.flg_v[j][v]) ? 1 : 0;
+    if (hits012 < 2) return;
+    const bool h3 = digit_hit(a.dig_a[3][i], a.dig_v[3][v], a.flg_v[3][v]);
+    const bool h4 = h3 ? true : digit_hit(a.dig_a[4][i], a.dig_v[4][v], a.flg_v[4][v]);
+    if (!h4) return;
+  }
+  double prob = 1.0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double* pa = a.ms_a[j] + i;
+    const double* pv = a.ms_v[j] + v;
+    double dot = 0.0;
+#pragma unroll
+    for (int k = 0; k < kWin; ++k) dot = fma(pa[k], pv[k], dot);
+    const double corr = dot / (a.nrm_a[j][i] * a.nrm_v[j][v]);
+    const double t = 1.0 - corr;
+    prob *= (t > 1e-8 ? t : 1e-8);
+  }
+  prob = pow(prob, 2.9);
+  if (prob > 1e-8) return;
+  double q = pow(prob / 1e-12, -1.0 / 3.0);
+  q = q < 50.0 ? q : 50.0;
+  const unsigned long long pos = atomicAdd(a.n_out, 1ull);
+  if (pos < a.out_capacity) {
+    a.keys[pos] = rec;
+    a.quals[pos] = q;
+  }
+}
+
+void launch_verify(const VerifyArgs& a, unsigned long long n_surv_host, hipStream_t s) {
+  if (n_surv_host == 0) return;
+  hipLaunchKernelGGL(k_verify, dim3((unsigned)((n_surv_host + 255) / 256)), dim3(256), 0, s, a, n_surv_host);
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 2: evaluation along a cluster's line (:901-906, :916-936), float64
+// ------------------------------------------------------------------------------------------
+__device__ inline void interp3(const double* __restrict__ vs, int64_t Lv, double y, double out[3]) {
+  // k=1 spline on integer knots (:864): linear interpolation between neighbouring frames
+  double fl = floor(y);
+  int64_t k = (int64_t)fl;
+  if (k < 0) { k = 0; }
+  if (k > Lv - 2) { k = Lv - 2; }
+  const double t = y - (double)k;
+  const double* p = vs + 3 * k;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[c] = p[c] * (1.0 - t) + p[3 + c] * t;
+}
+
+__global__ __launch_bounds__(256) void k_band_refine(BandArgs a, double* __restrict__ partials) {
+  // rows x in (lo, hi-1) exclusive of both ends (the reference drops the first and last, :918)
+  double cnt = 0, sde = 0, sdd = 0, see = 0;
+  for (int64_t x = a.lo + 1 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < a.hi - 1;
+       x += (int64_t)gridDim.x * blockDim.x) {
+    double vm[3], vp[3], vn[3];
+    interp3(a.v_scaled, a.Lv, a.slope * (double)x + a.offset, vm);
+    interp3(a.v_scaled, a.Lv, a.slope * (double)(x - 1) + a.offset, vp);
+    interp3(a.v_scaled, a.Lv, a.slope * (double)(x + 1) + a.offset, vn);
+    const double* am = a.a_scaled + 3 * x;
+    double e[3], mean = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { e[c] = am[c] - vm[c]; mean += e[c]; }
+    mean /= 3.0;
+    if (mean < 0.1) {
+      cnt += 1.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double d = (vn[c] - vp[c]) / 2.0;
+        sde = fma(d, e[c], sde); sdd = fma(d, d, sdd); see = fma(e[c], e[c], see);
+      }
+    }
+  }
+  __shared__ double red[4][256];
+  red[0][threadIdx.x] = cnt; red[1][threadIdx.x] = sde; red[2][threadIdx.x] = sdd; red[3][threadIdx.x] = see;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int c = 0; c < 4; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int c = 0; c < 4; ++c) partials[4 * blockIdx.x + c] = red[c][0];
+}
+void launch_band_refine(const BandArgs& a, double* d_partials, int n_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_band_refine, dim3(n_blocks), dim3(256), 0, s, a, d_partials);
+}
+
+__global__ __launch_bounds__(256) void k_band_quality(BandArgs a, double* __restrict__ ys, double* __restrict__ qs) {
+  const int64_t x = a.lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= a.hi) return;
+  const double y = a.slope * (double)x + a.offset;
+  double vm[3];
+  interp3(a.v_scaled, a.Lv, y, vm);
+  const double* am = a.a_scaled + 3 * x;
+  double q = 0.0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) q += -0.5 - log10(1e-4 + fabs(am[c] - vm[c]));
+  double g = vm[0] + 2.5 - a.v_max; g = g < 0 ? 0 : (g > 1 ? 1 : g);
+  q *= g;
+  double ga = am[0] + 2.5 - a.a_max; ga = ga < 0 ? 0 : (ga > 1 ? 1 : ga);
+  q += ga * 0.1;
+  ys[x - a.lo] = y;
+  qs[x - a.lo] = q;
+}
+void launch_band_quality(const BandArgs& a, double* d_y, double* d_q, hipStream_t s) {
+  const int64_t n = a.hi - a.lo;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_band_quality, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, d_y, d_q);
+}
+
+__global__ void k_colmax(const double* __restrict__ d, int64_t n, int stride, double* out) {
+  __shared__ double red[256];
+  double m = -1e300;
+  for (int64_t i = threadIdx.x; i < n; i += 256) m = fmax(m, d[i * stride]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0];
+}
+void launch_colmax(const double* d, int64_t n, int stride, double* d_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_colmax, dim3(1), dim3(256), 0, s, d, n, stride, d_out);
+}
+
+}  // namespace da

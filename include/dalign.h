@@ -1,0 +1,121 @@
+/* dalign.h -- C ABI of libdalign.so, the MI355X (gfx950) alignment core.
+ *
+ * The reference (julbean/describealign v2.0.8) has no FFI layer: its hot path is the Python
+ * call sequence in combine() (describealign.py:1098-1122).  This header is the boundary a
+ * maintainer would bind with ctypes in place of those calls; every entry
+ * point cites the reference lines it replaces.
+ *
+ * Conventions: plain C, caller-allocated buffers, return 0 = ok / negative = error
+ * (da_last_error gives the text the host raises as RuntimeError).  One da_ctx per thread/GPU;
+ * no globals.  There is NO CPU backend: da_create fails when no gfx950 device is usable.
+ */
+#ifndef DALIGN_H
+#define DALIGN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct da_ctx da_ctx;
+
+enum {
+  DA_OK = 0,
+  DA_ERR_ARG = -1,        /* bad argument */
+  DA_ERR_DEVICE = -2,     /* HIP runtime failure / no device */
+  DA_ERR_CAPACITY = -3,   /* caller buffer too small; required size is written back */
+  DA_ERR_MISMATCH = -4,   /* "Alignment failed, are the input files mismatched?" (:699, :992) */
+  DA_ERR_STATE = -5       /* call order violated (e.g. features before pcm upload) */
+};
+
+enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };       /* similarity-GEMM input precision */
+enum { DA_SIDE_VIDEO = 0, DA_SIDE_AUDIO = 1 };
+enum { DA_MATCH_HASHED = 0,  /* reference candidate vote (:649-660) applied to GEMM survivors */
+       DA_MATCH_DENSE = 1 }; /* every pair under the correlation threshold (no hash vote) */
+
+int  da_create(int device_id, int precision, da_ctx** out);
+void da_destroy(da_ctx* ctx);
+const char* da_last_error(const da_ctx* ctx);
+/* ABI version of this header (bumped on any signature change). */
+int  da_abi_version(void);
+
+/* ---- PCM residency -------------------------------------------------------------------------
+ * Replaces the array parse_audio_from_file returns (describealign.py:149-157): int16 PCM at
+ * 44.1 kHz, channels in {1,2}; planar = (C,N) like the reference's array, else interleaved
+ * s16le frames as ffmpeg emits them.  The copy into HBM happens here (host->device). */
+int da_pcm_upload(da_ctx* ctx, int side, const int16_t* pcm, int64_t n_samples, int channels,
+                  int planar);
+
+/* ---- features -------------------------------------------------------------------------------
+ * get_energy + get_zero_crossings + get_freq_bands (describealign.py:545-593) as one fused
+ * kernel over the resident PCM of `side`.  feats receives 5 rows (energy, zero crossings,
+ * 3 band energies) with row stride `row_stride` floats; lengths[0] = energy length
+ * ceil(floor(N/105)/2), lengths[1] = length of the other four rows floor(N/210).
+ * feats may be NULL to leave the rows on the device only. */
+int da_features_resident(da_ctx* ctx, int side, float* feats, int64_t row_stride, int64_t lengths[2]);
+
+/* One-shot convenience: upload + features (side slot DA_SIDE_VIDEO is used as scratch). */
+int da_features(da_ctx* ctx, const int16_t* pcm, int64_t n_samples, int channels, int planar,
+                float* feats, int64_t row_stride, int64_t lengths[2]);
+
+/* ---- stage 1+2: matching --------------------------------------------------------------------
+ * align() "memorizing video" + "matching audio" up to the verified match list
+ * (describealign.py:595-673): local-mean subtraction, window norms, hash digits, the
+ * 3 x 41-tap windowed correlation as an MFMA GEMM over (audio rows x video rows), exact fp64
+ * re-verification of the survivors, Naive-Bayes quality.  Feature rows are host pointers
+ * (5 rows, stride `*_stride` floats, lengths as returned by da_features*).
+ * Output: matches sorted by (audio frame i, video frame v); *n_out in: capacity, out: count
+ * (DA_ERR_CAPACITY with the needed count if too small). */
+int da_match(da_ctx* ctx,
+             const float* vfeat, int64_t v_stride, const int64_t v_lengths[2],
+             const float* afeat, int64_t a_stride, const int64_t a_lengths[2],
+             int mode, int64_t audio_row_begin, int64_t audio_row_end,
+             int32_t* out_i, int32_t* out_v, double* out_q, int64_t* n_out);
+
+/* Correlation values of the similarity GEMM for explicit (i, v) pairs, as the selected
+ * precision computes them (testing/diagnostics: "similarity values within 1e-3").
+ * corr receives [n][3].  Uses the feature rows of the last da_match call. */
+int da_match_corr(da_ctx* ctx, const int32_t* i, const int32_t* v, int64_t n, float* corr);
+
+/* ---- stage 2 DP: heaviest chain -------------------------------------------------------------
+ * describealign.py:654-656, :674-698: heaviest chain non-decreasing in both coordinates over
+ * matches sorted by (i, v).  *n_path in: capacity, out: length.  min_len = the reference's
+ * failure bound max(min(Lv,La)/500, 1050) (:698); shorter -> DA_ERR_MISMATCH. */
+int da_chain(da_ctx* ctx, const int32_t* i, const int32_t* v, const double* q, int64_t n,
+             double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path);
+
+/* ---- stage 4: banded line extension + second DP ---------------------------------------------
+ * describealign.py:895-993.  a_scaled [La][3], v_scaled [Lv][3] (the scaled feature stacks of
+ * :733-741); clusters given as first/last audio x of each line cluster plus (offset, slope)
+ * from :890-893.  path receives rows (video_idx, audio_idx, cluster, qual, cum_qual) in frames;
+ * *n_rows in: capacity, out: rows.  n_points (optional) receives the banded point count. */
+int da_refine(da_ctx* ctx, const double* a_scaled, int64_t La, const double* v_scaled, int64_t Lv,
+              const double* cl_x0, const double* cl_x1, const double* cl_offset,
+              const double* cl_slope, int n_clusters, double min_len,
+              double* path, int64_t* n_rows, int64_t* n_points);
+
+/* ---- timing / roofline counters of the most recent calls ------------------------------------ */
+typedef struct da_stats_t {
+  double features_ms;        /* device time of the feature kernel (HIP events), last call */
+  double features_bytes;     /* algorithmic bytes: 2*C*N read + 5 rows written */
+  double prep_ms;            /* mean-sub / norms / digits kernels, both sides */
+  double gemm_ms;            /* similarity GEMM kernel */
+  double gemm_pairs;         /* (audio rows) x (video rows) evaluated */
+  double gemm_flops;         /* 246 flop per pair (2*41*3, describealign.py:664-667) */
+  double verify_ms;          /* exact re-verification + compaction + sort */
+  double survivors;          /* pairs the GEMM passed to verification */
+  double matches;            /* verified matches returned */
+  double chain_ms;           /* host DP */
+  double refine_kernel_ms;   /* banded evaluation kernels */
+  double refine_dp_ms;       /* host second DP */
+  double refine_points;
+  double h2d_ms;             /* last da_pcm_upload */
+} da_stats_t;
+
+int da_stats(const da_ctx* ctx, da_stats_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DALIGN_H */

@@ -1,0 +1,213 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the reference goldens.
+Needs a real MI355X: run with `pytest -m gpu`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import dalign_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+INDEX = json.load(open(os.path.join(GOLD, "index.json")))
+HOP_S = 0.023          # north_star tolerance on node times: +-1 "STFT hop" (~23 ms)
+
+
+@pytest.fixture(scope="module")
+def native():
+  from describealign_amd import _native
+  return _native
+
+
+@pytest.fixture(scope="module")
+def ctx(native):
+  c = native.Context(0, native.PREC_F32)
+  yield c
+  c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx_bf16(native):
+  c = native.Context(0, native.PREC_BF16)
+  yield c
+  c.close()
+
+
+@pytest.fixture(scope="module")
+def a40():
+  g = np.load(os.path.join(GOLD, "align_a40.npz"))
+  vf = [g[f"vf{k}"] for k in range(5)]
+  af = [g[f"af{k}"] for k in range(5)]
+  return g, vf, af
+
+
+# ------------------------------------------------------------------------------------ features
+@pytest.mark.parametrize("name", cases.FEATURE_CLIPS)
+def test_features_vs_reference_golden(ctx, name):
+  g = np.load(os.path.join(GOLD, "features.npz"))
+  pcm = cases.feature_clip(name)
+  rows = ctx.features(pcm)
+  for k, f in enumerate(rows):
+    r = g[f"{name}.f{k}"]
+    assert f.shape == r.shape, (name, k, f.shape, r.shape)
+    # float32 arithmetic in a different summation order; tolerance 2e-5 relative + 2e-5 abs
+    np.testing.assert_allclose(f, r.astype(np.float32), rtol=2e-5, atol=2e-5, err_msg=f"{name} row {k}")
+
+
+@pytest.mark.parametrize("layout", ["planar", "interleaved"])
+def test_features_stereo_layouts_agree_with_oracle(ctx, layout):
+  pcm = cases.feature_clip("stereo")
+  want = O.features(pcm)
+  arg = pcm if layout == "planar" else np.ascontiguousarray(pcm.T)
+  rows = ctx.features(arg)
+  for f, r in zip(rows, want):
+    np.testing.assert_allclose(f, np.asarray(r, dtype=np.float32), rtol=2e-5, atol=2e-5)
+
+
+def test_features_long_clip_vs_oracle(ctx):
+  """A clip spanning many workgroup chunks (halo exchange between chunks), odd length."""
+  from describealign_amd import synth
+  pcm = synth.programme(77, 95 * 44100 + 12345).astype(np.int16)[None, :]
+  rows = ctx.features(pcm)
+  want = O.features(pcm)
+  for k, (f, r) in enumerate(zip(rows, want)):
+    assert f.shape == r.shape
+    np.testing.assert_allclose(f, np.asarray(r, dtype=np.float32), rtol=2e-5, atol=2e-5, err_msg=f"row {k}")
+
+
+def test_features_empty_and_tiny(ctx):
+  rows = ctx.features(np.zeros((1, 0), dtype=np.int16))
+  assert [len(r) for r in rows] == [0, 0, 0, 0, 0]
+  rows = ctx.features(np.ones((1, 100), dtype=np.int16))
+  assert [len(r) for r in rows] == [0, 0, 0, 0, 0]
+  pcm = cases.feature_clip("short")[:, :3000]
+  rows = ctx.features(pcm)
+  want = O.features(pcm)
+  for f, r in zip(rows, want):
+    np.testing.assert_allclose(f, np.asarray(r, dtype=np.float32), rtol=2e-5, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------ matching
+def _match_sets(i, v):
+  return set(zip(i.tolist(), v.tolist()))
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_match_equals_reference_matches(ctx, ctx_bf16, a40, prec):
+  g, vf, af = a40
+  c = ctx if prec == "f32" else ctx_bf16
+  mi, mv, mq = c.match(vf, af)
+  # sorted by (i, v)
+  key = mi.astype(np.int64) * (1 << 32) + mv
+  assert np.all(np.diff(key) > 0)
+  got, want = _match_sets(mi, mv), _match_sets(g["m_i"], g["m_v"])
+  # integer/index work: the verified match set must be identical (verification is float64)
+  assert got == want, (len(got - want), len(want - got))
+  np.testing.assert_allclose(mq, g["m_q"], rtol=1e-9)
+  st = c.stats()
+  assert st["survivors"] >= len(want) and st["gemm_pairs"] > 0
+
+
+def test_dense_mode_is_superset_and_matches_oracle_threshold(ctx, a40):
+  g, vf, af = a40
+  from describealign_amd import _native
+  mi, mv, mq = ctx.match(vf, af, mode=_native.MATCH_DENSE)
+  dense = _match_sets(mi, mv)
+  assert _match_sets(g["m_i"], g["m_v"]) <= dense
+  ms_v = [O.mean_sub(f) for f in vf]; ms_a = [O.mean_sub(f) for f in af]
+  nv = [O.window_norm(m) for m in ms_v]; na = [O.window_norm(m) for m in ms_a]
+  vr, ar = O.video_rows(vf[0]), O.audio_rows(af[0])
+  ii = np.repeat(ar, len(vr)); vv = np.tile(vr, len(ar))
+  _, keep, qual = O.verify(ii, vv, ms_v, nv, ms_a, na)
+  assert dense == _match_sets(ii[keep], vv[keep])
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-3), ("bf16", 2e-2)])
+def test_similarity_values_vs_fp64(ctx, ctx_bf16, a40, prec, tol):
+  """north_star: similarity values within 1e-3 relative (fp32 GEMM).  bf16 inputs are a
+  prefilter only (everything is re-verified in float64); their tolerance is 2e-2 absolute."""
+  g, vf, af = a40
+  c = ctx if prec == "f32" else ctx_bf16
+  c.match(vf, af)
+  ms_v = [O.mean_sub(f) for f in vf]; ms_a = [O.mean_sub(f) for f in af]
+  nv = [O.window_norm(m) for m in ms_v]; na = [O.window_norm(m) for m in ms_a]
+  rng = np.random.default_rng(0)
+  vr, ar = O.video_rows(vf[0]), O.audio_rows(af[0])
+  ii = np.concatenate([g["cand_i"], rng.choice(ar, 4000)]).astype(np.int32)
+  vv = np.concatenate([g["cand_v"], rng.choice(vr, 4000)]).astype(np.int32)
+  corr64, _, _ = O.verify(ii, vv, ms_v, nv, ms_a, na)
+  corr = c.match_corr(ii, vv)
+  if prec == "f32":
+    np.testing.assert_allclose(corr, corr64, rtol=1e-3, atol=1e-5)
+  else:
+    np.testing.assert_allclose(corr, corr64, rtol=0, atol=tol)
+
+
+def test_chain_equals_reference_path(ctx, a40):
+  g, _, _ = a40
+  pi, pv = ctx.chain(g["m_i"], g["m_v"], g["m_q"])
+  assert np.array_equal(pi, g["p1_x"]) and np.array_equal(pv, g["p1_y"])
+  # and against the oracle on a tie-heavy random instance (capped qualities produce equal sums)
+  rng = np.random.default_rng(5)
+  n = 20000
+  i = np.sort(rng.integers(0, 3000, n)); v = rng.integers(0, 800, n) * 4
+  keys = np.unique(i.astype(np.int64) * 100000 + v)
+  i, v = (keys // 100000).astype(np.int32), (keys % 100000).astype(np.int32)
+  q = rng.choice([50.0, 50.0, 12.5, 3.25], len(i))
+  idx = O.chain(i, v, q)
+  pi, pv = ctx.chain(i, v, q)
+  assert np.array_equal(pi, i[idx]) and np.array_equal(pv, v[idx])
+
+
+def test_chain_mismatch_error(ctx):
+  i = np.arange(10, dtype=np.int32); v = np.arange(10, dtype=np.int32); q = np.ones(10)
+  with pytest.raises(RuntimeError, match="Alignment failed, are the input files mismatched"):
+    ctx.chain(i, v, q, min_len=1050)
+
+
+def test_refine_equals_reference_path(ctx, a40):
+  g, vf, af = a40
+  path, npts = ctx.refine(g["a_scaled"], g["v_scaled"], g["cl_x0"], g["cl_x1"], g["cl_offset"], g["cl_slope"])
+  assert npts == len(g["pt_i"])
+  want = g["path2"].copy(); want[:, :2] *= 210.0
+  assert path.shape == want.shape
+  np.testing.assert_allclose(path[:, :3], want[:, :3], atol=1e-6)
+  np.testing.assert_allclose(path[:, 3:], want[:, 3:], atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------ end to end
+def test_align_from_reference_features(ctx, a40):
+  from describealign_amd import align as A
+  g, vf, af = a40
+  x, y, sim, path, med = A.align(vf, af, vf[0], af[0], ctx=ctx)
+  np.testing.assert_allclose(x, g["x"], atol=1e-6); np.testing.assert_allclose(y, g["y"], atol=1e-6)
+  assert abs(sim - float(g["sim"])) < 1e-6 and abs(med - float(g["med"])) < 1e-9
+  assert path.shape == g["path2"].shape
+
+
+@pytest.mark.parametrize("name,prec", [("e180", "f32"), ("e180", "bf16"), ("e180s", "f32"), ("rate2", "f32"),
+                                       ("e600", "bf16"), ("e1320", "f32")])
+def test_end_to_end_from_pcm(ctx, ctx_bf16, name, prec):
+  """PCM -> features -> align on the GPU vs the reference's recorded nodes: every node time
+  within +-23 ms (north_star), similarity within 0.5 points."""
+  from describealign_amd import align as A
+  c = ctx if prec == "f32" else ctx_bf16
+  g = np.load(os.path.join(GOLD, f"align_{name}.npz"))
+  pair = cases.align_case(name)
+  assert pair.sha1() == INDEX["align"][name]["sha1"]
+  vf = c.features(pair.video, 0); af = c.features(pair.audio, 1)
+  x, y, sim, path, med = A.align(vf, af, vf[0], af[0], ctx=c)
+  assert len(x) == len(g["x"])
+  assert np.max(np.abs(x - g["x"])) < HOP_S and np.max(np.abs(y - g["y"])) < HOP_S
+  assert abs(sim - float(g["sim"])) < 0.5 and abs(med - float(g["med"])) < 1e-4
+
+
+def test_mismatched_pair_raises(ctx):
+  from describealign_amd import align as A
+  pair = cases.align_case("mismatch")
+  vf = ctx.features(pair.video, 0); af = ctx.features(pair.audio, 1)
+  with pytest.raises(RuntimeError, match="Alignment failed, are the input files mismatched"):
+    A.align(vf, af, vf[0], af[0], ctx=ctx)
