@@ -1,0 +1,242 @@
+"""combine() and the command line: the entry points of describealign kept by this build
+(reference describealign.py:1031-1175, :1773-1849), with the compute section running on
+MI355X.  For every (video, audio description) pair: decode PCM, extract features, align, warn
+on suspicious similarity, write the alignment plot + text report, and -- when an ffmpeg binary
+is available -- mux the described audio onto the re-timed video with the same `setts`
+bitstream-filter command line the reference issues.
+
+A directory batch shards across GPUs with no collectives: pair k goes to GPU k % gpus, one
+worker process per GPU (`--gpus`).
+
+Out of scope here: --stretch_audio (replace_aligned_segments), the GUI.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+from . import REFERENCE_VERSION, __version__
+from . import media, report
+
+VIDEO_EXTENSIONS = set(['mp4', 'mkv', 'avi', 'mov', 'webm', 'm4v', 'flv', 'vob'])
+AUDIO_EXTENSIONS = set(['mp3', 'm4a', 'opus', 'wav', 'aac', 'flac', 'ac3', 'mka'])
+default_output_dir = os.path.expanduser('~') + '/videos_with_ad'
+default_alignment_dir = os.path.expanduser('~') + '/alignment_plots'
+
+
+def _natural_key(path):
+  return [int(tok) if tok.isdigit() else tok.lower() for tok in re.split(r'(\d+)', os.path.basename(path))]
+
+
+def ensure_folders_exist(dirs):
+  for d in dirs:
+    if not os.path.isdir(d):
+      print(f"Directory not found, creating it: {d}")
+      os.makedirs(d)
+
+
+def get_sorted_filenames(path, extensions, alt_extensions=set([])):
+  """A file, a directory or a list of files -> naturally sorted matching files and a flag per
+  file telling whether it only matched the alternative extensions (:94-121)."""
+  if type(path) is list:
+    files = [os.path.abspath(f) for f in path]
+    for f in files:
+      if not os.path.isfile(f):
+        raise RuntimeError(f"No file found at input path:\n  {f}")
+  else:
+    path = os.path.abspath(path)
+    if os.path.isdir(path):
+      files = glob.glob(glob.escape(path) + "/*")
+      if len(files) == 0:
+        raise RuntimeError(f"Empty input directory:\n  {path}")
+    else:
+      if not os.path.isfile(path):
+        raise RuntimeError(f"No file or directory found at input path:\n  {path}")
+      files = [path]
+  ext_of = lambda f: os.path.splitext(f)[1][1:]
+  files = [f for f in files if ext_of(f) in extensions | alt_extensions]
+  if len(files) == 0:
+    raise RuntimeError("\n".join([
+        f"No files with valid extensions found at input path:\n  {path}",
+        "Did you accidentally put the audio filepath before the video filepath?",
+        "The video path should be the first positional input, audio second.",
+        "Or maybe you need to add a new extension to this script's regex?",
+        f"valid extensions for this input are:\n  {extensions}"]))
+  files = sorted(files, key=_natural_key)
+  return files, [0 if ext_of(f) in extensions else 1 for f in files]
+
+
+from .distrib import shard_pairs  # noqa: E402  (round-robin pair -> GPU assignment)
+
+
+def _mux_command(ffmpeg, video_file, audio_desc_file, output_filename, setts_cmd, video_offset,
+                 after_start_key_frame, median_slope):
+  """ffmpeg argv for the default (video re-timing) output, same options as :489-510."""
+  start_offset = video_offset - after_start_key_frame
+  audio_codec = 'copy' if os.path.splitext(audio_desc_file)[1] != '.wav' else 'aac'
+  standards = 'normal' if os.path.splitext(audio_desc_file)[1] != '.flac' else 'experimental'
+  sub_stretch = f":duration='DURATION*{1. / median_slope:.6f}'"
+  return [ffmpeg, "-itsoffset", f"{max(0, start_offset):.6f}", "-i", audio_desc_file,
+          "-an", "-ss", f"{after_start_key_frame:.6f}", "-itsoffset", f"{max(0, -start_offset):.6f}", "-dn",
+          "-i", video_file, "-map", "0", "-map", "1",
+          "-acodec", audio_codec, "-vcodec", "copy", "-scodec", "copy", "-max_interleave_delta", "0",
+          "-loglevel", "error", "-strict", standards, "-movflags", "frag_keyframe",
+          "-bsf:v", f"setts=pts='{setts_cmd}':dts='{setts_cmd}'", "-bsf:s", f"setts=ts='{setts_cmd}'" + sub_stretch,
+          "-disposition:a:0", "default+visual_impaired+descriptions", "-metadata:s:a:0", "title=AD",
+          output_filename, "-y"]
+
+
+def process_pair(video_file, audio_desc_file, has_audio_extension, ctx, stretch_audio=False, prepend="ad_",
+                 no_pitch_correction=False, output_dir=default_output_dir, alignment_dir=default_alignment_dir):
+  """One iteration of the reference's per-pair loop (:1077-1174)."""
+  from . import _native
+  from .align import align
+  output_filename = os.path.join(output_dir, prepend + os.path.split(video_file)[1])
+  print(f" {output_filename}")
+  if (not stretch_audio) & has_audio_extension:
+    raise RuntimeError("Argument --stretch_audio is required when both inputs are audio files.")
+  if stretch_audio:
+    raise NotImplementedError("--stretch_audio (replace_aligned_segments) is outside this build's scope")
+  if os.path.exists(output_filename) and os.path.getsize(output_filename) > 1e5:
+    print("   output file already exists, skipping...")
+    return None
+  num_channels = 2 if stretch_audio else 1
+  print("  reading video file...\r", end='')
+  video_arr = media.parse_audio_from_file(video_file, num_channels)
+  print("  computing video features... \r", end='')
+  video_features = ctx.features(video_arr, _native.SIDE_VIDEO)
+  del video_arr
+  print("  reading audio file...       \r", end='')
+  audio_desc_arr = media.parse_audio_from_file(audio_desc_file, num_channels)
+  print("  computing audio features...\r", end='')
+  audio_desc_features = ctx.features(audio_desc_arr, _native.SIDE_AUDIO)
+  del audio_desc_arr
+  outputs = align(video_features, audio_desc_features, video_features[0], audio_desc_features[0], ctx=ctx)
+  audio_desc_times, video_times, similarity_percent, path, median_slope = outputs
+  if similarity_percent < 20:
+    print(f"  WARNING: similarity {similarity_percent:.1f}%, likely mismatched files")
+  if similarity_percent > 90:
+    print(f"  WARNING: similarity {similarity_percent:.1f}%, likely undescribed media")
+  if (median_slope < .1) or (median_slope > 10):
+    print("  WARNING: median slope estimation failed, output subtitles may be misaligned")
+    median_slope = 1.
+  video_offset = video_times[0] - audio_desc_times[0]
+  setts_cmd = report.encode_fit_as_ffmpeg_expr(audio_desc_times, video_times, video_offset)
+  ffmpeg_command = ""
+  ffmpeg = media.find_ffmpeg()
+  if ffmpeg is not None and not has_audio_extension:
+    print("  processing output file...                   \r", end='')
+    # without ffprobe's key-frame table the cut point is the offset itself
+    argv = _mux_command(ffmpeg, video_file, audio_desc_file, output_filename, setts_cmd, video_offset,
+                        max(0.0, video_offset), median_slope)
+    res = subprocess.run(argv, capture_output=True)
+    if res.returncode != 0:
+      print("  ERROR: ffmpeg failed to write output file: " + output_filename)
+      print(res.stderr.decode("utf-8", "replace"))
+      raise RuntimeError("FFmpeg error.")
+    ffmpeg_command = subprocess.list2cmdline(argv).replace('\\', '/')
+  else:
+    ffmpeg_command = f"(no ffmpeg binary on PATH; output not muxed) setts expression: {setts_cmd}"
+  stem = os.path.join(alignment_dir, os.path.splitext(os.path.split(video_file)[1])[0])
+  report.plot_alignment(stem, path, audio_desc_times, video_times, similarity_percent, median_slope,
+                        stretch_audio, no_pitch_correction, ffmpeg_command)
+  return dict(audio_desc_times=audio_desc_times, video_times=video_times, similarity_percent=similarity_percent,
+              median_slope=median_slope, setts=setts_cmd, report=stem + ".txt")
+
+
+def _worker(gpu, indices, pairs, kwargs, precision):
+  from . import _native
+  ctx = _native.Context(gpu, precision)
+  for k in indices:
+    v, a, alt = pairs[k]
+    process_pair(v, a, alt, ctx, **kwargs)
+  ctx.close()
+
+
+def combine(video, audio, stretch_audio=False, yes=False, prepend="ad_", no_pitch_correction=False,
+            output_dir=default_output_dir, alignment_dir=default_alignment_dir, gpus=1, precision="f32", device=0):
+  """Same signature as the reference's combine() (:1031-1032) plus gpus/precision/device."""
+  from . import _native
+  video_files, has_audio_extensions = get_sorted_filenames(video, VIDEO_EXTENSIONS, AUDIO_EXTENSIONS)
+  if yes == False and sum(has_audio_extensions) > 0:
+    print("")
+    print("One or more audio files found in video input. Was this intentional?")
+    print("If not, press ctrl+c to kill this script.")
+    input("If this was intended, press Enter to continue...")
+    print("")
+  audio_desc_files, _ = get_sorted_filenames(audio, AUDIO_EXTENSIONS)
+  if len(video_files) != len(audio_desc_files):
+    raise RuntimeError("\n".join(["Number of valid files in input paths are not the same.",
+                                  f"The video path has {len(video_files)} files",
+                                  f"The audio path has {len(audio_desc_files)} files"]))
+  print("")
+  ensure_folders_exist([output_dir, alignment_dir])
+  print("")
+  for v, a in zip(video_files, audio_desc_files):
+    print(os.path.split(v)[1])
+    print(os.path.split(a)[1])
+    print("")
+  if yes == False:
+    print("Are the above input file pairings correct?")
+    print("If not, press ctrl+c to kill this script.")
+    input("If they are correct, press Enter to continue...")
+    print("")
+  print(f"Processing files with describealign_amd v{__version__} (reproducing describealign v{REFERENCE_VERSION}):")
+  prec = _native.PREC_F32 if precision == "f32" else _native.PREC_BF16
+  pairs = list(zip(video_files, audio_desc_files, has_audio_extensions))
+  kwargs = dict(stretch_audio=stretch_audio, prepend=prepend, no_pitch_correction=no_pitch_correction,
+                output_dir=output_dir, alignment_dir=alignment_dir)
+  if gpus <= 1 or len(pairs) <= 1:
+    _worker(device, range(len(pairs)), pairs, kwargs, prec)
+  else:
+    import multiprocessing as mp
+    mpctx = mp.get_context("spawn")
+    procs = [mpctx.Process(target=_worker, args=(g, idx, pairs, kwargs, prec))
+             for g, idx in enumerate(shard_pairs(len(pairs), gpus)) if idx]
+    for p in procs:
+      p.start()
+    for p in procs:
+      p.join()
+    if any(p.exitcode != 0 for p in procs):
+      raise RuntimeError("one or more GPU workers failed")
+  print("All files processed.       ")
+
+
+def command_line_interface(argv=None):
+  """Same flags as the reference CLI (:1791-1817) plus --gpus / --precision / --device."""
+  parser = argparse.ArgumentParser(description="Replaces a video's sound with an audio description.",
+                                   usage="describealign_amd video_file.mp4 audio_file.mp3")
+  parser.add_argument("video", help='A video file or directory containing video files.', nargs='?', default=None)
+  parser.add_argument("audio", help='An audio file or directory containing audio files.', nargs='?', default=None)
+  parser.add_argument('--stretch_audio', action='store_true',
+                      help='Stretches the input audio to fit the input video (not available in this build).')
+  parser.add_argument('--yes', action='store_true', help='Auto-skips user prompts asking to verify information.')
+  parser.add_argument("--prepend", default="ad_", help='Output file name prepend text. Default is "ad_"')
+  parser.add_argument('--no_pitch_correction', action='store_true',
+                      help='Skips pitch correction step when stretching audio.')
+  parser.add_argument("--output_dir", default=default_output_dir,
+                      help='Directory combined output media is saved to. Default is "videos_with_ad"')
+  parser.add_argument("--alignment_dir", default=default_alignment_dir,
+                      help='Directory alignment data and plots are saved to. Default is "alignment_plots"')
+  parser.add_argument('--version', action='store_true', help='Prints the installed version.')
+  parser.add_argument('--gpus', type=int, default=1, help='Shard a directory batch over this many GPUs.')
+  parser.add_argument('--device', type=int, default=0, help='GPU index for single-GPU runs.')
+  parser.add_argument('--precision', choices=['f32', 'bf16'], default='f32', help='Similarity GEMM input precision.')
+  args = parser.parse_args(argv)
+  if args.version:
+    print(f"version: {__version__} (describealign {REFERENCE_VERSION} results)")
+  elif args.video and args.audio:
+    combine(args.video, args.audio, args.stretch_audio, args.yes, args.prepend, args.no_pitch_correction,
+            args.output_dir, args.alignment_dir, gpus=args.gpus, precision=args.precision, device=args.device)
+  else:
+    parser.print_usage()
+
+
+if __name__ == "__main__":
+  command_line_interface()
