@@ -154,15 +154,77 @@ __device__ inline void sink_push(SurvSink& sk, const MatchArgs& a, int lane, boo
   sk.count += n;
 }
 
-__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_match_f32(MatchArgs a) {
+// Software pipeline (one wave per SIMD, 512-VGPR budget): while the 63 MFMAs of tile t run, the
+// operand loads of tile t+1 are in flight and the threshold epilogue of tile t-1 is interleaved
+// between the MFMAs (VALU and matrix pipes overlap).  Two register sets are ping-ponged by
+// unrolling the tile loop by two, so nothing is copied.
+struct TileMeta {
+  float inv[3];
+  int32_t ic;
+  bool ok;
+};
+
+__device__ __forceinline__ void load_tile_b(const MatchArgs& a, int64_t at, int64_t a_end, int r, int h,
+                                            float (&b)[3][21], TileMeta& m) {
+  const int64_t ia = at + r;
+  m.ok = ia < a_end;
+  m.ic = a.alist[m.ok ? ia : a_end - 1];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float* p = a.ms_a[j] + m.ic + h;
+#pragma unroll
+    for (int s = 0; s < 21; ++s) b[j][s] = p[2 * s];
+    m.inv[j] = a.inv_a[j][m.ic];
+  }
+}
+
+__device__ __forceinline__ uint32_t threshold_row(const f32x16 (&acc)[3], const TileMeta& m, int g, float thr) {
+  const float t0 = fmaf(acc[0][g], m.inv[0], 1.0f);
+  const float t1 = fmaf(acc[1][g], m.inv[1], 1.0f);
+  const float t2 = fmaf(acc[2][g], m.inv[2], 1.0f);
+  return (t0 * t1 * t2 <= thr) ? (1u << g) : 0u;
+}
+
+// MFMAs of the current tile into acc, with the epilogue of the previous tile (accp/prev)
+// spread between them; returns the previous tile's pass mask (bit g = accumulator register g).
+__device__ __forceinline__ uint32_t mfma_tile_f32(const float (&A)[3][21], const float (&b)[3][21], f32x16 (&acc)[3],
+                                                  const f32x16 (&accp)[3], const TileMeta& prev, float thr) {
+  uint32_t mask = 0;
+#pragma unroll
+  for (int s = 0; s < 21; ++s) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][s], b[0][s], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][s], b[1][s], acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[2][s], b[2][s], acc[2], 0, 0, 0);
+    if (s < 16) mask |= threshold_row(accp, prev, s, thr);
+  }
+  return prev.ok ? mask : 0u;
+}
+
+__device__ __forceinline__ void emit_tile(SurvSink& sk, const MatchArgs& a, int lane, int h, int64_t vt0, uint32_t mask, int32_t ic) {
+  if (__ballot(mask != 0u) == 0ull) return;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
+    const int64_t vrr = vt0 + row;
+    const bool p = ((mask >> g) & 1u) && vrr < a.n_v;
+    unsigned long long rec = 0;
+    if (p) rec = ((unsigned long long)(uint32_t)ic << 32) | (uint32_t)a.vlist[vrr];
+    sink_push(sk, a, lane, p, rec);
+  }
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock, 1) void k_match_f32(MatchArgs a) {
   __shared__ unsigned long long s_surv[kWavesPerBlock][kSurvBuf];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int64_t vt0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 32;
   SurvSink sk{s_surv[wave], 0};
-  if (vt0 < a.n_v) {
-    // fixed operand: 32 video rows
+  const int64_t a_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block * 32;
+  int64_t a_end = a_begin + (int64_t)a.audio_tiles_per_block * 32;
+  if (a_end > a.n_a) a_end = a.n_a;
+  if (vt0 < a.n_v && a_begin < a_end) {
+    // fixed operand: 32 video rows, pre-scaled by -1/|V|
     const int64_t vr = vt0 + r;
     const bool vok = vr < a.n_v;
     const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
@@ -174,45 +236,47 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_match_f32(MatchArgs 
 #pragma unroll
       for (int s = 0; s < 21; ++s) A[j][s] = (2 * s + h < kWin) ? p[2 * s] * sc : 0.f;
     }
-    const int64_t a_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block * 32;
-    int64_t a_end = a_begin + (int64_t)a.audio_tiles_per_block * 32;
-    if (a_end > a.n_a) a_end = a.n_a;
-    for (int64_t at = a_begin; at < a_end; at += 32) {
-      const int64_t ia = at + r;
-      const bool aok = ia < a_end;
-      const int32_t ic = a.alist[aok ? ia : a_end - 1];
-      f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0};
-      const float* p0 = a.ms_a[0] + ic + h;
-      const float* p1 = a.ms_a[1] + ic + h;
-      const float* p2 = a.ms_a[2] + ic + h;
-      float B0[21], B1[21], B2[21];
+    float b0[3][21], b1[3][21];
+    TileMeta m0, m1;
+    f32x16 acc0[3], acc1[3];
 #pragma unroll
-      for (int s = 0; s < 21; ++s) { B0[s] = p0[2 * s]; B1[s] = p1[2 * s]; B2[s] = p2[2 * s]; }
+    for (int j = 0; j < 3; ++j) acc1[j] = f32x16{0};
+    m1.ok = false; m1.ic = 0; m1.inv[0] = m1.inv[1] = m1.inv[2] = 0.f;
+    load_tile_b(a, a_begin, a_end, r, h, b0, m0);
+    int64_t at = a_begin;
+    while (true) {
+      // ---- even phase: MFMAs of (b0, m0) -> acc0; epilogue of (acc1, m1); prefetch into (b1, m1)
+      {
+        const TileMeta prev = m1;
+        if (at + 32 < a_end) load_tile_b(a, at + 32, a_end, r, h, b1, m1);
 #pragma unroll
-      for (int s = 0; s < 21; ++s) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][s], B0[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][s], B1[s], acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[2][s], B2[s], acc2, 0, 0, 0);
+        for (int j = 0; j < 3; ++j) acc0[j] = f32x16{0};
+        const uint32_t mask = mfma_tile_f32(A, b0, acc0, acc1, prev, a.thr);
+        emit_tile(sk, a, lane, h, vt0, mask, prev.ic);
+        at += 32;
+        if (at >= a_end) {      // drain: epilogue of the last tile
+          uint32_t m = 0;
+#pragma unroll
+          for (int g = 0; g < 16; ++g) m |= threshold_row(acc0, m0, g, a.thr);
+          emit_tile(sk, a, lane, h, vt0, m0.ok ? m : 0u, m0.ic);
+          break;
+        }
       }
-      const float i0 = a.inv_a[0][ic], i1 = a.inv_a[1][ic], i2 = a.inv_a[2][ic];
-      bool any = false;
-      bool pass[16];
+      // ---- odd phase: MFMAs of (b1, m1) -> acc1; epilogue of (acc0, m0); prefetch into (b0, m0)
+      {
+        const TileMeta prev = m0;
+        if (at + 32 < a_end) load_tile_b(a, at + 32, a_end, r, h, b0, m0);
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const float t0 = fmaf(acc0[g], i0, 1.0f);
-        const float t1 = fmaf(acc1[g], i1, 1.0f);
-        const float t2 = fmaf(acc2[g], i2, 1.0f);
-        pass[g] = aok && (t0 * t1 * t2 <= a.thr);
-        any |= pass[g];
-      }
-      if (__ballot(any) != 0ull) {
+        for (int j = 0; j < 3; ++j) acc1[j] = f32x16{0};
+        const uint32_t mask = mfma_tile_f32(A, b1, acc1, acc0, prev, a.thr);
+        emit_tile(sk, a, lane, h, vt0, mask, prev.ic);
+        at += 32;
+        if (at >= a_end) {
+          uint32_t m = 0;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
-          const int64_t vrr = vt0 + row;
-          unsigned long long rec = 0;
-          if (pass[g]) rec = ((unsigned long long)(uint32_t)ic << 32) | (uint32_t)a.vlist[vrr < a.n_v ? vrr : a.n_v - 1];
-          sink_push(sk, a, lane, pass[g] && vrr < a.n_v, rec);
+          for (int g = 0; g < 16; ++g) m |= threshold_row(acc1, m1, g, a.thr);
+          emit_tile(sk, a, lane, h, vt0, m1.ok ? m : 0u, m1.ic);
+          break;
         }
       }
     }
