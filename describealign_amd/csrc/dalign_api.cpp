@@ -40,7 +40,7 @@ struct Side {
   DevBuf feat; int64_t feat_stride = 0; int64_t len[2] = {0, 0};
   // match-prep buffers
   DevBuf mfeat;                  // 5 rows uploaded by da_match
-  DevBuf ms[5], nrm[5], dig[5], flg[5], ms32[3], inv32[3], bfe[3], bfo[3];
+  DevBuf ms[5], nrm[5], dig[5], flg[5], ms32[3], inv32[3], nrm32[3], prod32, bfe[3], bfo[3];
   int64_t mlen[5] = {0, 0, 0, 0, 0}; int64_t lmax = 0;
 };
 
@@ -161,7 +161,8 @@ void da_destroy(da_ctx* c) {
   for (Side& s : c->side) {
     s.pcm.release(); s.feat.release(); s.mfeat.release();
     for (int j = 0; j < 5; ++j) { s.ms[j].release(); s.nrm[j].release(); s.dig[j].release(); s.flg[j].release(); }
-    for (int j = 0; j < 3; ++j) { s.ms32[j].release(); s.inv32[j].release(); s.bfe[j].release(); s.bfo[j].release(); }
+    for (int j = 0; j < 3; ++j) { s.ms32[j].release(); s.inv32[j].release(); s.nrm32[j].release(); s.bfe[j].release(); s.bfo[j].release(); }
+    s.prod32.release();
   }
   DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->counters, &c->keys0, &c->keys1,
                    &c->q0, &c->q1, &c->sort_tmp, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
@@ -270,9 +271,11 @@ int upload_and_prep(da_ctx* c, Side& s, const float* feat, int64_t stride, const
   for (int j = 0; j < 3; ++j) {
     HIP_TRY(c, s.ms32[j].ensure(sizeof(float) * n)); p.ms32[j] = s.ms32[j].as<float>();
     HIP_TRY(c, s.inv32[j].ensure(sizeof(float) * n)); p.inv32[j] = s.inv32[j].as<float>();
+    HIP_TRY(c, s.nrm32[j].ensure(sizeof(float) * n)); p.nrm32[j] = s.nrm32[j].as<float>();
     HIP_TRY(c, s.bfe[j].ensure(sizeof(uint16_t) * n + 64)); p.bf_even[j] = s.bfe[j].as<uint16_t>();
     HIP_TRY(c, s.bfo[j].ensure(sizeof(uint16_t) * n + 64)); p.bf_odd[j] = s.bfo[j].as<uint16_t>();
   }
+  HIP_TRY(c, s.prod32.ensure(sizeof(float) * n)); p.prod32 = s.prod32.as<float>();
   launch_prep(p, c->hann41.as<double>(), c->stream);
   HIP_TRY(c, hipGetLastError());
   return DA_OK;
@@ -322,9 +325,11 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
   for (int j = 0; j < 3; ++j) {
     m.ms_v[j] = V.ms32[j].as<float>(); m.ms_a[j] = A.ms32[j].as<float>();
     m.inv_v[j] = V.inv32[j].as<float>(); m.inv_a[j] = A.inv32[j].as<float>();
+    m.nrm_a[j] = A.nrm32[j].as<float>();
     m.bfa_even[j] = A.bfe[j].as<uint16_t>(); m.bfa_odd[j] = A.bfo[j].as<uint16_t>();
     m.msd_v[j] = V.ms[j].as<double>();
   }
+  m.prod_a = A.prod32.as<float>();
   m.vlist = c->vlist.as<int32_t>(); m.n_v = n_v;
   m.alist = c->alist.as<int32_t>(); m.n_a = n_a;
   const double thr_exact = std::pow(1e-8, 1.0 / 2.9);
@@ -371,8 +376,7 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
   // exact verification + sort
   unsigned long long n_match = 0;
   if (n_surv > 0) {
-    HIP_TRY(c, c->keys0.ensure(sizeof(unsigned long long) * n_surv)); HIP_TRY(c, c->keys1.ensure(sizeof(unsigned long long) * n_surv));
-    HIP_TRY(c, c->q0.ensure(sizeof(double) * n_surv)); HIP_TRY(c, c->q1.ensure(sizeof(double) * n_surv));
+    size_t mcap = (size_t)n_surv + (size_t)n_surv / 2 + 1024;     // verified matches are a fraction of the expanded pairs
     VerifyArgs v{};
     v.surv = c->surv.as<unsigned long long>(); v.capacity = cap;
     for (int j = 0; j < 3; ++j) {
@@ -383,13 +387,25 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
       v.dig_v[j] = V.dig[j].as<uint32_t>(); v.flg_v[j] = V.flg[j].as<uint32_t>(); v.dig_a[j] = A.dig[j].as<uint32_t>();
     }
     v.mode = mode;
-    v.keys = c->keys0.as<unsigned long long>(); v.quals = c->q0.as<double>();
-    v.n_out = d_cnt + 1; v.out_capacity = n_surv;
+    v.vlist = c->vlist.as<int32_t>(); v.n_v = n_v; v.n_pairs = d_cnt + 2;
+    v.n_out = d_cnt + 1;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    launch_verify(v, n_surv, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(&n_match, d_cnt + 1, sizeof n_match, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long n_pairs = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      HIP_TRY(c, c->keys0.ensure(sizeof(unsigned long long) * mcap)); HIP_TRY(c, c->keys1.ensure(sizeof(unsigned long long) * mcap));
+      HIP_TRY(c, c->q0.ensure(sizeof(double) * mcap)); HIP_TRY(c, c->q1.ensure(sizeof(double) * mcap));
+      v.keys = c->keys0.as<unsigned long long>(); v.quals = c->q0.as<double>(); v.out_capacity = mcap;
+      HIP_TRY(c, hipMemsetAsync(d_cnt + 1, 0, 2 * sizeof(unsigned long long), c->stream));
+      launch_verify(v, n_surv, c->stream);
+      HIP_TRY(c, hipGetLastError());
+      HIP_TRY(c, hipMemcpyAsync(&n_match, d_cnt + 1, sizeof n_match, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(&n_pairs, d_cnt + 2, sizeof n_pairs, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (n_match <= mcap) break;
+      if (attempt == 1) return fail(c, DA_ERR_DEVICE, "da_match: match list kept overflowing");
+      mcap = (size_t)n_match + 1024;
+    }
+    c->st.survivors = (double)n_pairs;
     if (n_match > 0) {
       size_t tmp_bytes = 0;
       if (sort_pairs(nullptr, nullptr, nullptr, nullptr, (int64_t)n_match, nullptr, &tmp_bytes, c->stream) != 0)

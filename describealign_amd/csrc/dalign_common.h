@@ -51,6 +51,8 @@ struct PrepArgs {
   uint32_t* flags[5];     // video only: ~(probe-next flags at bit 0 of each nibble)
   float* ms32[3];         // float32 copy of ms (features 0-2), padded
   float* inv32[3];        // 1/norm as float32
+  float* nrm32[3];        // norm as float32
+  float* prod32;          // nrm0*nrm1*nrm2 as float32 (per-frame threshold scale)
   uint16_t* bf_even[3];   // bf16 copy of ms: element e at [e]
   uint16_t* bf_odd[3];    // bf16 copy of ms shifted by one: element e+1 at [e]
 };
@@ -60,11 +62,12 @@ void launch_prep(const PrepArgs& a, const double* d_hann41n, hipStream_t s);
 struct MatchArgs {
   const float* ms_v[3]; const float* ms_a[3];
   const float* inv_v[3]; const float* inv_a[3];
+  const float* nrm_a[3]; const float* prod_a;                 // f32 GEMM: audio norms and their product
   const uint16_t* bfa_even[3]; const uint16_t* bfa_odd[3];   // audio side bf16 copies
   const double* msd_v[3];                                     // for building bf16 A fragments
   const int32_t* vlist; int64_t n_v;      // every 4th non-quiet video frame (:629-630)
   const int32_t* alist; int64_t n_a;      // non-quiet audio frames within the requested rows (:657-658)
-  unsigned long long* out;                // survivors: (i << 32) | v
+  unsigned long long* out;                // staged survivor records (see pack_record)
   unsigned long long* out_count;
   unsigned long long capacity;
   float thr;                              // (1e-8)^(1/2.9) times the precision's safety margin
@@ -85,6 +88,8 @@ struct VerifyArgs {
   const double* nrm_v[3]; const double* nrm_a[3];
   const uint32_t* dig_v[5]; const uint32_t* flg_v[5]; const uint32_t* dig_a[5];
   int mode;
+  const int32_t* vlist; int64_t n_v;      // to expand staged records (video tile, row mask)
+  unsigned long long* n_pairs;            // number of (i, v) pairs the records expand to
   unsigned long long* keys; double* quals; unsigned long long* n_out; unsigned long long out_capacity;
 };
 void launch_verify(const VerifyArgs& a, unsigned long long n_surv_host, hipStream_t s);

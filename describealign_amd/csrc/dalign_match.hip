@@ -15,6 +15,7 @@ namespace da {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load, 4-byte aligned
 
 // ------------------------------------------------------------------------------------------
 // prep: mean subtraction (:598-599, :605-606), window norms (:600-602), hash digits (:623-628,
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
       a.nrm[j][i] = 1.0;
       a.digits[j][i] = 0xFFFFFFFFu;          // never matches
       if (a.is_video) a.flags[j][i] = 0xFFFFFFFFu;
-      if (j < 3) a.inv32[j][i] = 0.f;
+      if (j < 3) { a.inv32[j][i] = 0.f; a.nrm32[j][i] = 1.f; }
     }
     return;
   }
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
   double nr = sqrt(ss);
   nr = nr < 0.001 ? 0.001 : nr;
   a.nrm[j][i] = nr;
-  if (j < 3) a.inv32[j][i] = (float)(1.0 / nr);
+  if (j < 3) { a.inv32[j][i] = (float)(1.0 / nr); a.nrm32[j][i] = (float)nr; }
   uint32_t dig = 0, flg = 0;
 #pragma unroll
   for (int b = 0; b < kTaps; ++b) {
@@ -100,11 +101,18 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_prep_prod(PrepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.lmax + kPad) return;
+  a.prod32[i] = (float)(a.nrm[0][i] * a.nrm[1][i] * a.nrm[2][i]);
+}
+
 void launch_prep(const PrepArgs& a, const double* d_hann41n, hipStream_t s) {
   const int64_t n = a.lmax + kPad;
   dim3 grid((unsigned)((n + 255) / 256), 5);
   hipLaunchKernelGGL(k_prep_ms, grid, dim3(256), 0, s, a, d_hann41n);
   hipLaunchKernelGGL(k_prep_norm, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_prep_prod, dim3(grid.x), dim3(256), 0, s, a);
 }
 
 // hash vote in closed form: feature j "hits" when every audio digit equals
@@ -118,8 +126,9 @@ __device__ inline bool digit_hit(uint32_t a_guarded, uint32_t v_dig, uint32_t v_
 // similarity GEMM, float32 inputs on v_mfma_f32_32x32x2_f32
 //
 // Tile: one wave owns 32 video rows (MFMA A operand, held in 63 VGPRs for the whole launch,
-// pre-scaled by -1/|V|) and streams 32 audio columns at a time (MFMA B operand: each lane loads
-// A_j[i_c + 2s + h] straight from L1/L2 - lanes of a half-wave read consecutive floats).
+// pre-scaled by -1/|V|) and streams 32 audio columns at a time (MFMA B operand, straight from
+// L1/L2).  The K index is permuted (lane half h, step s -> k = 21 h + s; k = 41 is the zero pad)
+// so that each lane's operands are 21 consecutive floats.
 // acc = -<A,V>/|V|;  t_j = 1 + acc * (1/|A|_i) = 1 - corr_j;  survivor when t_0 t_1 t_2 <= thr.
 // ------------------------------------------------------------------------------------------
 constexpr int kWavesPerBlock = 4;
@@ -148,7 +157,7 @@ __device__ inline void sink_push(SurvSink& sk, const MatchArgs& a, int lane, boo
   const int n = __popcll(m);
   if (sk.count + n > kSurvBuf) sink_flush(sk, a, lane);
   if (pass) {
-    const int pos = sk.count + __popcll(m & ((1ull << lane) - 1ull));
+    const int pos = sk.count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     sk.s_buf[pos] = rec;
   }
   sk.count += n;
@@ -159,58 +168,107 @@ __device__ inline void sink_push(SurvSink& sk, const MatchArgs& a, int lane, boo
 // between the MFMAs (VALU and matrix pipes overlap).  Two register sets are ping-ponged by
 // unrolling the tile loop by two, so nothing is copied.
 struct TileMeta {
-  float inv[3];
+  float thr;      // threshold of this lane's audio column: thr * |A|_0 |A|_1 |A|_2
   int32_t ic;
   bool ok;
 };
 
-__device__ __forceinline__ void load_tile_b(const MatchArgs& a, int64_t at, int64_t a_end, int r, int h,
+// audio frame number of column r of the tile starting at list position `at` (clamped at the end)
+__device__ __forceinline__ int32_t fetch_index(const MatchArgs& a, int64_t at, int64_t a_end, int r) {
+  int64_t ia = at + r;
+  if (ia >= a_end) ia = a_end - 1;
+  return a.alist[ia];
+}
+
+// Issue the operand loads of the tile at list position `at`, whose frame numbers `ic` were fetched
+// one phase earlier (a dependent index->operand load chain at the head of every phase would
+// expose a full memory round trip with no MFMA in flight).
+__device__ __forceinline__ void load_tile_b(const MatchArgs& a, int64_t at, int64_t a_end, int r, int h, int32_t ic,
                                             float (&b)[3][21], TileMeta& m) {
-  const int64_t ia = at + r;
-  m.ok = ia < a_end;
-  m.ic = a.alist[m.ok ? ia : a_end - 1];
+  m.ok = (at + r) < a_end;
+  m.ic = ic;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const float* p = a.ms_a[j] + m.ic + h;
+    // K permutation: lanes with h = 0 hold k = s, lanes with h = 1 hold k = 21 + s, so a lane's 21
+    // operands are contiguous: 5 x 16-byte + 1 x 4-byte loads (4-byte aligned) instead of 21 dword
+    // loads -- a wave may only have 63 vector-memory operations in flight (6-bit vmcnt).
+    const float* p = a.ms_a[j] + m.ic + 21 * h;
 #pragma unroll
-    for (int s = 0; s < 21; ++s) b[j][s] = p[2 * s];
-    m.inv[j] = a.inv_a[j][m.ic];
+    for (int q = 0; q < 5; ++q) {
+      const f32x4u w = *reinterpret_cast<const f32x4u*>(p + 4 * q);
+      b[j][4 * q + 0] = w[0]; b[j][4 * q + 1] = w[1]; b[j][4 * q + 2] = w[2]; b[j][4 * q + 3] = w[3];
+    }
+    // last K slot: k = 20 for h = 0; for h = 1 it is the spare slot k = 41, which carries the audio
+    // window norm (the A operand holds 1 there), so the accumulator ends as |A| - <A,V>/|V| = |A| (1 - corr)
+    b[j][20] = h ? a.nrm_a[j][m.ic] : p[20];
   }
+  m.thr = a.thr * a.prod_a[m.ic];
 }
 
-__device__ __forceinline__ uint32_t threshold_row(const f32x16 (&acc)[3], const TileMeta& m, int g, float thr) {
-  const float t0 = fmaf(acc[0][g], m.inv[0], 1.0f);
-  const float t1 = fmaf(acc[1][g], m.inv[1], 1.0f);
-  const float t2 = fmaf(acc[2][g], m.inv[2], 1.0f);
-  return (t0 * t1 * t2 <= thr) ? (1u << g) : 0u;
+// acc_j = |A|_j (1 - corr_j); survivor when prod_j acc_j <= thr |A|_0 |A|_1 |A|_2 (same test as
+// prod_j (1 - corr_j) <= thr, with the per-column norms folded into the threshold)
+__device__ __forceinline__ uint32_t threshold_row(const f32x16 (&acc)[3], const TileMeta& m, int g, float) {
+  return (acc[0][g] * acc[1][g] * acc[2][g] <= m.thr) ? (1u << g) : 0u;
 }
 
-// MFMAs of the current tile into acc, with the epilogue of the previous tile (accp/prev)
-// spread between them; returns the previous tile's pass mask (bit g = accumulator register g).
-__device__ __forceinline__ uint32_t mfma_tile_f32(const float (&A)[3][21], const float (&b)[3][21], f32x16 (&acc)[3],
-                                                  const f32x16 (&accp)[3], const TileMeta& prev, float thr) {
+// Survivors of one tile: mask bit g <-> accumulator register g of this lane.  Each lane that has
+// any stages ONE compact record  [63:41] audio frame | [40:17] video tile | [16] lane half | [15:0] mask
+// (wave-aggregated slot in LDS, no loops here); k_verify expands the bits into (i, v) pairs.
+__device__ __forceinline__ unsigned long long pack_record(int32_t ic, int64_t vtile, int h, uint32_t mask) {
+  return ((unsigned long long)(uint32_t)ic << 41) | ((unsigned long long)vtile << 17) | ((unsigned long long)h << 16) | mask;
+}
+
+__device__ __forceinline__ void emit_tile(SurvSink& sk, const MatchArgs& a, int lane, int h, int64_t vtile, uint32_t mask, int32_t ic) {
+  sink_push(sk, a, lane, mask != 0u, pack_record(ic, vtile, h, mask));
+}
+
+// MFMAs of the current tile into acc, with the threshold epilogue of the PREVIOUS tile (accp/prev)
+// interleaved between them (VALU issues under the matrix pipe), and the previous tile's survivors
+// emitted while the last MFMAs are still in the pipe.
+__device__ __forceinline__ void mfma_tile_f32(const float (&A)[3][21], const float (&b)[3][21], f32x16 (&acc)[3],
+                                              const f32x16 (&accp)[3], const TileMeta& prev, float thr,
+                                              SurvSink& sk, const MatchArgs& a, int lane, int h, int64_t vtile) {
   uint32_t mask = 0;
 #pragma unroll
-  for (int s = 0; s < 21; ++s) {
+  for (int s = 0; s < 17; ++s) {
     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][s], b[0][s], acc[0], 0, 0, 0);
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][s], b[1][s], acc[1], 0, 0, 0);
     acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[2][s], b[2][s], acc[2], 0, 0, 0);
+#ifndef DA_DBG_NO_EPILOGUE
     if (s < 16) mask |= threshold_row(accp, prev, s, thr);
+#endif
+    // per MFMA triple: one operand load of the next tile and a slice of the epilogue
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
   }
-  return prev.ok ? mask : 0u;
+#ifdef DA_DBG_NO_EPILOGUE
+  asm volatile("" ::"v"(accp[0][0]), "v"(accp[1][5]), "v"(accp[2][15]));
+#endif
+#ifdef DA_DBG_NO_EMIT
+  asm volatile("" ::"v"(mask));
+#else
+  emit_tile(sk, a, lane, h, vtile, prev.ok ? mask : 0u, prev.ic);
+#endif
+#pragma unroll
+  for (int s = 17; s < 21; ++s) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][s], b[0][s], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][s], b[1][s], acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[2][s], b[2][s], acc[2], 0, 0, 0);
+  }
 }
 
-__device__ __forceinline__ void emit_tile(SurvSink& sk, const MatchArgs& a, int lane, int h, int64_t vt0, uint32_t mask, int32_t ic) {
-  if (__ballot(mask != 0u) == 0ull) return;
+// All operand loads of the tile about to be consumed were issued one phase ago; naming them here
+// makes the compiler retire them (vmcnt) BEFORE the next prefetch batch is issued.  Otherwise its
+// in-order vmcnt bookkeeping (6-bit counter) would make the waits for these operands also wait
+// for part of the fresh batch.
+__device__ __forceinline__ void retire_loads(const float (&b)[3][21], const TileMeta& m) {
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
-    const int64_t vrr = vt0 + row;
-    const bool p = ((mask >> g) & 1u) && vrr < a.n_v;
-    unsigned long long rec = 0;
-    if (p) rec = ((unsigned long long)(uint32_t)ic << 32) | (uint32_t)a.vlist[vrr];
-    sink_push(sk, a, lane, p, rec);
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int s = 0; s < 21; ++s) asm volatile("" ::"v"(b[j][s]));
   }
+  asm volatile("" ::"v"(m.thr));
 }
 
 __global__ __launch_bounds__(64 * kWavesPerBlock, 1) void k_match_f32(MatchArgs a) {
@@ -232,50 +290,58 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 1) void k_match_f32(MatchArgs 
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const float sc = vok ? -a.inv_v[j][v] : 0.f;
-      const float* p = a.ms_v[j] + v + h;
+      const float* p = a.ms_v[j] + v + 21 * h;
 #pragma unroll
-      for (int s = 0; s < 21; ++s) A[j][s] = (2 * s + h < kWin) ? p[2 * s] * sc : 0.f;
+      for (int s = 0; s < 21; ++s) A[j][s] = (21 * h + s < kWin) ? p[s] * sc : 1.0f;    // k = 21 h + s; k = 41: norm slot
     }
+    const int64_t vtile = vt0 >> 5;
     float b0[3][21], b1[3][21];
     TileMeta m0, m1;
     f32x16 acc0[3], acc1[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc1[j] = f32x16{0};
-    m1.ok = false; m1.ic = 0; m1.inv[0] = m1.inv[1] = m1.inv[2] = 0.f;
-    load_tile_b(a, a_begin, a_end, r, h, b0, m0);
+    m1.ok = false; m1.ic = 0; m1.thr = 0.f;
     int64_t at = a_begin;
+    load_tile_b(a, at, a_end, r, h, fetch_index(a, at, a_end, r), b0, m0);
+    int32_t ic_next = fetch_index(a, at + 32, a_end, r);        // frame numbers of tile t+1
+    // The prefetch is unconditional (past the end it re-reads the clamped last row, flagged !ok)
+    // so that loads, epilogue and MFMAs share one basic block and can be interleaved.
     while (true) {
       // ---- even phase: MFMAs of (b0, m0) -> acc0; epilogue of (acc1, m1); prefetch into (b1, m1)
       {
         const TileMeta prev = m1;
-        if (at + 32 < a_end) load_tile_b(a, at + 32, a_end, r, h, b1, m1);
+        retire_loads(b0, m0);
+        asm volatile("" ::"v"(ic_next));
+        load_tile_b(a, at + 32, a_end, r, h, ic_next, b1, m1);
+        ic_next = fetch_index(a, at + 64, a_end, r);
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc0[j] = f32x16{0};
-        const uint32_t mask = mfma_tile_f32(A, b0, acc0, acc1, prev, a.thr);
-        emit_tile(sk, a, lane, h, vt0, mask, prev.ic);
+        mfma_tile_f32(A, b0, acc0, acc1, prev, a.thr, sk, a, lane, h, vtile);
         at += 32;
         if (at >= a_end) {      // drain: epilogue of the last tile
           uint32_t m = 0;
 #pragma unroll
           for (int g = 0; g < 16; ++g) m |= threshold_row(acc0, m0, g, a.thr);
-          emit_tile(sk, a, lane, h, vt0, m0.ok ? m : 0u, m0.ic);
+          emit_tile(sk, a, lane, h, vtile, m0.ok ? m : 0u, m0.ic);
           break;
         }
       }
       // ---- odd phase: MFMAs of (b1, m1) -> acc1; epilogue of (acc0, m0); prefetch into (b0, m0)
       {
         const TileMeta prev = m0;
-        if (at + 32 < a_end) load_tile_b(a, at + 32, a_end, r, h, b0, m0);
+        retire_loads(b1, m1);
+        asm volatile("" ::"v"(ic_next));
+        load_tile_b(a, at + 32, a_end, r, h, ic_next, b0, m0);
+        ic_next = fetch_index(a, at + 64, a_end, r);
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc1[j] = f32x16{0};
-        const uint32_t mask = mfma_tile_f32(A, b1, acc1, acc0, prev, a.thr);
-        emit_tile(sk, a, lane, h, vt0, mask, prev.ic);
+        mfma_tile_f32(A, b1, acc1, acc0, prev, a.thr, sk, a, lane, h, vtile);
         at += 32;
         if (at >= a_end) {
           uint32_t m = 0;
 #pragma unroll
           for (int g = 0; g < 16; ++g) m |= threshold_row(acc1, m1, g, a.thr);
-          emit_tile(sk, a, lane, h, vt0, m1.ok ? m : 0u, m1.ic);
+          emit_tile(sk, a, lane, h, vtile, m1.ok ? m : 0u, m1.ic);
           break;
         }
       }
@@ -340,26 +406,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_match_bf16(MatchArgs
         }
       }
       const float i0 = a.inv_a[0][ic], i1 = a.inv_a[1][ic], i2 = a.inv_a[2][ic];
-      bool any = false;
-      bool pass[16];
+      uint32_t mask = 0;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const float t0 = fmaf(acc[0][g], i0, 1.0f);
         const float t1 = fmaf(acc[1][g], i1, 1.0f);
         const float t2 = fmaf(acc[2][g], i2, 1.0f);
-        pass[g] = aok && (t0 * t1 * t2 <= a.thr);
-        any |= pass[g];
+        if (t0 * t1 * t2 <= a.thr) mask |= 1u << g;
       }
-      if (__ballot(any) != 0ull) {
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
-          const int64_t vrr = vt0 + row;
-          unsigned long long rec = 0;
-          if (pass[g]) rec = ((unsigned long long)(uint32_t)ic << 32) | (uint32_t)a.vlist[vrr < a.n_v ? vrr : a.n_v - 1];
-          sink_push(sk, a, lane, pass[g] && vrr < a.n_v, rec);
-        }
-      }
+      emit_tile(sk, a, lane, h, vt0 >> 5, aok ? mask : 0u, ic);
     }
   }
   sink_flush(sk, a, lane);
@@ -415,11 +470,7 @@ void launch_corr(const CorrArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // exact verification of survivors (float64), hash vote, quality (:649-673)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_verify(VerifyArgs a, unsigned long long n_surv) {
-  const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_surv) return;
-  const unsigned long long rec = a.surv[p];
-  const int32_t i = (int32_t)(rec >> 32), v = (int32_t)(rec & 0xffffffffu);
+__device__ inline void verify_pair(const VerifyArgs& a, int32_t i, int32_t v) {
   if (a.mode == 0) {
     int hits012 = 0;
 #pragma unroll
@@ -447,8 +498,30 @@ __global__ __launch_bounds__(256) void k_verify(VerifyArgs a, unsigned long long
   q = q < 50.0 ? q : 50.0;
   const unsigned long long pos = atomicAdd(a.n_out, 1ull);
   if (pos < a.out_capacity) {
-    a.keys[pos] = rec;
+    a.keys[pos] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v;
     a.quals[pos] = q;
+  }
+}
+
+// one thread per staged record: expand its row mask into (i, v) pairs and verify each
+__global__ __launch_bounds__(256) void k_verify(VerifyArgs a, unsigned long long n_rec) {
+  const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long rec = (p < n_rec) ? a.surv[p] : 0ull;
+  const int32_t i = (int32_t)(rec >> 41);
+  const int64_t vtile = (int64_t)((rec >> 17) & 0xFFFFFFull);
+  const int h = (int)((rec >> 16) & 1ull);
+  uint32_t mask = (uint32_t)(rec & 0xFFFFull);
+  // pair count for the statistics: one atomic per wave
+  unsigned int cnt = (unsigned int)__popc(mask);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(a.n_pairs, (unsigned long long)cnt);
+  while (mask != 0u) {
+    const int g = __ffs(mask) - 1;
+    mask &= mask - 1u;
+    const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
+    const int64_t vr = vtile * 32 + row;
+    if (vr < a.n_v) verify_pair(a, i, a.vlist[vr]);
   }
 }
 
