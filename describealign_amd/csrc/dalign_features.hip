@@ -5,49 +5,81 @@
 // (plus an 8-frame halo either side) from HBM into LDS with 16-byte loads, rounding through
 // float16 exactly as the reference's array does (:156), and everything downstream runs out of
 // LDS:
-//   stage 1  one thread per 35-sample group: block energy and sign-change partials, the 5x3
-//            low-pass (bb1), band-1 residual energy (be1) and its three separable blur sums
-//   stage 2  one thread per 35-sample group: the 7x3 low-pass (bb2), band-2 residual energy
-//            and its separable blur sums, band-3 energy
+//   stage 1  one thread per 70 samples (two 35-sample groups; the window always starts on an odd
+//            half-word, so every lane unpacks the same way): block-energy partials with packed
+//            half dot products, sign changes on packed words, the 5x3 low-pass (bb1), band-1
+//            residual energy (be1) and its three separable blur sums
+//   stage 2  one thread per 35-sample group: the 7x3 low-pass (bb2), band-2 residual energy,
+//            band-3 energy
 //   stage 3  one thread per frame: gather the six groups of the frame
 //   stage 4  one thread per output frame: 13-tap Hann smoothing of energy / zero crossings,
 //            15-tap combination of the blur sums, log10(1+x)/2, store.
-// The 630-tap and 90-tap Hann blurs of the reference are evaluated in their exactly
-// equivalent separable form (see FeatTables) in float64, so no precision is lost by it.
+// The stage outputs are written over the PCM region once every thread is done reading it, so a
+// workgroup needs 54 KB of LDS and two fit per CU.
+// The 630-tap and 90-tap Hann blurs of the reference are evaluated in their exactly equivalent
+// separable form (see FeatTables): per-group partial sums in float32, combined in float64.
 //
 // Roofline: HBM bound.  Algorithmic bytes = 2*C*N read + 5 rows * 4 B * N/210 written.
 #include "dalign_common.h"
 
 namespace da {
 
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
 template <int C> struct FeatCfg {
   static constexpr int kExt = (C == 1) ? 128 : 64;    // frames staged per workgroup (incl. halo)
   static constexpr int kHalo = 8;
   static constexpr int kOut = kExt - 2 * kHalo;       // frames produced per workgroup
   static constexpr int kNQ = kExt * 6;                // 35-sample groups per chunk
+  static constexpr int kPairs = kNQ / 2;              // stage-1 work items = threads per workgroup
+  static constexpr int kThreads = kPairs;             // 384 (mono) / 192 (stereo)
   static constexpr int kFront = 8;                    // extra samples staged before the chunk
   static constexpr int kTot = kExt * 210 + 16;        // staged samples per channel
+  static constexpr int kXBytes = C * kTot * 2;
 };
 
-constexpr int kThreads = 256;
+// LDS map.  Region X holds the staged PCM during stage 0/1; afterwards:
+//   [0, 28*kNQ)            s_bb1  float[kNQ*7]
+//   then 5 x float[kNQ]    s_e, s_z, s_S0, s_Sc, s_Ss
+//   then float[kNQ]        s_T0     (be2)
+//   then double[kNQ]       s_R3     (bb2^2)
+//   then double[7][kExt]   s_F      per-frame sums
+//   then float[2*kExt]     s_eb, float[kExt] s_zf
+template <int C> struct FeatLds {
+  using Cfg = FeatCfg<C>;
+  static constexpr int o_bb1 = 0;
+  static constexpr int o_e = o_bb1 + 28 * Cfg::kNQ;
+  static constexpr int o_z = o_e + 4 * Cfg::kNQ;
+  static constexpr int o_S0 = o_z + 4 * Cfg::kNQ;
+  static constexpr int o_Sc = o_S0 + 4 * Cfg::kNQ;
+  static constexpr int o_Ss = o_Sc + 4 * Cfg::kNQ;
+  static constexpr int o_T0 = o_Ss + 4 * Cfg::kNQ;
+  static constexpr int o_R3 = (o_T0 + 4 * Cfg::kNQ + 7) & ~7;
+  static constexpr int o_F = o_R3 + 8 * Cfg::kNQ;
+  static constexpr int o_eb = o_F + 8 * 7 * Cfg::kExt;
+  static constexpr int o_zf = o_eb + 4 * 2 * Cfg::kExt;
+  static constexpr int o_tab = o_zf + 4 * Cfg::kExt;          // cos1/sin1 tables as float[84]
+  static constexpr int aliased_end = o_tab + 4 * 84;
+  static constexpr int total = ((Cfg::kXBytes > aliased_end ? Cfg::kXBytes : aliased_end) + 15) & ~15;
+};
 
 template <int C>
-__global__ __launch_bounds__(kThreads) void k_features(FeatArgs a, const FeatTables* __restrict__ tp) {
+__global__ __launch_bounds__(FeatCfg<C>::kThreads) void k_features(FeatArgs a, const FeatTables* __restrict__ tp) {
   using Cfg = FeatCfg<C>;
+  using L = FeatLds<C>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  _Float16* s_x = reinterpret_cast<_Float16*>(smem);                        // [C][kTot]
-  double* s_d = reinterpret_cast<double*>(smem + ((C * Cfg::kTot * 2 + 15) & ~15));
-  double* s_S0 = s_d;                    // [kNQ] band-1 blur partials per group
-  double* s_Sc = s_S0 + Cfg::kNQ;
-  double* s_Ss = s_Sc + Cfg::kNQ;
-  double* s_T0 = s_Ss + Cfg::kNQ;        // [kNQ] band-2: be2, and bb2^2
-  double* s_R3 = s_T0 + Cfg::kNQ;
-  double* s_F = s_R3 + Cfg::kNQ;         // [7][kExt] per-frame: S0,Sc,Ss,T0,Tc,Ts,be3
-  float* s_bb1 = reinterpret_cast<float*>(s_F + 7 * Cfg::kExt);   // [kNQ*7]
-  float* s_e = s_bb1 + Cfg::kNQ * 7;     // [kNQ] energy partial (sum of squares over 35 samples, all channels)
-  float* s_z = s_e + Cfg::kNQ;           // [kNQ] sign-change partial
-  float* s_eb = s_z + Cfg::kNQ;          // [2*kExt] block energies
-  float* s_zf = s_eb + 2 * Cfg::kExt;    // [kExt] frame sign changes
+  const uint32_t* s_xw = reinterpret_cast<const uint32_t*>(smem);           // packed halves, [C][kTot/2]
+  float* s_bb1 = reinterpret_cast<float*>(smem + L::o_bb1);
+  float* s_e = reinterpret_cast<float*>(smem + L::o_e);
+  float* s_z = reinterpret_cast<float*>(smem + L::o_z);
+  float* s_S0 = reinterpret_cast<float*>(smem + L::o_S0);
+  float* s_Sc = reinterpret_cast<float*>(smem + L::o_Sc);
+  float* s_Ss = reinterpret_cast<float*>(smem + L::o_Ss);
+  float* s_T0 = reinterpret_cast<float*>(smem + L::o_T0);
+  double* s_R3 = reinterpret_cast<double*>(smem + L::o_R3);
+  double* s_F = reinterpret_cast<double*>(smem + L::o_F);
+  float* s_eb = reinterpret_cast<float*>(smem + L::o_eb);
+  float* s_zf = reinterpret_cast<float*>(smem + L::o_zf);
 
   const FeatTables& T = *tp;
   const int tid = threadIdx.x;
@@ -55,137 +87,169 @@ __global__ __launch_bounds__(kThreads) void k_features(FeatArgs a, const FeatTab
   const int64_t s0 = 210 * (f0 - Cfg::kHalo) - Cfg::kFront;      // sample index of LDS slot 0
 
   // ---- stage 0: HBM -> LDS, int16 -> float16 (round to nearest even, as numpy astype) -------
-  for (int t = tid; t < Cfg::kTot / 8; t += kThreads) {
+  for (int t = tid; t < Cfg::kTot / 8; t += Cfg::kThreads) {
     const int64_t n0 = s0 + 8 * (int64_t)t;
-    short v[C][8];
-    if (n0 >= 0 && n0 + 8 <= a.n_energy && a.stride_n == 1) {
+    uint32_t w[C][4];
+    const bool inside = n0 >= 0 && n0 + 8 <= a.n_energy;
+    if (inside && a.stride_n == 1 && ((reinterpret_cast<uintptr_t>(a.pcm + n0) & 3) == 0) && ((a.stride_c & 1) == 0)) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        const int16_t* p = a.pcm + c * a.stride_c + n0;
-        // 4-byte aligned 16-byte load (n0 is even whenever the base is 4-byte aligned)
-        if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
-          const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
-          uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
-          v[c][0] = (short)(w0 & 0xffff); v[c][1] = (short)(w0 >> 16);
-          v[c][2] = (short)(w1 & 0xffff); v[c][3] = (short)(w1 >> 16);
-          v[c][4] = (short)(w2 & 0xffff); v[c][5] = (short)(w2 >> 16);
-          v[c][6] = (short)(w3 & 0xffff); v[c][7] = (short)(w3 >> 16);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[c][e] = p[e];
-        }
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(a.pcm + c * a.stride_c + n0);
+        const uint4 v = *reinterpret_cast<const uint4*>(q);   // dword-aligned 16-byte load
+        w[c][0] = v.x; w[c][1] = v.y; w[c][2] = v.z; w[c][3] = v.w;
       }
-    } else if (n0 >= 0 && n0 + 8 <= a.n_energy && C == 2 && a.stride_n == 2 && a.stride_c == 1) {
-      // interleaved stereo: 8 frames = 32 bytes
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(a.pcm + 2 * n0);
+    } else if (inside && C == 2 && a.stride_n == 2 && a.stride_c == 1) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(a.pcm + 2 * n0);   // interleaved stereo frames
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        uint32_t w = q[e];
-        v[0][e] = (short)(w & 0xffff);
-        if (C == 2) v[C - 1][e] = (short)(w >> 16);
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t fa = q[2 * e], fb = q[2 * e + 1];
+        w[0][e] = (fa & 0xffffu) | (fb << 16);
+        w[C - 1][e] = (fa >> 16) | (fb & 0xffff0000u);
       }
     } else {
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int64_t n = n0 + e;
-          v[c][e] = (n >= 0 && n < a.n_energy) ? a.pcm[c * a.stride_c + n * a.stride_n] : (short)0;
+        for (int e = 0; e < 4; ++e) {
+          uint32_t lohi[2];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int64_t n = n0 + 2 * e + b;
+            lohi[b] = (n >= 0 && n < a.n_energy) ? (uint16_t)a.pcm[c * a.stride_c + n * a.stride_n] : 0u;
+          }
+          w[c][e] = lohi[0] | (lohi[1] << 16);
         }
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      _Float16 h[8];
+      uint32_t o[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) h[e] = (_Float16)(float)v[c][e];
-      *reinterpret_cast<uint4*>(&s_x[c * Cfg::kTot + 8 * t]) = *reinterpret_cast<const uint4*>(h);
+      for (int e = 0; e < 4; ++e) {
+        const _Float16 lo = (_Float16)(short)(w[c][e] & 0xffffu);
+        const _Float16 hi = (_Float16)(short)(w[c][e] >> 16);
+        half2_t p = {lo, hi};
+        o[e] = *reinterpret_cast<uint32_t*>(&p);
+      }
+      *reinterpret_cast<uint4*>(smem + 2 * (c * Cfg::kTot + 8 * t)) = make_uint4(o[0], o[1], o[2], o[3]);
     }
   }
   __syncthreads();
 
-  // ---- stage 1: per 35-sample group --------------------------------------------------------
-  const int64_t q0 = 6 * (f0 - Cfg::kHalo);          // global group index of local group 0
-  const int64_t nq_band = 6 * a.len_other;           // groups the band / zero-crossing rows may see
-  for (int q = tid; q < Cfg::kNQ; q += kThreads) {
-    const int64_t Q = q0 + q;
-    const int base = Cfg::kFront + 35 * q - 5;       // LDS slot of window element 0
-    float m[45];
-    float esum = 0.f;
-    int zc = 0;
+  // ---- stage 1: one thread per 70 samples -----------------------------------------------
+  // window element t (0..79) <-> sample 70*K - 5 + t  (K = global pair index) = staged half-word
+  // 70*k + 3 + t; the 41 dwords read start at half-word 70*k + 2.
+  const int64_t q0g = 6 * (f0 - Cfg::kHalo);          // global group index of local group 0
+  const int64_t nq_band = 6 * a.len_other;            // groups the band / zero-crossing rows may see
+  float r_e[2], r_z[2], r_S0[2], r_Sc[2], r_Ss[2], r_bb[14];
+  {
+    const int k = tid;
+    const int64_t Q0 = q0g + 2 * k;
+    float m[80];
+    float e0 = 0.f, e1 = 0.f;
+    int z0 = 0, z1 = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      const _Float16* xp = s_x + c * Cfg::kTot + base;
-      float x[45];
+      const uint32_t* xp = s_xw + c * (Cfg::kTot / 2) + 35 * k + 1;
+      uint32_t w[41];
 #pragma unroll
-      for (int t = 0; t < 45; ++t) x[t] = (float)xp[t];
+      for (int d = 0; d < 41; ++d) w[d] = xp[d];
+      // own samples: half-words 6..75 of the read = dwords 3..37; group 0 = half-words 6..40
 #pragma unroll
-      for (int t = 5; t < 40; ++t) {
-        esum = fmaf(x[t], x[t], esum);
-        zc += (int)((__float_as_uint(x[t]) ^ __float_as_uint(x[t - 1])) >> 31);
+      for (int d = 3; d <= 37; ++d) {
+        const half2_t hv = *reinterpret_cast<const half2_t*>(&w[d]);
+        const uint32_t flips = (w[d] ^ __builtin_amdgcn_alignbit(w[d], w[d - 1], 16)) & 0x80008000u;
+        if (d < 20) {
+          e0 = __builtin_amdgcn_fdot2(hv, hv, e0, false);
+          z0 += __builtin_popcount(flips);
+        } else if (d > 20) {
+          e1 = __builtin_amdgcn_fdot2(hv, hv, e1, false);
+          z1 += __builtin_popcount(flips);
+        } else {
+          const float lo = (float)hv[0], hi = (float)hv[1];
+          e0 = fmaf(lo, lo, e0); e1 = fmaf(hi, hi, e1);
+          z0 += (int)((flips >> 15) & 1u); z1 += (int)(flips >> 31);
+        }
       }
-      if (c == 0) {
+      // float32 window for the band path
 #pragma unroll
-        for (int t = 0; t < 45; ++t) m[t] = x[t];
-      } else {
-        // channel mean kept in float16, accumulated in float32 (np.mean on a float16 array, :576)
-#pragma unroll
-        for (int t = 0; t < 45; ++t) m[t] = (float)(_Float16)((m[t] + x[t]) * 0.5f);
+      for (int t = 0; t < 80; ++t) {
+        const int hw = t + 1;
+        const half2_t hv = *reinterpret_cast<const half2_t*>(&w[hw >> 1]);
+        const float x = (float)hv[hw & 1];
+        if (c == 0) m[t] = x;
+        else m[t] = (float)(_Float16)((m[t] + x) * 0.5f);     // np.mean on float16, float32 accumulate (:576)
       }
     }
-    const bool in_band = (Q >= 0) && (Q < nq_band);
     // samples at or beyond n_band do not exist for the band rows (arr is truncated first, :577)
-    const int64_t nwin0 = 35 * Q - 5;
-    if (nwin0 + 45 > a.n_band) {
+    const int64_t nwin0 = 35 * Q0 - 5;
+    if (nwin0 + 80 > a.n_band) {
 #pragma unroll
-      for (int t = 0; t < 45; ++t)
+      for (int t = 0; t < 80; ++t)
         if (nwin0 + t >= a.n_band) m[t] = 0.f;
     }
-    s_e[q] = esum;
-    s_z[q] = in_band ? (float)zc : 0.f;
-    double S0 = 0.0, Sc = 0.0, Ss = 0.0;
-    const int iq = 7 * (int)(((Q % 6) + 6) % 6);
+    const float* tab = reinterpret_cast<const float*>(smem + L::o_tab);   // not yet valid: filled below
+    (void)tab;
 #pragma unroll
-    for (int g = 0; g < 7; ++g) {
-      float bb = 0.f;
+    for (int u = 0; u < 2; ++u) {
+      const int64_t Q = Q0 + u;
+      const bool in_band = (Q >= 0) && (Q < nq_band);
+      const int iq = 7 * (int)(((Q % 6) + 6) % 6);
+      float S0 = 0.f, Sc = 0.f, Ss = 0.f;
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
+      for (int g = 0; g < 7; ++g) {
+        const int gg = 7 * u + g;                 // group within the 70-sample item
+        float bb = 0.f;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) bb = fmaf(T.w15[i + 5 * k], m[5 + 5 * (g + 1 - k) + i], bb);
-      float be = 0.f;
+        for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const float d = m[5 + 5 * g + i] - bb;
-        be = fmaf(d, d, be);
+          for (int i = 0; i < 5; ++i) bb = fmaf(T.w15[i + 5 * kk], m[5 + 5 * (gg + 1 - kk) + i], bb);
+        float be = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const float d = m[5 + 5 * gg + i] - bb;
+          be = fmaf(d, d, be);
+        }
+        if (!in_band) { bb = 0.f; be = 0.f; }
+        r_bb[gg] = bb;
+        S0 += be;
+        Sc = fmaf((float)T.cos1[iq + g], be, Sc);
+        Ss = fmaf((float)T.sin1[iq + g], be, Ss);
       }
-      if (!in_band) { bb = 0.f; be = 0.f; }
-      s_bb1[7 * q + g] = bb;
-      const double bed = (double)be;
-      S0 += bed;
-      Sc = fma(T.cos1[iq + g], bed, Sc);
-      Ss = fma(T.sin1[iq + g], bed, Ss);
+      r_S0[u] = S0; r_Sc[u] = Sc; r_Ss[u] = Ss;
+      r_e[u] = u ? e1 : e0;
+      r_z[u] = in_band ? (float)(u ? z1 : z0) : 0.f;
     }
-    s_S0[q] = S0; s_Sc[q] = Sc; s_Ss[q] = Ss;
+  }
+  __syncthreads();                                    // everyone is done reading the PCM region
+  {
+    const int k = tid;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = 2 * k + u;
+      s_e[q] = r_e[u]; s_z[q] = r_z[u]; s_S0[q] = r_S0[u]; s_Sc[q] = r_Sc[u]; s_Ss[q] = r_Ss[u];
+#pragma unroll
+      for (int g = 0; g < 7; ++g) s_bb1[7 * q + g] = r_bb[7 * u + g];
+    }
   }
   __syncthreads();
 
   // ---- stage 2: second low-pass level ---------------------------------------------------
-  for (int q = tid; q < Cfg::kNQ; q += kThreads) {
-    const int64_t Q = q0 + q;
-    double be2 = 0.0, r3 = 0.0;
+  for (int q = tid; q < Cfg::kNQ; q += Cfg::kThreads) {
+    const int64_t Q = q0g + q;
+    float be2 = 0.f;
+    double r3 = 0.0;
     if (q >= 1 && q < Cfg::kNQ - 1 && Q >= 0 && Q < nq_band) {
       const float* bp = s_bb1 + 7 * (q - 1);
       float bb2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
+      for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
-        for (int i = 0; i < 7; ++i) bb2 = fmaf(T.w21[i + 7 * k], bp[7 * (2 - k) + i], bb2);
-      float be = 0.f;
+        for (int i = 0; i < 7; ++i) bb2 = fmaf(T.w21[i + 7 * kk], bp[7 * (2 - kk) + i], bb2);
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         const float d = bp[7 + i] - bb2;
-        be = fmaf(d, d, be);
+        be2 = fmaf(d, d, be2);
       }
-      be2 = (double)be;
       r3 = (double)bb2 * (double)bb2;     // band 3 is float64 in the reference (:583, :588)
     }
     s_T0[q] = be2;
@@ -194,14 +258,14 @@ __global__ __launch_bounds__(kThreads) void k_features(FeatArgs a, const FeatTab
   __syncthreads();
 
   // ---- stage 3: per frame -------------------------------------------------------------------
-  for (int g = tid; g < Cfg::kExt; g += kThreads) {
+  for (int g = tid; g < Cfg::kExt; g += Cfg::kThreads) {
     double S0 = 0, Sc = 0, Ss = 0, T0 = 0, Tc = 0, Ts = 0, R = 0;
     float z = 0.f;
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
       const int q = 6 * g + s;
-      S0 += s_S0[q]; Sc += s_Sc[q]; Ss += s_Ss[q];
-      const double b2 = s_T0[q];
+      S0 += (double)s_S0[q]; Sc += (double)s_Sc[q]; Ss += (double)s_Ss[q];
+      const double b2 = (double)s_T0[q];
       T0 += b2; Tc = fma(T.cos2[s], b2, Tc); Ts = fma(T.sin2[s], b2, Ts);
       R += s_R3[q];
       z += s_z[q];
@@ -217,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void k_features(FeatArgs a, const FeatTab
   __syncthreads();
 
   // ---- stage 4: outputs -----------------------------------------------------------------------
-  for (int ml = tid; ml < Cfg::kOut; ml += kThreads) {
+  for (int ml = tid; ml < Cfg::kOut; ml += Cfg::kThreads) {
     const int64_t mfr = f0 + ml;
     const int g = ml + Cfg::kHalo;
     if (mfr < a.len_energy) {
@@ -247,35 +311,22 @@ __global__ __launch_bounds__(kThreads) void k_features(FeatArgs a, const FeatTab
   }
 }
 
-template <int C> static size_t feat_smem_bytes() {
+template <int C> static void launch_one(const FeatArgs& a, const FeatTables* d_tables, hipStream_t s) {
   using Cfg = FeatCfg<C>;
-  size_t b = (C * Cfg::kTot * 2 + 15) & ~size_t(15);
-  b += sizeof(double) * (5 * Cfg::kNQ + 7 * Cfg::kExt);
-  b += sizeof(float) * (Cfg::kNQ * 7 + 2 * Cfg::kNQ + 3 * Cfg::kExt);
-  return b;
+  const int64_t blocks = (a.len_energy + Cfg::kOut - 1) / Cfg::kOut;
+  const int smem = FeatLds<C>::total;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_features<C>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    once = true;
+  }
+  hipLaunchKernelGGL(k_features<C>, dim3((unsigned)blocks), dim3(Cfg::kThreads), smem, s, a, d_tables);
 }
 
 void launch_features(const FeatArgs& a, int channels, const FeatTables* d_tables, hipStream_t s) {
   if (a.len_energy <= 0) return;
-  if (channels == 1) {
-    const int64_t blocks = (a.len_energy + FeatCfg<1>::kOut - 1) / FeatCfg<1>::kOut;
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_features<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)feat_smem_bytes<1>());
-      once = true;
-    }
-    hipLaunchKernelGGL(k_features<1>, dim3((unsigned)blocks), dim3(kThreads), feat_smem_bytes<1>(), s, a, d_tables);
-  } else {
-    const int64_t blocks = (a.len_energy + FeatCfg<2>::kOut - 1) / FeatCfg<2>::kOut;
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_features<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)feat_smem_bytes<2>());
-      once = true;
-    }
-    hipLaunchKernelGGL(k_features<2>, dim3((unsigned)blocks), dim3(kThreads), feat_smem_bytes<2>(), s, a, d_tables);
-  }
+  if (channels == 1) launch_one<1>(a, d_tables, s);
+  else launch_one<2>(a, d_tables, s);
 }
 
 }  // namespace da
