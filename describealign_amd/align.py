@@ -271,6 +271,56 @@ def default_context(device: int = 0, precision: int = _native.PREC_F32) -> "_nat
   return _default_ctx
 
 
+def _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm):
+  """Stages 1+2 on the GPU: prep, similarity GEMM, exact verification, sort."""
+  t0 = time.perf_counter()
+  mi, mv, mq = ctx.match(video_features, audio_desc_features, mode=mode)
+  tm["device"] = ctx.stats()
+  tm["match_s"] = time.perf_counter() - t0
+  tm["n_matches"] = len(mi)
+  return mi, mv, mq
+
+
+def _stage_chain_pass1(ctx, matches, video_features, audio_desc_features, n_ve, n_ae, tm):
+  """Chain DP (host C++) + pass-1 host work: continuity filter, scaling, compression."""
+  mi, mv, mq = matches
+  t1 = time.perf_counter()
+  px, py = ctx.chain(mi, mv, mq, min_len=min_path_length(n_ve, n_ae))      # raises the mismatch error
+  tm.setdefault("device", {})["chain_ms"] = ctx.stats()["chain_ms"]
+  t2 = time.perf_counter()
+  x = px.astype(np.int64); y = py.astype(np.int64)
+  keep = continuity_error(x, y) < 3
+  x, y = x[keep], y[keep]
+  a_scaled, v_scaled = scale_feature_stacks(video_features, audio_desc_features, x, y)
+  fx, fy = compress_path(x, y)
+  t3 = time.perf_counter()
+  tm.update(chain_s=t2 - t1, pass1_host_s=t3 - t2, n_path1=len(px), n_fit_points=len(fx))
+  return fx, fy, a_scaled, v_scaled
+
+
+def _stage_match(ctx, video_features, audio_desc_features, n_ve, n_ae, mode, tm):
+  matches = _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm)
+  return _stage_chain_pass1(ctx, matches, video_features, audio_desc_features, n_ve, n_ae, tm)
+
+
+def _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm):
+  """Stage 4: clustering, banded extension + second DP (GPU + host), nodes."""
+  t0 = time.perf_counter()
+  x0, x1, off, slo = cluster_lines(lp["smooth_x"], lp["smooth_y"], lp["slopes"])
+  t1 = time.perf_counter()
+  path, n_points = ctx.refine(a_scaled, v_scaled, x0, x1, off, slo, min_len=min_path_length(n_ve, n_ae))
+  st = ctx.stats()
+  t2 = time.perf_counter()
+  nx, ny, sim = nodes_and_similarity(path, len(a_scaled), len(v_scaled), n_ae, n_ve)
+  path[:, :2] /= float(FRAMES_PER_SECOND)
+  t3 = time.perf_counter()
+  tm.update(cluster_s=t1 - t0, refine_s=t2 - t1, nodes_s=t3 - t2, n_clusters=len(x0), n_points=n_points,
+            n_path2=len(path))
+  tm.setdefault("device", {}).update(refine_kernel_ms=st["refine_kernel_ms"], refine_dp_ms=st["refine_dp_ms"],
+                                     refine_points=st["refine_points"])
+  return nx, ny, sim, path, lp["median_slope"]
+
+
 def align(video_features, audio_desc_features, video_energy, audio_desc_energy, ctx=None, timings=None,
           mode=_native.MATCH_HASHED):
   """Drop-in for describealign.align (:595-1027); same arguments, same return tuple."""
@@ -280,31 +330,102 @@ def align(video_features, audio_desc_features, video_energy, audio_desc_energy, 
   n_ve, n_ae = len(video_energy), len(audio_desc_energy)
   print("  memorizing video...        \r", end='')
   print("  matching audio...  \r", end='')
-  mi, mv, mq = ctx.match(video_features, audio_desc_features, mode=mode)
-  t1 = time.perf_counter()
-  px, py = ctx.chain(mi, mv, mq, min_len=min_path_length(n_ve, n_ae))      # raises the mismatch error
-  t2 = time.perf_counter()
-  x = px.astype(np.int64); y = py.astype(np.int64)
-
+  fx, fy, a_scaled, v_scaled = _stage_match(ctx, video_features, audio_desc_features, n_ve, n_ae, mode, tm)
   print("  refining match: pass 1 of 2...\r", end='')
-  keep = continuity_error(x, y) < 3
-  x, y = x[keep], y[keep]
-  a_scaled, v_scaled = scale_feature_stacks(video_features, audio_desc_features, x, y)
-  fx, fy = compress_path(x, y)
-  t3 = time.perf_counter()
+  t1 = time.perf_counter()
   lp = solve_trend_lp(fx, fy)
-  t4 = time.perf_counter()
-
+  tm["lp_s"] = time.perf_counter() - t1
   print("  refining match: pass 2 of 2...\r", end='')
-  x0, x1, off, slo = cluster_lines(lp["smooth_x"], lp["smooth_y"], lp["slopes"])
-  t5 = time.perf_counter()
-  path, n_points = ctx.refine(a_scaled, v_scaled, x0, x1, off, slo, min_len=min_path_length(n_ve, n_ae))
-  t6 = time.perf_counter()
-  nx, ny, sim = nodes_and_similarity(path, len(a_scaled), len(v_scaled), n_ae, n_ve)
-  path[:, :2] /= float(FRAMES_PER_SECOND)
-  t7 = time.perf_counter()
-  tm.update(match_s=t1 - t0, chain_s=t2 - t1, pass1_host_s=t3 - t2, lp_s=t4 - t3, cluster_s=t5 - t4,
-            refine_s=t6 - t5, nodes_s=t7 - t6, total_s=t7 - t0, n_matches=len(mi), n_path1=len(px),
-            n_fit_points=len(fx), n_clusters=len(x0), n_points=n_points, n_path2=len(path))
-  tm["device"] = ctx.stats()
-  return nx, ny, sim, path, lp["median_slope"]
+  out = _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm)
+  tm["total_s"] = time.perf_counter() - t0
+  return out
+
+
+def _lp_worker(args):
+  fx, fy = args
+  t0 = time.perf_counter()
+  lp = solve_trend_lp(fx, fy)
+  lp.pop("solution", None)
+  return lp, time.perf_counter() - t0
+
+
+class AlignPipeline:
+  """Directory-batch throughput.  One pair's latency is dominated by host work (the
+  single-threaded HiGHS LP, the two sequential DPs), so pairs are pipelined:
+
+    calling thread   GPU matching of pair k+1 (prep, similarity GEMM, verification, sort)
+    worker threads   per pair: chain DP (C++, GIL released) -> pass-1 host -> wait for the LP ->
+                     clustering -> banded extension + second DP -> nodes; one da_ctx per thread
+    LP processes     scipy.optimize.linprog (HiGHS), one pair each
+
+  Results come back in submission order and are identical to align()'s.
+
+      with AlignPipeline(ctx, lp_workers=4) as pipe:
+        for result in pipe.run(jobs):      # jobs: iterable of (video_features, audio_features)
+          ...
+  """
+
+  def __init__(self, ctx=None, lp_workers=4, mode=_native.MATCH_HASHED):
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    import threading
+    self.ctx = ctx or default_context()
+    self.mode = mode
+    self.depth = max(1, int(lp_workers))
+    self.pool = cf.ProcessPoolExecutor(max_workers=self.depth, mp_context=mp.get_context("spawn"))
+    self.threads = cf.ThreadPoolExecutor(max_workers=self.depth)
+    self._local = threading.local()
+    self._ctxs = []
+    self._lock = threading.Lock()
+
+  def _thread_ctx(self):
+    c = getattr(self._local, "ctx", None)
+    if c is None:
+      c = _native.Context(self.ctx.device, self.ctx.precision)
+      self._local.ctx = c
+      with self._lock:
+        self._ctxs.append(c)
+    return c
+
+  def warm(self):
+    """Start the worker processes (imports scipy) and threads before anything is timed."""
+    x = np.arange(40, dtype=np.float64)
+    list(self.pool.map(_lp_worker, [(x, x + 0.25 * np.sin(x))] * self.depth))
+    list(self.threads.map(lambda _: self._thread_ctx(), range(self.depth)))
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    self.threads.shutdown(wait=True, cancel_futures=True)
+    self.pool.shutdown(wait=True, cancel_futures=True)
+    for c in self._ctxs:
+      c.close()
+    self._ctxs = []
+
+  def _rest(self, matches, vf, af, tm):
+    ctx = self._thread_ctx()
+    n_ve, n_ae = len(vf[0]), len(af[0])
+    fx, fy, a_s, v_s = _stage_chain_pass1(ctx, matches, vf, af, n_ve, n_ae, tm)
+    lp, lp_s = self.pool.submit(_lp_worker, (fx, fy)).result()
+    tm["lp_s"] = lp_s
+    return _stage_refine(ctx, lp, a_s, v_s, n_ve, n_ae, tm)
+
+  def run(self, jobs, timings=None):
+    pending = []          # (future, tm) in submission order
+
+    def finish(entry):
+      fut, tm = entry
+      out = fut.result()
+      if timings is not None:
+        timings.append(tm)
+      return out
+
+    for vf, af in jobs:
+      tm = {}
+      matches = _stage_gpu_match(self.ctx, vf, af, self.mode, tm)
+      pending.append((self.threads.submit(self._rest, matches, vf, af, tm), tm))
+      while pending and (len(pending) > self.depth or pending[0][0].done()):
+        yield finish(pending.pop(0))
+    while pending:
+      yield finish(pending.pop(0))

@@ -213,3 +213,19 @@ def test_mismatched_pair_raises(ctx):
   vf = ctx.features(pair.video, 0); af = ctx.features(pair.audio, 1)
   with pytest.raises(RuntimeError, match="Alignment failed, are the input files mismatched"):
     A.align(vf, af, vf[0], af[0], ctx=ctx)
+
+
+def test_pipeline_equals_sequential(ctx):
+  """The batch pipeline (LP in worker processes, next pair's GPU stages overlapped) returns
+  exactly what align() returns, in submission order."""
+  from describealign_amd import align as A
+  pairs = [cases.align_case("a40"), cases.align_case("e180")]
+  feats = [(ctx.features(p.video, 0), ctx.features(p.audio, 1)) for p in pairs]
+  want = [A.align(vf, af, vf[0], af[0], ctx=ctx) for vf, af in feats]
+  with A.AlignPipeline(ctx, lp_workers=2) as pipe:
+    got = list(pipe.run(feats + feats))
+  assert len(got) == 4
+  for k, g in enumerate(got):
+    w = want[k % 2]
+    assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]) and g[2] == w[2] and g[4] == w[4]
+    assert np.array_equal(g[3], w[3])
