@@ -341,6 +341,34 @@ def align(video_features, audio_desc_features, video_energy, audio_desc_energy, 
   return out
 
 
+def align_tiled(video_features, audio_desc_features, video_energy, audio_desc_energy, group, ctx=None,
+                timings=None, mode=_native.MATCH_HASHED):
+  """One long pair across all ranks of `group` (BASELINE config 5): the quadratic matching stage
+  is split into contiguous audio-row blocks, one per GPU (each rank holds all video features);
+  the verified match lists are exchanged with a single all-gather (RCCL over xGMI), after which
+  every rank holds the full list and finishes the (sequential, host-side) rest identically.
+  Returns the same tuple as align() on every rank."""
+  from .distrib import row_blocks
+  ctx = ctx or default_context()
+  tm = timings if timings is not None else {}
+  n_ve, n_ae = len(video_energy), len(audio_desc_energy)
+  t0 = time.perf_counter()
+  rb, re = row_blocks(max(0, n_ae - (2 * NODE_FRAMES - 1)), group.world)[group.rank]
+  mi, mv, mq = ctx.match(video_features, audio_desc_features, mode=mode, rows=(rb, re))
+  tm["device"] = ctx.stats()
+  t1 = time.perf_counter()
+  mi, mv, mq = group.all_gather_matches(mi, mv, mq)
+  t2 = time.perf_counter()
+  tm.update(match_s=t1 - t0, gather_s=t2 - t1, n_matches=len(mi), rows=(rb, re))
+  fx, fy, a_scaled, v_scaled = _stage_chain_pass1(ctx, (mi, mv, mq), video_features, audio_desc_features, n_ve, n_ae, tm)
+  t3 = time.perf_counter()
+  lp = solve_trend_lp(fx, fy)
+  tm["lp_s"] = time.perf_counter() - t3
+  out = _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm)
+  tm["total_s"] = time.perf_counter() - t0
+  return out
+
+
 def _lp_worker(args):
   fx, fy = args
   t0 = time.perf_counter()

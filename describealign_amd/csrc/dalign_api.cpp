@@ -40,7 +40,7 @@ struct Side {
   DevBuf feat; int64_t feat_stride = 0; int64_t len[2] = {0, 0};
   // match-prep buffers
   DevBuf mfeat;                  // 5 rows uploaded by da_match
-  DevBuf ms[5], nrm[5], dig[5], flg[5], ms32[3], inv32[3], nrm32[3], prod32, bfe[3], bfo[3];
+  DevBuf ms[5], nrm[5], dig[5], flg[5], ms32[3], inv32[3], nrm32[3], nrmpk[3], prod32, bfe[3], bfo[3];
   int64_t mlen[5] = {0, 0, 0, 0, 0}; int64_t lmax = 0;
 };
 
@@ -161,7 +161,7 @@ void da_destroy(da_ctx* c) {
   for (Side& s : c->side) {
     s.pcm.release(); s.feat.release(); s.mfeat.release();
     for (int j = 0; j < 5; ++j) { s.ms[j].release(); s.nrm[j].release(); s.dig[j].release(); s.flg[j].release(); }
-    for (int j = 0; j < 3; ++j) { s.ms32[j].release(); s.inv32[j].release(); s.nrm32[j].release(); s.bfe[j].release(); s.bfo[j].release(); }
+    for (int j = 0; j < 3; ++j) { s.ms32[j].release(); s.inv32[j].release(); s.nrm32[j].release(); s.nrmpk[j].release(); s.bfe[j].release(); s.bfo[j].release(); }
     s.prod32.release();
   }
   DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->counters, &c->keys0, &c->keys1,
@@ -272,6 +272,7 @@ int upload_and_prep(da_ctx* c, Side& s, const float* feat, int64_t stride, const
     HIP_TRY(c, s.ms32[j].ensure(sizeof(float) * n)); p.ms32[j] = s.ms32[j].as<float>();
     HIP_TRY(c, s.inv32[j].ensure(sizeof(float) * n)); p.inv32[j] = s.inv32[j].as<float>();
     HIP_TRY(c, s.nrm32[j].ensure(sizeof(float) * n)); p.nrm32[j] = s.nrm32[j].as<float>();
+    HIP_TRY(c, s.nrmpk[j].ensure(sizeof(uint32_t) * n)); p.nrmpk[j] = s.nrmpk[j].as<uint32_t>();
     HIP_TRY(c, s.bfe[j].ensure(sizeof(uint16_t) * n + 64)); p.bf_even[j] = s.bfe[j].as<uint16_t>();
     HIP_TRY(c, s.bfo[j].ensure(sizeof(uint16_t) * n + 64)); p.bf_odd[j] = s.bfo[j].as<uint16_t>();
   }
@@ -325,7 +326,7 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
   for (int j = 0; j < 3; ++j) {
     m.ms_v[j] = V.ms32[j].as<float>(); m.ms_a[j] = A.ms32[j].as<float>();
     m.inv_v[j] = V.inv32[j].as<float>(); m.inv_a[j] = A.inv32[j].as<float>();
-    m.nrm_a[j] = A.nrm32[j].as<float>();
+    m.nrm_a[j] = A.nrm32[j].as<float>(); m.nrmpk_a[j] = A.nrmpk[j].as<uint32_t>();
     m.bfa_even[j] = A.bfe[j].as<uint16_t>(); m.bfa_odd[j] = A.bfo[j].as<uint16_t>();
     m.msd_v[j] = V.ms[j].as<double>();
   }
@@ -405,7 +406,7 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
       if (attempt == 1) return fail(c, DA_ERR_DEVICE, "da_match: match list kept overflowing");
       mcap = (size_t)n_match + 1024;
     }
-    c->st.survivors = (double)n_pairs;
+    (void)n_pairs;
     if (n_match > 0) {
       size_t tmp_bytes = 0;
       if (sort_pairs(nullptr, nullptr, nullptr, nullptr, (int64_t)n_match, nullptr, &tmp_bytes, c->stream) != 0)

@@ -53,6 +53,7 @@ struct PrepArgs {
   float* inv32[3];        // 1/norm as float32
   float* nrm32[3];        // norm as float32
   float* prod32;          // nrm0*nrm1*nrm2 as float32 (per-frame threshold scale)
+  uint32_t* nrmpk[3];     // norm split into two bf16 (hi | lo << 16): rides in two spare K slots of the bf16 GEMM
   uint16_t* bf_even[3];   // bf16 copy of ms: element e at [e]
   uint16_t* bf_odd[3];    // bf16 copy of ms shifted by one: element e+1 at [e]
 };
@@ -62,7 +63,8 @@ void launch_prep(const PrepArgs& a, const double* d_hann41n, hipStream_t s);
 struct MatchArgs {
   const float* ms_v[3]; const float* ms_a[3];
   const float* inv_v[3]; const float* inv_a[3];
-  const float* nrm_a[3]; const float* prod_a;                 // f32 GEMM: audio norms and their product
+  const float* nrm_a[3]; const float* prod_a;                 // audio norms and their product
+  const uint32_t* nrmpk_a[3];                                 // bf16 GEMM: audio norm as two bf16
   const uint16_t* bfa_even[3]; const uint16_t* bfa_odd[3];   // audio side bf16 copies
   const double* msd_v[3];                                     // for building bf16 A fragments
   const int32_t* vlist; int64_t n_v;      // every 4th non-quiet video frame (:629-630)

@@ -16,6 +16,7 @@ namespace da {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load, 4-byte aligned
+typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // ------------------------------------------------------------------------------------------
 // prep: mean subtraction (:598-599, :605-606), window norms (:600-602), hash digits (:623-628,
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
       a.nrm[j][i] = 1.0;
       a.digits[j][i] = 0xFFFFFFFFu;          // never matches
       if (a.is_video) a.flags[j][i] = 0xFFFFFFFFu;
-      if (j < 3) { a.inv32[j][i] = 0.f; a.nrm32[j][i] = 1.f; }
+      if (j < 3) { a.inv32[j][i] = 0.f; a.nrm32[j][i] = 1.f; a.nrmpk[j][i] = 0x00003F80u; }
     }
     return;
   }
@@ -76,7 +77,13 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
   double nr = sqrt(ss);
   nr = nr < 0.001 ? 0.001 : nr;
   a.nrm[j][i] = nr;
-  if (j < 3) { a.inv32[j][i] = (float)(1.0 / nr); a.nrm32[j][i] = (float)nr; }
+  if (j < 3) {
+    a.inv32[j][i] = (float)(1.0 / nr); a.nrm32[j][i] = (float)nr;
+    const uint16_t hi = f32_to_bf16((float)nr);
+    const float hif = __uint_as_float((uint32_t)hi << 16);
+    const uint16_t lo = f32_to_bf16((float)(nr - (double)hif));
+    a.nrmpk[j][i] = (uint32_t)hi | ((uint32_t)lo << 16);
+  }
   uint32_t dig = 0, flg = 0;
 #pragma unroll
   for (int b = 0; b < kTaps; ++b) {
@@ -351,13 +358,71 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 1) void k_match_f32(MatchArgs 
 }
 
 // ------------------------------------------------------------------------------------------
-// similarity GEMM, bf16 inputs / f32 accumulate on v_mfma_f32_32x32x16_bf16.
-// K = 41 padded to 48 (three K-steps of 16).  A operand: 8 consecutive bf16 of the video row
-// (lane l holds k = 16 s + 8 (l >> 5) + e), built once and pre-scaled by -1/|V|.  B operand: 8
-// consecutive bf16 of the audio row starting at i_c + 16 s + 8 h; a 16-byte load needs 4-byte
-// alignment, so two copies of the row are kept (even / shifted by one element) and each lane
-// picks the one that makes its start even.
+// similarity GEMM, bf16 inputs / f32 accumulate on v_mfma_f32_32x32x16_bf16 (a PREFILTER: every
+// survivor is re-verified in float64 by k_verify).
+// K = 41 padded to 48 = three K-steps of 16.  K is permuted so that lane half h, step s, element e
+// holds k = 24 h + 8 s + e: each lane's operands are 24 consecutive bf16 (3 x 16-byte loads; the
+// two shifted copies of the row make any start 4-byte aligned).  Spare slots k = 42, 43 carry the
+// audio window norm split into two bf16 (A holds 1 there), so the accumulator ends as
+// |A| (1 - corr) and the epilogue is 2 multiplies + 1 compare against thr |A|_0 |A|_1 |A|_2.
+// Same software pipeline as the f32 kernel (prefetch of tile t+1, epilogue of tile t-1 under the
+// MFMAs of tile t), two waves per SIMD.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_tile_bf16(const MatchArgs& a, int64_t at, int64_t a_end, int r, int h, int32_t ic,
+                                               bf16x8 (&b)[3][3], TileMeta& m) {
+  m.ok = (at + r) < a_end;
+  m.ic = ic;
+  const int32_t st = ic + 24 * h;                // first element of this lane's run
+  const int32_t odd = st & 1;
+  const int32_t ev = st - odd;                   // even element index into the chosen copy
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const uint16_t* base = (odd ? a.bfa_odd[j] : a.bfa_even[j]) + ev;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const u32x4u w = *reinterpret_cast<const u32x4u*>(base + 8 * s);
+      uint4 t = make_uint4(w[0], w[1], w[2], w[3]);
+      if (s == 2) {                                // k = 40..47 for h = 1: slots 42, 43 carry the norm
+        const uint32_t nk = a.nrmpk_a[j][ic];
+        if (h) t.y = nk;
+      }
+      *reinterpret_cast<uint4*>(&b[j][s]) = t;
+    }
+  }
+  m.thr = a.thr * a.prod_a[ic];
+}
+
+__device__ __forceinline__ void retire_loads_bf16(const bf16x8 (&b)[3][3], const TileMeta& m) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const uint4 t = *reinterpret_cast<const uint4*>(&b[j][s]);
+      asm volatile("" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
+    }
+  asm volatile("" ::"v"(m.thr));
+}
+
+__device__ __forceinline__ void mfma_tile_bf16(const bf16x8 (&A)[3][3], const bf16x8 (&b)[3][3], f32x16 (&acc)[3],
+                                               const f32x16 (&accp)[3], const TileMeta& prev,
+                                               SurvSink& sk, const MatchArgs& a, int lane, int h, int64_t vtile) {
+  uint32_t mask = 0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][s], b[j][s], acc[j], 0, 0, 0);
+      const int u = 3 * j + s;                    // 0..8: two epilogue rows per MFMA gap
+      if (2 * u < 16) mask |= threshold_row(accp, prev, 2 * u, 0.f);
+      if (2 * u + 1 < 16) mask |= threshold_row(accp, prev, 2 * u + 1, 0.f);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+    }
+  }
+  emit_tile(sk, a, lane, h, vtile, prev.ok ? mask : 0u, prev.ic);
+}
+
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_match_bf16(MatchArgs a) {
   __shared__ unsigned long long s_surv[kWavesPerBlock][kSurvBuf];
   const int lane = threadIdx.x & 63;
@@ -365,10 +430,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_match_bf16(MatchArgs
   const int r = lane & 31, h = lane >> 5;
   const int64_t vt0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 32;
   SurvSink sk{s_surv[wave], 0};
-  if (vt0 < a.n_v) {
+  const int64_t a_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block * 32;
+  int64_t a_end = a_begin + (int64_t)a.audio_tiles_per_block * 32;
+  if (a_end > a.n_a) a_end = a.n_a;
+  if (vt0 < a.n_v && a_begin < a_end) {
     const int64_t vr = vt0 + r;
     const bool vok = vr < a.n_v;
     const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
+    const int64_t vtile = vt0 >> 5;
     bf16x8 A[3][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -378,43 +447,59 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_match_bf16(MatchArgs
       for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int k = 16 * s + 8 * h + e;
-          const float x = (k < kWin) ? (float)(p[k] * sc) : 0.f;
-          A[j][s][e] = (short)f32_to_bf16(x);
+          const int k = 24 * h + 8 * s + e;
+          uint16_t x = 0;
+          if (k < kWin) x = f32_to_bf16((float)(p[k] * sc));
+          else if (k == 42 || k == 43) x = 0x3F80;            // 1.0: the norm slots
+          A[j][s][e] = (short)x;
         }
     }
-    const int64_t a_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block * 32;
-    int64_t a_end = a_begin + (int64_t)a.audio_tiles_per_block * 32;
-    if (a_end > a.n_a) a_end = a.n_a;
-    for (int64_t at = a_begin; at < a_end; at += 32) {
-      const int64_t ia = at + r;
-      const bool aok = ia < a_end;
-      const int32_t ic = a.alist[aok ? ia : a_end - 1];
-      const int32_t st = ic + 8 * h;                 // first element of this lane's K-step-0 fragment
-      const bool odd = st & 1;
-      const int32_t ev = st - (odd ? 1 : 0);         // even element index into the chosen copy
-      f32x16 acc[3] = {{0}, {0}, {0}};
+    bf16x8 b0[3][3], b1[3][3];
+    TileMeta m0, m1;
+    f32x16 acc0[3], acc1[3];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const uint16_t* base = (odd ? a.bfa_odd[j] : a.bfa_even[j]) + ev;
+    for (int j = 0; j < 3; ++j) acc1[j] = f32x16{0};
+    m1.ok = false; m1.ic = 0; m1.thr = 0.f;
+    int64_t at = a_begin;
+    load_tile_bf16(a, at, a_end, r, h, fetch_index(a, at, a_end, r), b0, m0);
+    int32_t ic_next = fetch_index(a, at + 32, a_end, r);
+    while (true) {
+      {
+        const TileMeta prev = m1;
+        retire_loads_bf16(b0, m0);
+        asm volatile("" ::"v"(ic_next));
+        load_tile_bf16(a, at + 32, a_end, r, h, ic_next, b1, m1);
+        ic_next = fetch_index(a, at + 64, a_end, r);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const uint4 w = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(base) + 8 * s);
-          bf16x8 b;
-          *reinterpret_cast<uint4*>(&b) = w;
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][s], b, acc[j], 0, 0, 0);
+        for (int j = 0; j < 3; ++j) acc0[j] = f32x16{0};
+        mfma_tile_bf16(A, b0, acc0, acc1, prev, sk, a, lane, h, vtile);
+        at += 32;
+        if (at >= a_end) {
+          uint32_t m = 0;
+#pragma unroll
+          for (int g = 0; g < 16; ++g) m |= threshold_row(acc0, m0, g, 0.f);
+          emit_tile(sk, a, lane, h, vtile, m0.ok ? m : 0u, m0.ic);
+          break;
         }
       }
-      const float i0 = a.inv_a[0][ic], i1 = a.inv_a[1][ic], i2 = a.inv_a[2][ic];
-      uint32_t mask = 0;
+      {
+        const TileMeta prev = m0;
+        retire_loads_bf16(b1, m1);
+        asm volatile("" ::"v"(ic_next));
+        load_tile_bf16(a, at + 32, a_end, r, h, ic_next, b0, m0);
+        ic_next = fetch_index(a, at + 64, a_end, r);
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const float t0 = fmaf(acc[0][g], i0, 1.0f);
-        const float t1 = fmaf(acc[1][g], i1, 1.0f);
-        const float t2 = fmaf(acc[2][g], i2, 1.0f);
-        if (t0 * t1 * t2 <= a.thr) mask |= 1u << g;
+        for (int j = 0; j < 3; ++j) acc1[j] = f32x16{0};
+        mfma_tile_bf16(A, b1, acc1, acc0, prev, sk, a, lane, h, vtile);
+        at += 32;
+        if (at >= a_end) {
+          uint32_t m = 0;
+#pragma unroll
+          for (int g = 0; g < 16; ++g) m |= threshold_row(acc1, m1, g, 0.f);
+          emit_tile(sk, a, lane, h, vtile, m1.ok ? m : 0u, m1.ic);
+          break;
+        }
       }
-      emit_tile(sk, a, lane, h, vt0 >> 5, aok ? mask : 0u, ic);
     }
   }
   sink_flush(sk, a, lane);
@@ -470,15 +555,16 @@ void launch_corr(const CorrArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // exact verification of survivors (float64), hash vote, quality (:649-673)
 // ------------------------------------------------------------------------------------------
-__device__ inline void verify_pair(const VerifyArgs& a, int32_t i, int32_t v) {
+// exact float64 re-evaluation of one pair; returns true and the quality when it is a match
+__device__ inline bool verify_pair(const VerifyArgs& a, int32_t i, int32_t v, double& q_out) {
   if (a.mode == 0) {
     int hits012 = 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) hits012 += digit_hit(a.dig_a[j][i], a.dig_v[j][v], a.flg_v[j][v]) ? 1 : 0;
-    if (hits012 < 2) return;
+    if (hits012 < 2) return false;
     const bool h3 = digit_hit(a.dig_a[3][i], a.dig_v[3][v], a.flg_v[3][v]);
     const bool h4 = h3 ? true : digit_hit(a.dig_a[4][i], a.dig_v[4][v], a.flg_v[4][v]);
-    if (!h4) return;
+    if (!h4) return false;
   }
   double prob = 1.0;
 #pragma unroll
@@ -493,41 +579,77 @@ __device__ inline void verify_pair(const VerifyArgs& a, int32_t i, int32_t v) {
     prob *= (t > 1e-8 ? t : 1e-8);
   }
   prob = pow(prob, 2.9);
-  if (prob > 1e-8) return;
-  double q = pow(prob / 1e-12, -1.0 / 3.0);
-  q = q < 50.0 ? q : 50.0;
-  const unsigned long long pos = atomicAdd(a.n_out, 1ull);
-  if (pos < a.out_capacity) {
-    a.keys[pos] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v;
-    a.quals[pos] = q;
-  }
+  if (prob > 1e-8) return false;
+  const double q = pow(prob / 1e-12, -1.0 / 3.0);
+  q_out = q < 50.0 ? q : 50.0;
+  return true;
 }
 
-// one thread per staged record: expand its row mask into (i, v) pairs and verify each
-__global__ __launch_bounds__(256) void k_verify(VerifyArgs a, unsigned long long n_rec) {
-  const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long rec = (p < n_rec) ? a.surv[p] : 0ull;
-  const int32_t i = (int32_t)(rec >> 41);
-  const int64_t vtile = (int64_t)((rec >> 17) & 0xFFFFFFull);
-  const int h = (int)((rec >> 16) & 1ull);
-  uint32_t mask = (uint32_t)(rec & 0xFFFFull);
-  // pair count for the statistics: one atomic per wave
-  unsigned int cnt = (unsigned int)__popc(mask);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(a.n_pairs, (unsigned long long)cnt);
-  while (mask != 0u) {
-    const int g = __ffs(mask) - 1;
-    mask &= mask - 1u;
-    const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
-    const int64_t vr = vtile * 32 + row;
-    if (vr < a.n_v) verify_pair(a, i, a.vlist[vr]);
+// Grid-stride over the staged records: expand each row mask into (i, v) pairs, verify, and stage
+// the matches of the whole block in LDS; output space is reserved with ONE global atomic per
+// flush (a single hot counter sustains only ~90 atomics/us, and there are up to 1e9 pairs).
+constexpr int kVerifyThreads = 256;
+constexpr int kVerifyStage = 1024;
+
+__global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyArgs a, unsigned long long n_rec) {
+  __shared__ unsigned long long s_key[kVerifyStage];
+  __shared__ double s_q[kVerifyStage];
+  __shared__ unsigned int s_n;
+  __shared__ unsigned long long s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const unsigned long long stride = (unsigned long long)gridDim.x * kVerifyThreads;
+  const unsigned long long rounds = (n_rec + stride - 1) / stride;
+  for (unsigned long long rnd = 0; rnd < rounds; ++rnd) {
+    const unsigned long long p = rnd * stride + (unsigned long long)blockIdx.x * kVerifyThreads + threadIdx.x;
+    const unsigned long long rec = (p < n_rec) ? a.surv[p] : 0ull;
+    const int32_t i = (int32_t)(rec >> 41);
+    const int64_t vtile = (int64_t)((rec >> 17) & 0xFFFFFFull);
+    const int h = (int)((rec >> 16) & 1ull);
+    uint32_t mask = (uint32_t)(rec & 0xFFFFull);
+    while (mask != 0u) {
+      const int g = __ffs(mask) - 1;
+      mask &= mask - 1u;
+      const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
+      const int64_t vr = vtile * 32 + row;
+      double q;
+      if (vr < a.n_v) {
+        const int32_t v = a.vlist[vr];
+        if (verify_pair(a, i, v, q)) {
+          const unsigned int pos = atomicAdd(&s_n, 1u);
+          if (pos < (unsigned)kVerifyStage) {
+            s_key[pos] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v;
+            s_q[pos] = q;
+          } else {                                   // stage full: rare, go straight to global
+            const unsigned long long gp = atomicAdd(a.n_out, 1ull);
+            if (gp < a.out_capacity) { a.keys[gp] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v; a.quals[gp] = q; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // flush when the stage could overflow in the next round (each thread adds at most 16)
+    const unsigned int n = s_n < (unsigned)kVerifyStage ? s_n : (unsigned)kVerifyStage;
+    const bool last = (rnd + 1 == rounds);
+    if (n > (unsigned)(kVerifyStage / 2) || (last && n > 0)) {
+      if (threadIdx.x == 0) s_base = atomicAdd(a.n_out, (unsigned long long)n);
+      __syncthreads();
+      for (unsigned int t = threadIdx.x; t < n; t += kVerifyThreads) {
+        const unsigned long long gp = s_base + t;
+        if (gp < a.out_capacity) { a.keys[gp] = s_key[t]; a.quals[gp] = s_q[t]; }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_n = 0;
+      __syncthreads();
+    }
   }
 }
 
 void launch_verify(const VerifyArgs& a, unsigned long long n_surv_host, hipStream_t s) {
   if (n_surv_host == 0) return;
-  hipLaunchKernelGGL(k_verify, dim3((unsigned)((n_surv_host + 255) / 256)), dim3(256), 0, s, a, n_surv_host);
+  unsigned long long blocks = (n_surv_host + kVerifyThreads - 1) / kVerifyThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(k_verify, dim3((unsigned)blocks), dim3(kVerifyThreads), 0, s, a, n_surv_host);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -50,6 +50,36 @@ class Group:
     self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
     return float(t.item())
 
+  def all_gather_matches(self, mi, mv, mq):
+    """The one exchange step of a single long pair tiled over ranks: every
+    rank matched its own contiguous block of audio rows; gather counts, then the padded (i, v, q)
+    lists, and concatenate in rank order -- which is (i, v) order, because blocks are contiguous
+    and each rank's list is already sorted.  With RCCL the tensors live in HBM and travel over
+    xGMI; with gloo (tests) they are host tensors."""
+    import numpy as np
+    if self.dist is None:
+      return mi, mv, mq
+    import torch
+    dev = self.device
+    n = torch.tensor([len(mi)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+    self.dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    cap = max(1, max(counts))
+    # one int64 payload: i, v and the float64 quality bit pattern, padded to the largest count
+    buf = np.zeros((3, cap), dtype=np.int64)
+    buf[0, :len(mi)] = mi; buf[1, :len(mv)] = mv
+    buf[2, :len(mq)] = np.ascontiguousarray(mq, dtype=np.float64).view(np.int64)
+    mine = torch.from_numpy(buf).to(dev)
+    parts = [torch.empty_like(mine) for _ in range(self.world)]
+    self.dist.all_gather(parts, mine)
+    out_i, out_v, out_q = [], [], []
+    for r, c in enumerate(counts):
+      a = parts[r].cpu().numpy()
+      out_i.append(a[0, :c].astype(np.int32)); out_v.append(a[1, :c].astype(np.int32))
+      out_q.append(a[2, :c].copy().view(np.float64))
+    return np.concatenate(out_i), np.concatenate(out_v), np.concatenate(out_q)
+
   def close(self):
     if self.dist is not None:
       self.dist.destroy_process_group()
@@ -60,3 +90,15 @@ def shard_pairs(n_pairs: int, world: int):
   """Round-robin assignment of pair indices to ranks/GPUs (no collectives needed)."""
   world = max(1, int(world))
   return [list(range(r, n_pairs, world)) for r in range(world)]
+
+
+def row_blocks(n_rows: int, world: int):
+  """Contiguous [begin, end) audio-row blocks, one per rank, sizes differing by at most one."""
+  world = max(1, int(world))
+  base, extra = divmod(max(0, int(n_rows)), world)
+  out, b = [], 0
+  for r in range(world):
+    e = b + base + (1 if r < extra else 0)
+    out.append((b, e))
+    b = e
+  return out

@@ -145,6 +145,15 @@ def test_synth_is_deterministic_and_chunk_invariant():
   assert p.audio.shape[1] == p.video.shape[1] + 3 * 44100 and p.true_offset_at(12.0) == 3.0
 
 
+def test_row_blocks_cover_exactly():
+  from describealign_amd.distrib import row_blocks
+  for n, w in ((10, 3), (7, 8), (0, 2), (1000003, 8)):
+    b = row_blocks(n, w)
+    assert len(b) == w and b[0][0] == 0 and b[-1][1] == n
+    assert all(b[k][1] == b[k + 1][0] for k in range(w - 1))
+    assert max(e - s for s, e in b) - min(e - s for s, e in b) <= 1
+
+
 _GLOO_WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])
@@ -157,6 +166,15 @@ m = g.max_over_ranks(10.0 + g.rank)
 s = g.sum_over_ranks(float(len(mine)))
 assert m == 10.0 + g.world - 1, m
 assert s == 5.0, s
+# the one exchange step of the tiled single-pair mode: ragged per-rank match lists
+import numpy as np
+n = 3 + 4 * g.rank
+mi = (np.arange(n) + 100 * g.rank).astype(np.int32); mv = (np.arange(n) * 4).astype(np.int32)
+mq = np.linspace(0.5, 50.0, n) + g.rank
+gi, gv, gq = g.all_gather_matches(mi, mv, mq)
+assert len(gi) == 3 + 7 and gi.dtype == np.int32 and gq.dtype == np.float64
+assert np.array_equal(gi[:3], np.arange(3)) and np.array_equal(gi[3:], np.arange(7) + 100)
+assert np.array_equal(gq[3:], np.linspace(0.5, 50.0, 7) + 1)
 g.barrier()
 g.close()
 print("rank", g.rank, "ok", mine)
