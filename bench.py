@@ -60,7 +60,7 @@ def main():
   ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS))
   ap.add_argument("--precision", default=None, choices=["f32", "bf16"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--pipeline", type=int, default=12,
+  ap.add_argument("--pipeline", type=int, default=16,
                   help="host LP worker processes; pair k+1's GPU/DP stages overlap pair k's LP (0 = strictly sequential)")
   args = ap.parse_args()
 
@@ -173,13 +173,24 @@ def main():
                         "ms_per_step": acc["feat_ms"] / k},
       "stage_ms_per_step": {n: round(acc[n] / k, 3) for n in ("feat_ms", "prep_ms", "gemm_ms", "verify_ms", "chain_ms",
                                                               "refine_kernel_ms", "refine_dp_ms")},
-      "host_s_per_step": {"lp": round(acc["lp_s"] / k, 4), "align_latency_per_pair": round(acc["align_s"] / k, 4)},
+      "host_s_per_step": {"lp": round(acc["lp_s"] / k, 4), "align_latency_per_pair": round(acc["align_s"] / k, 4),
+                          "gpu_match_stage_wall": round(acc["match_s"] / k, 4)},
       "pipeline": {"lp_worker_processes": args.pipeline, "host_cores": os.cpu_count(),
                    "note": "GPU + DP stages of pair k+1 overlap the host LP of pair k; results identical to sequential align()"},
       "counts": {"gemm_pairs": acc["gemm_pairs"] / k, "survivors": acc["survivors"] / k, "matches": acc["matches"] / k},
       "max_offset_err_vs_injected_ms": round(inj_err_ms, 3),
       "pcm_h2d_ms_audio_side": round(h2d_ms, 2),
     }
+    # HBM traffic of the dominant kernel from the committed PMC profile of this workload (PMC
+    # collection needs its own rocprofv3 passes; bench.py itself only times with HIP events)
+    try:
+      prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+      key = {"cfg1": "cfg1_" + prec_name}.get(args.workload)
+      if key in prof:
+        res["roofline"]["traffic"] = prof[key]["k_match_" + prec_name]["traffic_bytes_per_launch"]
+        res["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    except Exception:
+      pass
     if world == 1 and not args.no_cpu_baseline:
       spair, (ox, oy), cb = cpu_baseline()
       # same sample through the GPU path: max |node time| difference vs the CPU reference port

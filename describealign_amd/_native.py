@@ -25,7 +25,7 @@ ERR_CAPACITY = -3
 ERR_MISMATCH = -4
 
 EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm_upload",
-           "da_features_resident", "da_features", "da_match", "da_match_corr", "da_chain",
+           "da_features_resident", "da_features", "da_match", "da_match_fetch", "da_match_corr", "da_chain",
            "da_refine", "da_stats"]
 
 
@@ -73,6 +73,7 @@ def load():
     lib.da_features_resident.argtypes = [vp, i32, vp, i64, P(i64)]
     lib.da_features.argtypes = [vp, vp, i64, i32, i32, vp, i64, P(i64)]
     lib.da_match.argtypes = [vp, vp, i64, P(i64), vp, i64, P(i64), i32, i64, i64, vp, vp, vp, P(i64)]
+    lib.da_match_fetch.argtypes = [vp, vp, vp, vp, i64]
     lib.da_match_corr.argtypes = [vp, vp, vp, i64, vp]
     lib.da_chain.argtypes = [vp, vp, vp, vp, i64, C.c_double, vp, vp, P(i64)]
     lib.da_refine.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, vp, i32, C.c_double, vp, P(i64), P(i64)]
@@ -151,10 +152,10 @@ class Context:
       self._check(self._lib.da_features_resident(self._h, side, None, 0, lengths))
       return None
     le = ((self._n[side] // 105) + 1) // 2
-    out = np.zeros((5, max(le, 1)), dtype=np.float32)
+    out = np.empty((5, max(le, 1)), dtype=np.float32)
     self._check(self._lib.da_features_resident(self._h, side, _ptr(out), out.shape[1], lengths))
     le, lo = lengths[0], lengths[1]
-    return [out[0, :le].copy()] + [out[k, :lo].copy() for k in range(1, 5)]
+    return [out[0, :le]] + [out[k, :lo] for k in range(1, 5)]      # row views of one buffer
 
   def features(self, pcm: np.ndarray, side: int = SIDE_VIDEO):
     """Upload + feature kernel: the five feature rows as a list of float32 arrays."""
@@ -177,19 +178,17 @@ class Context:
     vrows, vlen = self._pack_rows(video_features)
     arows, alen = self._pack_rows(audio_features)
     rb, re = (0, -1) if rows is None else rows
-    cap = int(capacity or max(1 << 20, int(3e-4 * vlen[0] * alen[0] / 4) + (1 << 16)))
-    for _ in range(2):
-      oi = np.empty(cap, dtype=np.int32); ov = np.empty(cap, dtype=np.int32); oq = np.empty(cap, dtype=np.float64)
-      n = C.c_int64(cap)
-      rc = self._lib.da_match(self._h, _ptr(vrows), vrows.shape[1], vlen, _ptr(arows), arows.shape[1], alen,
-                              mode, rb, re, _ptr(oi), _ptr(ov), _ptr(oq), C.byref(n))
-      if rc == ERR_CAPACITY:
-        cap = int(n.value) + 1024
-        continue
+    # phase 1: compute (results stay on the device), learn the count; phase 2: exact-size fetch
+    n = C.c_int64(0)
+    rc = self._lib.da_match(self._h, _ptr(vrows), vrows.shape[1], vlen, _ptr(arows), arows.shape[1], alen,
+                            mode, rb, re, None, None, None, C.byref(n))
+    if rc != ERR_CAPACITY:
       self._check(rc)
-      k = n.value
-      return oi[:k].copy(), ov[:k].copy(), oq[:k].copy()
-    raise RuntimeError("da_match: capacity negotiation failed")
+    k = n.value
+    oi = np.empty(k, dtype=np.int32); ov = np.empty(k, dtype=np.int32); oq = np.empty(k, dtype=np.float64)
+    if k:
+      self._check(self._lib.da_match_fetch(self._h, _ptr(oi), _ptr(ov), _ptr(oq), k))
+    return oi, ov, oq
 
   def match_corr(self, i, v):
     i = np.ascontiguousarray(i, dtype=np.int32); v = np.ascontiguousarray(v, dtype=np.int32)

@@ -405,6 +405,11 @@ class AlignPipeline:
     self._local = threading.local()
     self._ctxs = []
     self._lock = threading.Lock()
+    # the calling thread re-acquires the GIL after every ctypes call; with the default 5 ms switch
+    # interval those hand-offs (behind worker threads doing numpy) cost more than the GPU work
+    import sys
+    self._old_switch = sys.getswitchinterval()
+    sys.setswitchinterval(2e-4)
 
   def _thread_ctx(self):
     c = getattr(self._local, "ctx", None)
@@ -430,6 +435,8 @@ class AlignPipeline:
     for c in self._ctxs:
       c.close()
     self._ctxs = []
+    import sys
+    sys.setswitchinterval(self._old_switch)
 
   def _rest(self, matches, vf, af, tm):
     ctx = self._thread_ctx()

@@ -63,6 +63,7 @@ struct da_ctx {
   DevBuf pair_i, pair_v, pair_c;
   DevBuf ascaled, vscaled, band_y, band_q, band_part;
   bool match_ready = false;
+  unsigned long long n_match_resident = 0;
   MatchArgs last_match{};
   da_stats_t st{};
 };
@@ -421,16 +422,32 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
     float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.verify_ms = ms;
   }
   c->st.matches = (double)n_match;
+  c->n_match_resident = n_match;
+  if (n_match > 0) {
+    // keys0 is free again after the sort: unpack the sorted keys into two int32 arrays there
+    launch_unpack_keys(c->keys1.as<unsigned long long>(), (int64_t)n_match, c->keys0.as<int32_t>(),
+                       c->keys0.as<int32_t>() + n_match, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   const int64_t capacity = *n_out;
   *n_out = (int64_t)n_match;
   if ((int64_t)n_match > capacity) return fail(c, DA_ERR_CAPACITY, "da_match: %llu matches exceed the caller's capacity %lld", n_match, (long long)capacity);
-  if (n_match > 0) {
-    if (!out_i || !out_v || !out_q) return fail(c, DA_ERR_ARG, "da_match: null output");
-    std::vector<unsigned long long> keys(n_match);
-    HIP_TRY(c, hipMemcpy(keys.data(), c->keys1.p, sizeof(unsigned long long) * n_match, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(out_q, c->q1.p, sizeof(double) * n_match, hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < n_match; ++k) { out_i[k] = (int32_t)(keys[k] >> 32); out_v[k] = (int32_t)(keys[k] & 0xffffffffu); }
-  }
+  return da_match_fetch(c, out_i, out_v, out_q, (int64_t)n_match);
+}
+
+extern "C" int da_match_fetch(da_ctx* c, int32_t* out_i, int32_t* out_v, double* out_q, int64_t n) {
+  if (!c) return DA_ERR_ARG;
+  if (!c->match_ready) return fail(c, DA_ERR_STATE, "da_match_fetch: call da_match first");
+  if (n < 0 || (uint64_t)n > c->n_match_resident) return fail(c, DA_ERR_ARG, "da_match_fetch: n out of range");
+  if (n == 0) return DA_OK;
+  if (!out_i || !out_v || !out_q) return fail(c, DA_ERR_ARG, "da_match_fetch: null output");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int32_t* d_i = c->keys0.as<int32_t>();
+  HIP_TRY(c, hipMemcpyAsync(out_i, d_i, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out_v, d_i + c->n_match_resident, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out_q, c->q1.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return DA_OK;
 }
 

@@ -96,6 +96,9 @@ struct VerifyArgs {
 };
 void launch_verify(const VerifyArgs& a, unsigned long long n_surv_host, hipStream_t s);
 
+// split sorted keys (i << 32 | v) into two int32 arrays
+void launch_unpack_keys(const unsigned long long* keys, int64_t n, int32_t* out_i, int32_t* out_v, hipStream_t s);
+
 // device radix sort of (key, qual) pairs (hipCUB); returns 0 on success
 int sort_pairs(unsigned long long* keys_in, unsigned long long* keys_out, double* vals_in, double* vals_out,
                int64_t n, void* temp, size_t* temp_bytes, hipStream_t s);

@@ -645,6 +645,18 @@ __global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyArgs a, unsigne
   }
 }
 
+__global__ void k_unpack_keys(const unsigned long long* __restrict__ keys, int64_t n, int32_t* __restrict__ oi, int32_t* __restrict__ ov) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const unsigned long long k = keys[p];
+  oi[p] = (int32_t)(k >> 32);
+  ov[p] = (int32_t)(k & 0xffffffffu);
+}
+void launch_unpack_keys(const unsigned long long* keys, int64_t n, int32_t* out_i, int32_t* out_v, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_unpack_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, n, out_i, out_v);
+}
+
 void launch_verify(const VerifyArgs& a, unsigned long long n_surv_host, hipStream_t s) {
   if (n_surv_host == 0) return;
   unsigned long long blocks = (n_surv_host + kVerifyThreads - 1) / kVerifyThreads;

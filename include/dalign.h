@@ -73,6 +73,11 @@ int da_match(da_ctx* ctx,
              int mode, int64_t audio_row_begin, int64_t audio_row_end,
              int32_t* out_i, int32_t* out_v, double* out_q, int64_t* n_out);
 
+/* Copy out the matches of the most recent da_match (they stay resident on the device until the
+ * next da_match): lets a caller run da_match with *n_out = 0 to learn the count (it returns
+ * DA_ERR_CAPACITY and the count) and then fetch into exactly sized buffers. */
+int da_match_fetch(da_ctx* ctx, int32_t* out_i, int32_t* out_v, double* out_q, int64_t n);
+
 /* Correlation values of the similarity GEMM for explicit (i, v) pairs, as the selected
  * precision computes them (testing/diagnostics: "similarity values within 1e-3").
  * corr receives [n][3].  Uses the feature rows of the last da_match call. */
