@@ -55,8 +55,8 @@ def cpu_baseline(sample_seconds=600.0):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=5)
-  ap.add_argument("--warmup", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=32)
+  ap.add_argument("--warmup", type=int, default=4)
   ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS))
   ap.add_argument("--precision", default=None, choices=["f32", "bf16"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
