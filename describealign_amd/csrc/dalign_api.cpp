@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -339,6 +340,7 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
   // bf16 operands carry 2^-9 relative rounding each, so the product of three (1-corr) terms is
   // thresholded with a factor-2 margin and everything is re-verified in float64 afterwards.
   m.thr = (float)(thr_exact * (c->precision == DA_PREC_F32 ? 1.001 : 2.0));
+  if (const char* dbg = std::getenv("DALIGN_DEBUG_THR_SCALE")) m.thr *= (float)std::atof(dbg);   // profiling only
   // audio chunking: enough blocks to fill the chip several times over
   {
     const int64_t vblocks = ((n_v + 31) / 32 + 3) / 4;
@@ -366,6 +368,11 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
     HIP_TRY(c, hipMemcpyAsync(&n_surv, d_cnt, sizeof n_surv, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1); c->st.gemm_ms = ms;
+    if (std::getenv("DALIGN_DEBUG_STAMPS")) {
+      unsigned long long st[16]; debug_read_stamps(st);
+      unsigned long long tot = 0; for (int k = 0; k < 10; ++k) tot += st[k];
+      if (tot) { std::fprintf(stderr, "stamps(%%):"); for (int k = 0; k < 10; ++k) std::fprintf(stderr, " %d:%.1f", k, 100.0 * st[k] / tot); std::fprintf(stderr, "  total_cycles_per_wave=%.0f\n", (double)tot); }
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (n_surv <= cap) break;
     cap = (size_t)(n_surv + n_surv / 16 + 1024);

@@ -77,6 +77,7 @@ struct MatchArgs {
 };
 void launch_match_f32(const MatchArgs& a, hipStream_t s);
 void launch_match_bf16(const MatchArgs& a, hipStream_t s);
+void debug_read_stamps(unsigned long long out[16]);   // diagnostic builds only (zeros otherwise)
 
 struct CorrArgs {   // diagnostics: GEMM-precision correlations for explicit pairs
   MatchArgs m; const int32_t* pi; const int32_t* pv; int64_t n; float* corr; int precision;

@@ -15,6 +15,7 @@ namespace da {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load, 4-byte aligned
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -144,6 +145,7 @@ constexpr int kSurvBuf = 256;          // survivor staging slots per wave (LDS)
 struct SurvSink {
   unsigned long long* s_buf;           // this wave's LDS staging
   int count;                           // wave-uniform
+  int cap = kSurvBuf;                  // slots in s_buf
 };
 
 __device__ inline void sink_flush(SurvSink& sk, const MatchArgs& a, int lane) {
@@ -162,7 +164,7 @@ __device__ inline void sink_push(SurvSink& sk, const MatchArgs& a, int lane, boo
   const unsigned long long m = __ballot(pass);
   if (m == 0ull) return;
   const int n = __popcll(m);
-  if (sk.count + n > kSurvBuf) sink_flush(sk, a, lane);
+  if (sk.count + n > sk.cap) sink_flush(sk, a, lane);
   if (pass) {
     const int pos = sk.count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     sk.s_buf[pos] = rec;
@@ -218,6 +220,17 @@ __device__ __forceinline__ uint32_t threshold_row(const f32x16 (&acc)[3], const 
   return (acc[0][g] * acc[1][g] * acc[2][g] <= m.thr) ? (1u << g) : 0u;
 }
 
+// Two rows at once: packed products, then for each row  mask = 2*mask + (prod <= thr)  as one
+// compare + one add-with-carry.  Rows must be fed in descending order (row g ends at bit g).
+__device__ __forceinline__ void threshold_rows2(const f32x16 (&acc)[3], float thr, int g_hi, uint32_t& mask) {
+  const f32x2 x0 = {acc[0][g_hi - 1], acc[0][g_hi]};
+  const f32x2 x1 = {acc[1][g_hi - 1], acc[1][g_hi]};
+  const f32x2 x2 = {acc[2][g_hi - 1], acc[2][g_hi]};
+  const f32x2 pr = x0 * x1 * x2;
+  asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[1]), "v"(thr) : "vcc");
+  asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[0]), "v"(thr) : "vcc");
+}
+
 // Survivors of one tile: mask bit g <-> accumulator register g of this lane.  Each lane that has
 // any stages ONE compact record  [63:41] audio frame | [40:17] video tile | [16] lane half | [15:0] mask
 // (wave-aggregated slot in LDS, no loops here); k_verify expands the bits into (i, v) pairs.
@@ -242,7 +255,7 @@ __device__ __forceinline__ void mfma_tile_f32(const float (&A)[3][21], const flo
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][s], b[1][s], acc[1], 0, 0, 0);
     acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[2][s], b[2][s], acc[2], 0, 0, 0);
 #ifndef DA_DBG_NO_EPILOGUE
-    if (s < 16) mask |= threshold_row(accp, prev, s, thr);
+    if (s < 16 && (s & 1) == 0) threshold_rows2(accp, prev.thr, 15 - s, mask);     // rows 15-s, 14-s
 #endif
     // per MFMA triple: one operand load of the next tile and a slice of the epilogue
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
@@ -360,18 +373,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 1) void k_match_f32(MatchArgs 
 // ------------------------------------------------------------------------------------------
 // similarity GEMM, bf16 inputs / f32 accumulate on v_mfma_f32_32x32x16_bf16 (a PREFILTER: every
 // survivor is re-verified in float64 by k_verify).
-// K = 41 padded to 48 = three K-steps of 16.  K is permuted so that lane half h, step s, element e
-// holds k = 24 h + 8 s + e: each lane's operands are 24 consecutive bf16 (3 x 16-byte loads; the
-// two shifted copies of the row make any start 4-byte aligned).  Spare slots k = 42, 43 carry the
-// audio window norm split into two bf16 (A holds 1 there), so the accumulator ends as
-// |A| (1 - corr) and the epilogue is 2 multiplies + 1 compare against thr |A|_0 |A|_1 |A|_2.
-// Same software pipeline as the f32 kernel (prefetch of tile t+1, epilogue of tile t-1 under the
-// MFMAs of tile t), two waves per SIMD.
+// K = 41 padded to 48 = three K-steps of 16, permuted so that lane half h, step s, element e holds
+// k = 24 h + 8 s + e (each lane's operands are 24 consecutive bf16; two shifted copies of the row
+// make any start 4-byte aligned).  Spare slots k = 42, 43 carry the audio window norm split into
+// two bf16 (A holds 1 there): the accumulator ends as |A| (1 - corr) and the epilogue is
+// 2 multiplies + 1 compare against thr |A|_0 |A|_1 |A|_2.
+//
+// Workgroup = 4 waves x 64 video rows (two 32-row MFMA tiles per wave, A operand in 72 VGPRs).
+// The streamed audio operand is shared by all four waves: it is staged in LDS in MFMA fragment
+// order [tile][feature][step][lane] (1 KiB per fragment) by direct global->LDS DMA, one group of
+// four 32-column tiles at a time, double buffered: the DMA of group g+1 is in flight while group
+// g is consumed (wave w stages tile w of the group).  Two workgroups per CU = two waves per SIMD,
+// so one wave's VALU epilogue runs under the other's MFMAs.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_tile_bf16(const MatchArgs& a, int64_t at, int64_t a_end, int r, int h, int32_t ic,
-                                               bf16x8 (&b)[3][3], TileMeta& m) {
-  m.ok = (at + r) < a_end;
-  m.ic = ic;
+constexpr int kBfGroup = 4;                           // tiles per staged group (= waves per block)
+constexpr int kBfTileBytes = 9 * 1024;                // 3 features x 3 steps x 64 lanes x 16 B
+constexpr int kBfBufBytes = kBfGroup * kBfTileBytes;  // one group
+constexpr int kBfSurv = 128;                          // survivor staging slots per wave (keeps two workgroups per CU)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void stage_tile_bf16(const MatchArgs& a, unsigned char* tile_lds, int32_t ic, int h) {
   const int32_t st = ic + 24 * h;                // first element of this lane's run
   const int32_t odd = st & 1;
   const int32_t ev = st - odd;                   // even element index into the chosen copy
@@ -380,65 +402,46 @@ __device__ __forceinline__ void load_tile_bf16(const MatchArgs& a, int64_t at, i
     const uint16_t* base = (odd ? a.bfa_odd[j] : a.bfa_even[j]) + ev;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      const u32x4u w = *reinterpret_cast<const u32x4u*>(base + 8 * s);
-      uint4 t = make_uint4(w[0], w[1], w[2], w[3]);
-      if (s == 2) {                                // k = 40..47 for h = 1: slots 42, 43 carry the norm
-        const uint32_t nk = a.nrmpk_a[j][ic];
-        if (h) t.y = nk;
-      }
-      *reinterpret_cast<uint4*>(&b[j][s]) = t;
+      unsigned char* dst = tile_lds + (3 * j + s) * 1024;        // + lane*16 added by the hardware
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + 8 * s), (lds_ptr_t)dst, 16, 0, 0);
     }
   }
-  m.thr = a.thr * a.prod_a[ic];
 }
 
-__device__ __forceinline__ void retire_loads_bf16(const bf16x8 (&b)[3][3], const TileMeta& m) {
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const uint4 t = *reinterpret_cast<const uint4*>(&b[j][s]);
-      asm volatile("" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
-    }
-  asm volatile("" ::"v"(m.thr));
-}
+#ifdef DA_DBG_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 
-__device__ __forceinline__ void mfma_tile_bf16(const bf16x8 (&A)[3][3], const bf16x8 (&b)[3][3], f32x16 (&acc)[3],
-                                               const f32x16 (&accp)[3], const TileMeta& prev,
-                                               SurvSink& sk, const MatchArgs& a, int lane, int h, int64_t vtile) {
-  uint32_t mask = 0;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][s], b[j][s], acc[j], 0, 0, 0);
-      const int u = 3 * j + s;                    // 0..8: two epilogue rows per MFMA gap
-      if (2 * u < 16) mask |= threshold_row(accp, prev, 2 * u, 0.f);
-      if (2 * u + 1 < 16) mask |= threshold_row(accp, prev, 2 * u + 1, 0.f);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
-    }
-  }
-  emit_tile(sk, a, lane, h, vtile, prev.ok ? mask : 0u, prev.ic);
-}
-
-__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_match_bf16(MatchArgs a) {
-  __shared__ unsigned long long s_surv[kWavesPerBlock][kSurvBuf];
+__global__ __launch_bounds__(256, 2) void k_match_bf16(MatchArgs a) {
+#ifdef DA_DBG_STAMPS
+  unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory");
+#endif
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_b = smem;                                                        // [2][kBfGroup][9 KiB]
+  unsigned long long* s_surv = reinterpret_cast<unsigned long long*>(smem + 2 * kBfBufBytes);   // [4][kBfSurv]
+  float* s_thr = reinterpret_cast<float*>(smem + 2 * kBfBufBytes + 4 * kBfSurv * 8);           // [2][kBfGroup][32]
+  int32_t* s_ic = reinterpret_cast<int32_t*>(s_thr + 2 * kBfGroup * 32);                        // [2][kBfGroup][32]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t vt0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 32;
-  SurvSink sk{s_surv[wave], 0};
+  const int64_t vt0 = ((int64_t)blockIdx.x * 4 + wave) * 64;              // this wave's first video row
+  SurvSink sk{s_surv + wave * kBfSurv, 0, kBfSurv};
   const int64_t a_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block * 32;
   int64_t a_end = a_begin + (int64_t)a.audio_tiles_per_block * 32;
   if (a_end > a.n_a) a_end = a.n_a;
-  if (vt0 < a.n_v && a_begin < a_end) {
-    const int64_t vr = vt0 + r;
+  if (a_begin >= a_end) return;                                           // uniform per block
+
+  // fixed operand: 2 x 32 video rows, pre-scaled by -1/|V| (rows past the end stay inert)
+  bf16x8 A[2][3][3];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int64_t vr = vt0 + 32 * t + r;
     const bool vok = vr < a.n_v;
     const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
-    const int64_t vtile = vt0 >> 5;
-    bf16x8 A[3][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const double sc = vok ? -(double)a.inv_v[j][v] : 0.0;
@@ -451,58 +454,125 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void k_match_bf16(MatchArgs
           uint16_t x = 0;
           if (k < kWin) x = f32_to_bf16((float)(p[k] * sc));
           else if (k == 42 || k == 43) x = 0x3F80;            // 1.0: the norm slots
-          A[j][s][e] = (short)x;
+          A[t][j][s][e] = (short)x;
         }
     }
-    bf16x8 b0[3][3], b1[3][3];
-    TileMeta m0, m1;
-    f32x16 acc0[3], acc1[3];
+  }
+
+  const int64_t n_groups = (a_end - a_begin + 32 * kBfGroup - 1) / (32 * kBfGroup);
+  // stage group 0 (wave w stages tile w), and fetch the row indices of group 1
+  auto tile_pos = [&](int64_t g, int w) { return a_begin + (g * kBfGroup + w) * 32; };
+  // per-lane patch value of the tile this wave stages: h = 1 lanes need the three packed norms,
+  // h = 0 lanes the column threshold; fetched one group ahead like the row indices
+  auto fetch_patch = [&](int32_t ic, uint32_t (&pv)[3]) {
+    if (h) { pv[0] = a.nrmpk_a[0][ic]; pv[1] = a.nrmpk_a[1][ic]; pv[2] = a.nrmpk_a[2][ic]; }
+    else { pv[0] = __float_as_uint(a.prod_a[ic]); pv[1] = 0; pv[2] = 0; }
+  };
+  int32_t ic_cur = fetch_index(a, tile_pos(0, wave), a_end, r);
+  uint32_t pv_cur[3], pv_nxt[3] = {0, 0, 0};
+  fetch_patch(ic_cur, pv_cur);
+  stage_tile_bf16(a, s_b + wave * kBfTileBytes, ic_cur, h);
+  int32_t ic_nxt = fetch_index(a, tile_pos(1, wave), a_end, r);
+  for (int64_t g = 0; g < n_groups; ++g) {
+    const int cur = (int)(g & 1);
+    if (g > 0) { pv_cur[0] = pv_nxt[0]; pv_cur[1] = pv_nxt[1]; pv_cur[2] = pv_nxt[2]; }
+    STAMP(0);
+    // ---- finish staging of group g: wait for this wave's DMA, patch the norm slots, publish
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(1);
+    {
+      unsigned char* tile = s_b + cur * kBfBufBytes + wave * kBfTileBytes;
+      if (h) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) acc1[j] = f32x16{0};
-    m1.ok = false; m1.ic = 0; m1.thr = 0.f;
-    int64_t at = a_begin;
-    load_tile_bf16(a, at, a_end, r, h, fetch_index(a, at, a_end, r), b0, m0);
-    int32_t ic_next = fetch_index(a, at + 32, a_end, r);
-    while (true) {
-      {
-        const TileMeta prev = m1;
-        retire_loads_bf16(b0, m0);
-        asm volatile("" ::"v"(ic_next));
-        load_tile_bf16(a, at + 32, a_end, r, h, ic_next, b1, m1);
-        ic_next = fetch_index(a, at + 64, a_end, r);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc0[j] = f32x16{0};
-        mfma_tile_bf16(A, b0, acc0, acc1, prev, sk, a, lane, h, vtile);
-        at += 32;
-        if (at >= a_end) {
-          uint32_t m = 0;
-#pragma unroll
-          for (int g = 0; g < 16; ++g) m |= threshold_row(acc0, m0, g, 0.f);
-          emit_tile(sk, a, lane, h, vtile, m0.ok ? m : 0u, m0.ic);
-          break;
-        }
+        for (int j = 0; j < 3; ++j)
+          *reinterpret_cast<uint32_t*>(tile + (3 * j + 2) * 1024 + lane * 16 + 4) = pv_cur[j];
+      } else {
+        s_thr[(cur * kBfGroup + wave) * 32 + r] = ((tile_pos(g, wave) + r) < a_end) ? a.thr * __uint_as_float(pv_cur[0]) : -__builtin_inff();
+        s_ic[(cur * kBfGroup + wave) * 32 + r] = ic_cur;
       }
-      {
-        const TileMeta prev = m0;
-        retire_loads_bf16(b1, m1);
-        asm volatile("" ::"v"(ic_next));
-        load_tile_bf16(a, at + 32, a_end, r, h, ic_next, b0, m0);
-        ic_next = fetch_index(a, at + 64, a_end, r);
+    }
+    STAMP(2);
+    __syncthreads();
+    STAMP(3);
+    // ---- start staging group g+1 into the other buffer (its last readers passed the barrier above)
+    ic_cur = ic_nxt;
+    if (g + 1 < n_groups) {
+      fetch_patch(ic_cur, pv_nxt);               // consumed after the next barrier
+      stage_tile_bf16(a, s_b + (cur ^ 1) * kBfBufBytes + wave * kBfTileBytes, ic_cur, h);
+      ic_nxt = fetch_index(a, tile_pos(g + 2, wave), a_end, r);
+    }
+    STAMP(4);
+    // ---- consume group g.  The fragments of tile w+1 are read from LDS right after the MFMAs of
+    // tile w have been issued, so their latency hides under tile w's epilogue.
+    const unsigned char* gbase = s_b + cur * kBfBufBytes + lane * 16;
+    bf16x8 frag[3][3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc1[j] = f32x16{0};
-        mfma_tile_bf16(A, b1, acc1, acc0, prev, sk, a, lane, h, vtile);
-        at += 32;
-        if (at >= a_end) {
-          uint32_t m = 0;
+    for (int j = 0; j < 3; ++j)
 #pragma unroll
-          for (int g = 0; g < 16; ++g) m |= threshold_row(acc1, m1, g, 0.f);
-          emit_tile(sk, a, lane, h, vtile, m1.ok ? m : 0u, m1.ic);
-          break;
+      for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(&frag[j][s]) = *reinterpret_cast<const uint4*>(gbase + (3 * j + s) * 1024);
+    float thr_n = s_thr[(cur * kBfGroup + 0) * 32 + r];                // -inf: column past the end
+    int32_t ic_n = s_ic[(cur * kBfGroup + 0) * 32 + r];
+#pragma unroll 1
+    for (int w = 0; w < kBfGroup; ++w) {
+      if (tile_pos(g, w) >= a_end) break;
+      STAMP(5);
+      const float thr_c = thr_n;
+      const int32_t ic = ic_n;
+      f32x16 acc[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[t][j] = f32x16{0};
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][j][s], frag[j][s], acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][j][s], frag[j][s], acc[1][j], 0, 0, 0);
         }
+      STAMP(6);
+      if (w + 1 < kBfGroup) {
+        const unsigned char* nt = gbase + (w + 1) * kBfTileBytes;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(&frag[j][s]) = *reinterpret_cast<const uint4*>(nt + (3 * j + s) * 1024);
+        thr_n = s_thr[(cur * kBfGroup + w + 1) * 32 + r];
+        ic_n = s_ic[(cur * kBfGroup + w + 1) * 32 + r];
       }
+      STAMP(7);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        // rows 15..0: packed products for two rows at a time, then mask = 2*mask + (prod <= thr)
+        // as one compare + one add-with-carry per row (row q ends at bit q)
+        uint32_t mask = 0;
+#pragma unroll
+        for (int q = 14; q >= 0; q -= 2) {
+          const f32x2 x0 = {acc[t][0][q], acc[t][0][q + 1]};
+          const f32x2 x1 = {acc[t][1][q], acc[t][1][q + 1]};
+          const f32x2 x2 = {acc[t][2][q], acc[t][2][q + 1]};
+          const f32x2 pr = x0 * x1 * x2;
+          asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[1]), "v"(thr_c) : "vcc");
+          asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[0]), "v"(thr_c) : "vcc");
+        }
+        emit_tile(sk, a, lane, h, (vt0 >> 5) + t, mask, ic);
+      }
+      STAMP(8);
     }
   }
   sink_flush(sk, a, lane);
+#ifdef DA_DBG_STAMPS
+  if (lane == 0) for (int k = 0; k < 10; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
+#endif
+}
+
+void debug_read_stamps(unsigned long long out[16]) {
+  for (int k = 0; k < 16; ++k) out[k] = 0;
+#ifdef DA_DBG_STAMPS
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+  unsigned long long z[16] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
+#endif
 }
 
 static dim3 match_grid(const MatchArgs& a) {
@@ -519,7 +589,16 @@ void launch_match_f32(const MatchArgs& a, hipStream_t s) {
 }
 void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   if (a.n_v <= 0 || a.n_a <= 0) return;
-  hipLaunchKernelGGL(k_match_bf16, match_grid(a), dim3(64 * kWavesPerBlock), 0, s, a);
+  const int smem = 2 * kBfBufBytes + 4 * kBfSurv * 8 + 2 * kBfGroup * 32 * (4 + 4);
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    once = true;
+  }
+  const int64_t bx = (a.n_v + 255) / 256;                       // 4 waves x 64 video rows per block
+  const int64_t atiles = (a.n_a + 31) / 32;
+  const int64_t by = (atiles + a.audio_tiles_per_block - 1) / a.audio_tiles_per_block;
+  hipLaunchKernelGGL(k_match_bf16, dim3((unsigned)bx, (unsigned)by), dim3(256), smem, s, a);
 }
 
 // diagnostics: the correlations exactly as the GEMM precision forms them, for explicit pairs.
