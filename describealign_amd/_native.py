@@ -173,7 +173,7 @@ class Context:
       rows[k, :len(f)] = f
     return rows, (C.c_int64 * 2)(le, lo)
 
-  def match(self, video_features, audio_features, mode: int = MATCH_HASHED, rows=None, capacity=None):
+  def match(self, video_features, audio_features, mode: int = MATCH_HASHED, rows=None, capacity=None, alloc=None):
     """Verified matches (i, v, qual) sorted by (i, v) -- describealign.py:595-673."""
     vrows, vlen = self._pack_rows(video_features)
     arows, alen = self._pack_rows(audio_features)
@@ -185,7 +185,10 @@ class Context:
     if rc != ERR_CAPACITY:
       self._check(rc)
     k = n.value
-    oi = np.empty(k, dtype=np.int32); ov = np.empty(k, dtype=np.int32); oq = np.empty(k, dtype=np.float64)
+    if alloc is None:
+      oi = np.empty(k, dtype=np.int32); ov = np.empty(k, dtype=np.int32); oq = np.empty(k, dtype=np.float64)
+    else:
+      oi, ov, oq = alloc(k)          # caller-provided buffers (e.g. shared memory for a worker process)
     if k:
       self._check(self._lib.da_match_fetch(self._h, _ptr(oi), _ptr(ov), _ptr(oq), k))
     return oi, ov, oq

@@ -271,10 +271,10 @@ def default_context(device: int = 0, precision: int = _native.PREC_F32) -> "_nat
   return _default_ctx
 
 
-def _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm):
+def _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm, alloc=None):
   """Stages 1+2 on the GPU: prep, similarity GEMM, exact verification, sort."""
   t0 = time.perf_counter()
-  mi, mv, mq = ctx.match(video_features, audio_desc_features, mode=mode)
+  mi, mv, mq = ctx.match(video_features, audio_desc_features, mode=mode, alloc=alloc)
   tm["device"] = ctx.stats()
   tm["match_s"] = time.perf_counter() - t0
   tm["n_matches"] = len(mi)
@@ -377,90 +377,169 @@ def _lp_worker(args):
   return lp, time.perf_counter() - t0
 
 
+# ---- worker-process side of the batch pipeline ---------------------------------------------------
+_proc_ctx = None
+
+
+def _proc_init(device, precision):
+  global _proc_ctx
+  _proc_ctx = _native.Context(device, precision)
+
+
+def _block_layout(n, le_v, lo_v, le_a, lo_a, cap_rows):
+  """Byte offsets of one pair's shared block: match lists, feature rows, path output."""
+  off, lay = 0, {}
+  for name, count, size in (("mq", n, 8), ("path", cap_rows * 5, 8), ("mi", n, 4), ("mv", n, 4),
+                            ("vf0", le_v, 4), ("vf", 4 * lo_v, 4), ("af0", le_a, 4), ("af", 4 * lo_a, 4)):
+    lay[name] = (off, count)
+    off += ((count * size + 63) // 64) * 64
+  return lay, max(off, 64)
+
+
+def _block_views(buf, lay, le_v, lo_v, le_a, lo_a):
+  def arr(name, dtype, shape=None):
+    o, c = lay[name]
+    a = np.frombuffer(buf, dtype=dtype, count=c, offset=o)
+    return a if shape is None else a.reshape(shape)
+  vf = [arr("vf0", np.float32)] + list(arr("vf", np.float32, (4, lo_v)))
+  af = [arr("af0", np.float32)] + list(arr("af", np.float32, (4, lo_a)))
+  return arr("mi", np.int32), arr("mv", np.int32), arr("mq", np.float64), vf, af, arr("path", np.float64)
+
+
+def _proc_rest(fname, n, le_v, lo_v, le_a, lo_a, cap_rows):
+  """Everything after the GPU matching for one pair, in a worker process (own GIL, own da_ctx)."""
+  lay, size = _block_layout(n, le_v, lo_v, le_a, lo_a, cap_rows)
+  mm = np.memmap(fname, dtype=np.uint8, mode="r+", shape=(size,))
+  mi, mv, mq, vf, af, path_out = _block_views(mm, lay, le_v, lo_v, le_a, lo_a)
+  tm = {}
+  ctx = _proc_ctx
+  fx, fy, a_s, v_s = _stage_chain_pass1(ctx, (mi, mv, mq), vf, af, le_v, le_a, tm)
+  t0 = time.perf_counter()
+  lp = solve_trend_lp(fx, fy)
+  tm["lp_s"] = time.perf_counter() - t0
+  nx, ny, sim, path, med = _stage_refine(ctx, lp, a_s, v_s, le_v, le_a, tm)
+  rows = len(path)
+  if rows > cap_rows:
+    raise RuntimeError("pipeline path buffer too small")
+  path_out[:rows * 5] = path.ravel()
+  mm.flush()
+  del mm
+  return nx, ny, sim, float(med), rows, tm
+
+
 class AlignPipeline:
   """Directory-batch throughput.  One pair's latency is dominated by host work (the
   single-threaded HiGHS LP, the two sequential DPs), so pairs are pipelined:
 
-    calling thread   GPU matching of pair k+1 (prep, similarity GEMM, verification, sort)
-    worker threads   per pair: chain DP (C++, GIL released) -> pass-1 host -> wait for the LP ->
-                     clustering -> banded extension + second DP -> nodes; one da_ctx per thread
-    LP processes     scipy.optimize.linprog (HiGHS), one pair each
+    GPU threads       (one da_ctx / HIP stream each) features + matching of successive pairs:
+                      prep, similarity GEMM, verification, sort; the verified match lists are
+                      copied from the device straight into a /dev/shm block
+    worker processes  (own GIL, own da_ctx) per pair: chain DP -> pass-1 host -> LP (HiGHS) ->
+                      clustering -> banded extension + second DP -> nodes; they map the pair's
+                      /dev/shm block, so nothing big is pickled
 
-  Results come back in submission order and are identical to align()'s.
+  A job is either a tuple (video_features, audio_features) or a callable job(ctx) returning that
+  tuple (e.g. running the feature kernel on that context's resident PCM).  Results come back in
+  submission order and are identical to align()'s.
 
-      with AlignPipeline(ctx, lp_workers=4) as pipe:
-        for result in pipe.run(jobs):      # jobs: iterable of (video_features, audio_features)
+      with AlignPipeline([ctx0, ctx1], lp_workers=16) as pipe:
+        for result in pipe.run(jobs):
           ...
   """
 
   def __init__(self, ctx=None, lp_workers=4, mode=_native.MATCH_HASHED):
     import concurrent.futures as cf
     import multiprocessing as mp
-    import threading
-    self.ctx = ctx or default_context()
+    import os
+    import tempfile
+    if ctx is None:
+      ctx = default_context()
+    self.gpu_ctxs = list(ctx) if isinstance(ctx, (list, tuple)) else [ctx]
+    self.ctx = self.gpu_ctxs[0]
     self.mode = mode
     self.depth = max(1, int(lp_workers))
-    self.pool = cf.ProcessPoolExecutor(max_workers=self.depth, mp_context=mp.get_context("spawn"))
-    self.threads = cf.ThreadPoolExecutor(max_workers=self.depth)
-    self._local = threading.local()
-    self._ctxs = []
-    self._lock = threading.Lock()
-    # the calling thread re-acquires the GIL after every ctypes call; with the default 5 ms switch
-    # interval those hand-offs (behind worker threads doing numpy) cost more than the GPU work
+    self.pool = cf.ProcessPoolExecutor(max_workers=self.depth, mp_context=mp.get_context("spawn"),
+                                       initializer=_proc_init, initargs=(self.ctx.device, self.ctx.precision))
+    self.gpu_threads = [cf.ThreadPoolExecutor(max_workers=1) for _ in self.gpu_ctxs]
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    self._dir = tempfile.mkdtemp(prefix=f"dalign_{os.getpid()}_", dir=shm)
+    self._seq = 0
     import sys
     self._old_switch = sys.getswitchinterval()
     sys.setswitchinterval(2e-4)
 
-  def _thread_ctx(self):
-    c = getattr(self._local, "ctx", None)
-    if c is None:
-      c = _native.Context(self.ctx.device, self.ctx.precision)
-      self._local.ctx = c
-      with self._lock:
-        self._ctxs.append(c)
-    return c
-
   def warm(self):
-    """Start the worker processes (imports scipy) and threads before anything is timed."""
-    x = np.arange(40, dtype=np.float64)
-    list(self.pool.map(_lp_worker, [(x, x + 0.25 * np.sin(x))] * self.depth))
-    list(self.threads.map(lambda _: self._thread_ctx(), range(self.depth)))
+    """Start the worker processes (imports, da_ctx creation) before anything is timed."""
+    list(self.pool.map(_lp_worker, [(np.arange(40.0), np.arange(40.0) + 0.25 * np.sin(np.arange(40.0)))] * self.depth))
 
   def __enter__(self):
     return self
 
   def __exit__(self, *exc):
-    self.threads.shutdown(wait=True, cancel_futures=True)
-    self.pool.shutdown(wait=True, cancel_futures=True)
-    for c in self._ctxs:
-      c.close()
-    self._ctxs = []
+    import shutil
     import sys
+    for g in self.gpu_threads:
+      g.shutdown(wait=True, cancel_futures=True)
+    self.pool.shutdown(wait=True, cancel_futures=True)
+    shutil.rmtree(self._dir, ignore_errors=True)
     sys.setswitchinterval(self._old_switch)
 
-  def _rest(self, matches, vf, af, tm):
-    ctx = self._thread_ctx()
-    n_ve, n_ae = len(vf[0]), len(af[0])
-    fx, fy, a_s, v_s = _stage_chain_pass1(ctx, matches, vf, af, n_ve, n_ae, tm)
-    lp, lp_s = self.pool.submit(_lp_worker, (fx, fy)).result()
-    tm["lp_s"] = lp_s
-    return _stage_refine(ctx, lp, a_s, v_s, n_ve, n_ae, tm)
+  def _gpu_stage(self, ctx, job, tm, fname):
+    t0 = time.perf_counter()
+    vf, af = job(ctx) if callable(job) else job
+    tm["features_s"] = time.perf_counter() - t0
+    le_v, lo_v, le_a, lo_a = len(vf[0]), len(vf[1]), len(af[0]), len(af[1])
+    cap_rows = le_v + le_a + 16
+    state = {}
+
+    def alloc(n):
+      lay, size = _block_layout(n, le_v, lo_v, le_a, lo_a, cap_rows)
+      mm = np.memmap(fname, dtype=np.uint8, mode="w+", shape=(size,))
+      mi, mv, mq, bvf, baf, _ = _block_views(mm, lay, le_v, lo_v, le_a, lo_a)
+      for dst, src in zip(bvf, vf):
+        dst[:] = src
+      for dst, src in zip(baf, af):
+        dst[:] = src
+      state.update(mm=mm, lay=lay, size=size, n=n)
+      return mi, mv, mq
+
+    _stage_gpu_match(ctx, vf, af, self.mode, tm, alloc=alloc)
+    n = state["n"]
+    state["mm"].flush()
+    fut = self.pool.submit(_proc_rest, fname, n, le_v, lo_v, le_a, lo_a, cap_rows)
+    return fut, state, (le_v, lo_v, le_a, lo_a, cap_rows)
 
   def run(self, jobs, timings=None):
-    pending = []          # (future, tm) in submission order
+    import os
+    pending = []          # (future of gpu stage, tm, fname) in submission order
+    n_gpu = len(self.gpu_ctxs)
 
     def finish(entry):
-      fut, tm = entry
-      out = fut.result()
+      gfut, tm, fname = entry
+      fut, state, dims = gfut.result()
+      nx, ny, sim, med, rows, wtm = fut.result()
+      dev = tm.get("device", {})
+      dev.update(wtm.pop("device", {}))
+      tm.update(wtm); tm["device"] = dev
+      _, _, _, _, _, path_out = _block_views(state["mm"], state["lay"], *dims[:4])
+      path = np.array(path_out[:rows * 5]).reshape(rows, 5)
+      del path_out
+      state.clear()
+      try:
+        os.unlink(fname)
+      except OSError:
+        pass
       if timings is not None:
         timings.append(tm)
-      return out
+      return nx, ny, sim, path, med
 
-    for vf, af in jobs:
+    for k, job in enumerate(jobs):
       tm = {}
-      matches = _stage_gpu_match(self.ctx, vf, af, self.mode, tm)
-      pending.append((self.threads.submit(self._rest, matches, vf, af, tm), tm))
-      while pending and (len(pending) > self.depth or pending[0][0].done()):
+      g = k % n_gpu
+      fname = os.path.join(self._dir, f"pair{self._seq}.bin")
+      self._seq += 1
+      pending.append((self.gpu_threads[g].submit(self._gpu_stage, self.gpu_ctxs[g], job, tm, fname), tm, fname))
+      while len(pending) > self.depth + n_gpu:
         yield finish(pending.pop(0))
     while pending:
       yield finish(pending.pop(0))
