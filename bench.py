@@ -55,14 +55,14 @@ def cpu_baseline(sample_seconds=600.0):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=32)
-  ap.add_argument("--warmup", type=int, default=4)
+  ap.add_argument("--steps", type=int, default=64)
+  ap.add_argument("--warmup", type=int, default=8)
   ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS))
   ap.add_argument("--precision", default=None, choices=["f32", "bf16"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--gpu-streams", type=int, default=2,
+  ap.add_argument("--gpu-streams", type=int, default=1,
                   help="contexts (HIP streams + host threads) feeding the GPU matching stage; pipelined mode only")
-  ap.add_argument("--pipeline", type=int, default=16,
+  ap.add_argument("--pipeline", type=int, default=32,
                   help="host LP worker processes; pair k+1's GPU/DP stages overlap pair k's LP (0 = strictly sequential)")
   args = ap.parse_args()
 

@@ -88,6 +88,22 @@ def _ptr(a: np.ndarray):
   return a.ctypes.data_as(C.c_void_p)
 
 
+def chain_host(i, v, q, min_len: float = 0.0):
+  """da_chain without a device context (host-only DP) -- usable from CPU worker processes."""
+  lib = load()
+  i = np.ascontiguousarray(i, dtype=np.int32); v = np.ascontiguousarray(v, dtype=np.int32)
+  q = np.ascontiguousarray(q, dtype=np.float64)
+  n = len(i)
+  pi = np.empty(max(n, 1), dtype=np.int32); pv = np.empty(max(n, 1), dtype=np.int32)
+  m = C.c_int64(n)
+  rc = lib.da_chain(None, _ptr(i), _ptr(v), _ptr(q), n, float(min_len), _ptr(pi), _ptr(pv), C.byref(m))
+  if rc == ERR_MISMATCH:
+    raise RuntimeError("Alignment failed, are the input files mismatched?")
+  if rc != 0:
+    raise RuntimeError(f"da_chain failed with code {rc}")
+  return pi[:m.value].copy(), pv[:m.value].copy()
+
+
 class Context:
   """One da_ctx: one GPU, one HIP stream.  Not thread-safe; use one per thread."""
 

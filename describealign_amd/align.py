@@ -285,8 +285,12 @@ def _stage_chain_pass1(ctx, matches, video_features, audio_desc_features, n_ve, 
   """Chain DP (host C++) + pass-1 host work: continuity filter, scaling, compression."""
   mi, mv, mq = matches
   t1 = time.perf_counter()
-  px, py = ctx.chain(mi, mv, mq, min_len=min_path_length(n_ve, n_ae))      # raises the mismatch error
-  tm.setdefault("device", {})["chain_ms"] = ctx.stats()["chain_ms"]
+  if ctx is None:                                # CPU worker process: host-only DP, no device
+    px, py = _native.chain_host(mi, mv, mq, min_len=min_path_length(n_ve, n_ae))
+    tm.setdefault("device", {})["chain_ms"] = 1e3 * (time.perf_counter() - t1)
+  else:
+    px, py = ctx.chain(mi, mv, mq, min_len=min_path_length(n_ve, n_ae))    # raises the mismatch error
+    tm.setdefault("device", {})["chain_ms"] = ctx.stats()["chain_ms"]
   t2 = time.perf_counter()
   x = px.astype(np.int64); y = py.astype(np.int64)
   keep = continuity_error(x, y) < 3
@@ -303,10 +307,10 @@ def _stage_match(ctx, video_features, audio_desc_features, n_ve, n_ae, mode, tm)
   return _stage_chain_pass1(ctx, matches, video_features, audio_desc_features, n_ve, n_ae, tm)
 
 
-def _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm):
+def _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm, clusters=None):
   """Stage 4: clustering, banded extension + second DP (GPU + host), nodes."""
   t0 = time.perf_counter()
-  x0, x1, off, slo = cluster_lines(lp["smooth_x"], lp["smooth_y"], lp["slopes"])
+  x0, x1, off, slo = clusters if clusters is not None else cluster_lines(lp["smooth_x"], lp["smooth_y"], lp["slopes"])
   t1 = time.perf_counter()
   path, n_points = ctx.refine(a_scaled, v_scaled, x0, x1, off, slo, min_len=min_path_length(n_ve, n_ae))
   st = ctx.stats()
@@ -378,18 +382,15 @@ def _lp_worker(args):
 
 
 # ---- worker-process side of the batch pipeline ---------------------------------------------------
-_proc_ctx = None
+# Worker processes never touch the GPU (a second process with a device context makes the GPU
+# time-slice between processes, which costs far more than it gains): they run the host-only
+# stages -- chain DP (C++), pass-1 numpy, the HiGHS LP, clustering -- each under its own GIL.
 
-
-def _proc_init(device, precision):
-  global _proc_ctx
-  _proc_ctx = _native.Context(device, precision)
-
-
-def _block_layout(n, le_v, lo_v, le_a, lo_a, cap_rows):
-  """Byte offsets of one pair's shared block: match lists, feature rows, path output."""
+def _block_layout(n, le_v, lo_v, le_a, lo_a):
+  """Byte offsets of one pair's shared block: match lists, feature rows, scaled stacks."""
   off, lay = 0, {}
-  for name, count, size in (("mq", n, 8), ("path", cap_rows * 5, 8), ("mi", n, 4), ("mv", n, 4),
+  la, lv = min(le_a, lo_a), min(le_v, lo_v)
+  for name, count, size in (("mq", n, 8), ("a_scaled", 3 * la, 8), ("v_scaled", 3 * lv, 8), ("mi", n, 4), ("mv", n, 4),
                             ("vf0", le_v, 4), ("vf", 4 * lo_v, 4), ("af0", le_a, 4), ("af", 4 * lo_a, 4)):
     lay[name] = (off, count)
     off += ((count * size + 63) // 64) * 64
@@ -403,28 +404,28 @@ def _block_views(buf, lay, le_v, lo_v, le_a, lo_a):
     return a if shape is None else a.reshape(shape)
   vf = [arr("vf0", np.float32)] + list(arr("vf", np.float32, (4, lo_v)))
   af = [arr("af0", np.float32)] + list(arr("af", np.float32, (4, lo_a)))
-  return arr("mi", np.int32), arr("mv", np.int32), arr("mq", np.float64), vf, af, arr("path", np.float64)
+  return (arr("mi", np.int32), arr("mv", np.int32), arr("mq", np.float64), vf, af,
+          arr("a_scaled", np.float64, (-1, 3)), arr("v_scaled", np.float64, (-1, 3)))
 
 
-def _proc_rest(fname, n, le_v, lo_v, le_a, lo_a, cap_rows):
-  """Everything after the GPU matching for one pair, in a worker process (own GIL, own da_ctx)."""
-  lay, size = _block_layout(n, le_v, lo_v, le_a, lo_a, cap_rows)
+def _proc_mid(fname, n, le_v, lo_v, le_a, lo_a):
+  """Host-only middle of the pipeline for one pair: chain DP, pass 1, LP, clustering."""
+  lay, size = _block_layout(n, le_v, lo_v, le_a, lo_a)
   mm = np.memmap(fname, dtype=np.uint8, mode="r+", shape=(size,))
-  mi, mv, mq, vf, af, path_out = _block_views(mm, lay, le_v, lo_v, le_a, lo_a)
+  mi, mv, mq, vf, af, a_out, v_out = _block_views(mm, lay, le_v, lo_v, le_a, lo_a)
   tm = {}
-  ctx = _proc_ctx
-  fx, fy, a_s, v_s = _stage_chain_pass1(ctx, (mi, mv, mq), vf, af, le_v, le_a, tm)
+  fx, fy, a_s, v_s = _stage_chain_pass1(None, (mi, mv, mq), vf, af, le_v, le_a, tm)
   t0 = time.perf_counter()
   lp = solve_trend_lp(fx, fy)
   tm["lp_s"] = time.perf_counter() - t0
-  nx, ny, sim, path, med = _stage_refine(ctx, lp, a_s, v_s, le_v, le_a, tm)
-  rows = len(path)
-  if rows > cap_rows:
-    raise RuntimeError("pipeline path buffer too small")
-  path_out[:rows * 5] = path.ravel()
+  t1 = time.perf_counter()
+  clusters = cluster_lines(lp["smooth_x"], lp["smooth_y"], lp["slopes"])
+  tm["cluster_s"] = time.perf_counter() - t1
+  a_out[:] = a_s
+  v_out[:] = v_s
   mm.flush()
   del mm
-  return nx, ny, sim, float(med), rows, tm
+  return clusters, float(lp["median_slope"]), tm
 
 
 class AlignPipeline:
@@ -434,9 +435,9 @@ class AlignPipeline:
     GPU threads       (one da_ctx / HIP stream each) features + matching of successive pairs:
                       prep, similarity GEMM, verification, sort; the verified match lists are
                       copied from the device straight into a /dev/shm block
-    worker processes  (own GIL, own da_ctx) per pair: chain DP -> pass-1 host -> LP (HiGHS) ->
-                      clustering -> banded extension + second DP -> nodes; they map the pair's
-                      /dev/shm block, so nothing big is pickled
+    worker processes  (own GIL, no device) per pair: chain DP -> pass-1 host -> LP (HiGHS) ->
+                      clustering; they map the pair's /dev/shm block, nothing big is pickled
+    refine threads    (one da_ctx each, this process) banded extension kernels + second DP + nodes
 
   A job is either a tuple (video_features, audio_features) or a callable job(ctx) returning that
   tuple (e.g. running the feature kernel on that context's resident PCM).  Results come back in
@@ -447,20 +448,35 @@ class AlignPipeline:
           ...
   """
 
-  def __init__(self, ctx=None, lp_workers=4, mode=_native.MATCH_HASHED):
+  def __init__(self, ctx=None, lp_workers=4, mode=_native.MATCH_HASHED, refine_threads=4):
     import concurrent.futures as cf
     import multiprocessing as mp
     import os
     import tempfile
+    import threading
     if ctx is None:
       ctx = default_context()
     self.gpu_ctxs = list(ctx) if isinstance(ctx, (list, tuple)) else [ctx]
     self.ctx = self.gpu_ctxs[0]
     self.mode = mode
     self.depth = max(1, int(lp_workers))
-    self.pool = cf.ProcessPoolExecutor(max_workers=self.depth, mp_context=mp.get_context("spawn"),
-                                       initializer=_proc_init, initargs=(self.ctx.device, self.ctx.precision))
+    # worker processes inherit the environment: one BLAS/OpenMP thread each, or dozens of workers
+    # oversubscribe the host with their numpy thread pools and every LP slows down
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved:
+      os.environ[k] = "1"
+    self.pool = cf.ProcessPoolExecutor(max_workers=self.depth, mp_context=mp.get_context("spawn"))
+    list(self.pool.map(int, range(self.depth)))          # spawn them now, under that environment
+    for k, v in saved.items():
+      if v is None:
+        os.environ.pop(k, None)
+      else:
+        os.environ[k] = v
     self.gpu_threads = [cf.ThreadPoolExecutor(max_workers=1) for _ in self.gpu_ctxs]
+    self.refine_pool = cf.ThreadPoolExecutor(max_workers=max(1, int(refine_threads)))
+    self._local = threading.local()
+    self._ctxs = []
+    self._lock = threading.Lock()
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     self._dir = tempfile.mkdtemp(prefix=f"dalign_{os.getpid()}_", dir=shm)
     self._seq = 0
@@ -468,9 +484,20 @@ class AlignPipeline:
     self._old_switch = sys.getswitchinterval()
     sys.setswitchinterval(2e-4)
 
+  def _thread_ctx(self):
+    c = getattr(self._local, "ctx", None)
+    if c is None:
+      c = _native.Context(self.ctx.device, self.ctx.precision)
+      self._local.ctx = c
+      with self._lock:
+        self._ctxs.append(c)
+    return c
+
   def warm(self):
-    """Start the worker processes (imports, da_ctx creation) before anything is timed."""
-    list(self.pool.map(_lp_worker, [(np.arange(40.0), np.arange(40.0) + 0.25 * np.sin(np.arange(40.0)))] * self.depth))
+    """Start the worker processes (imports) and refine threads before anything is timed."""
+    x = np.arange(40.0)
+    list(self.pool.map(_lp_worker, [(x, x + 0.25 * np.sin(x))] * self.depth))
+    list(self.refine_pool.map(lambda _: self._thread_ctx(), range(self.refine_pool._max_workers)))
 
   def __enter__(self):
     return self
@@ -481,6 +508,10 @@ class AlignPipeline:
     for g in self.gpu_threads:
       g.shutdown(wait=True, cancel_futures=True)
     self.pool.shutdown(wait=True, cancel_futures=True)
+    self.refine_pool.shutdown(wait=True, cancel_futures=True)
+    for c in self._ctxs:
+      c.close()
+    self._ctxs = []
     shutil.rmtree(self._dir, ignore_errors=True)
     sys.setswitchinterval(self._old_switch)
 
@@ -488,26 +519,47 @@ class AlignPipeline:
     t0 = time.perf_counter()
     vf, af = job(ctx) if callable(job) else job
     tm["features_s"] = time.perf_counter() - t0
-    le_v, lo_v, le_a, lo_a = len(vf[0]), len(vf[1]), len(af[0]), len(af[1])
-    cap_rows = le_v + le_a + 16
+    dims = (len(vf[0]), len(vf[1]), len(af[0]), len(af[1]))
     state = {}
 
     def alloc(n):
-      lay, size = _block_layout(n, le_v, lo_v, le_a, lo_a, cap_rows)
+      lay, size = _block_layout(n, *dims)
       mm = np.memmap(fname, dtype=np.uint8, mode="w+", shape=(size,))
-      mi, mv, mq, bvf, baf, _ = _block_views(mm, lay, le_v, lo_v, le_a, lo_a)
+      mi, mv, mq, bvf, baf, _, _ = _block_views(mm, lay, *dims)
       for dst, src in zip(bvf, vf):
         dst[:] = src
       for dst, src in zip(baf, af):
         dst[:] = src
-      state.update(mm=mm, lay=lay, size=size, n=n)
+      state.update(mm=mm, lay=lay, n=n)
       return mi, mv, mq
 
     _stage_gpu_match(ctx, vf, af, self.mode, tm, alloc=alloc)
-    n = state["n"]
     state["mm"].flush()
-    fut = self.pool.submit(_proc_rest, fname, n, le_v, lo_v, le_a, lo_a, cap_rows)
-    return fut, state, (le_v, lo_v, le_a, lo_a, cap_rows)
+    mid = self.pool.submit(_proc_mid, fname, state["n"], *dims)
+    # the refine stage is queued when the worker process finishes (no thread blocks on it)
+    import concurrent.futures as cf
+    done = cf.Future()
+
+    def on_mid(f):
+      def work():
+        try:
+          done.set_result(self._refine_stage(f.result(), state, dims, tm))
+        except BaseException as e:          # surfaces in finish()
+          done.set_exception(e)
+      self.refine_pool.submit(work)
+
+    mid.add_done_callback(on_mid)
+    return done
+
+  def _refine_stage(self, mid_result, state, dims, tm):
+    clusters, med, wtm = mid_result
+    dev = tm.get("device", {})
+    dev.update(wtm.pop("device", {}))
+    tm.update(wtm); tm["device"] = dev
+    ctx = self._thread_ctx()
+    _, _, _, _, _, a_s, v_s = _block_views(state["mm"], state["lay"], *dims)
+    out = _stage_refine(ctx, dict(median_slope=med), a_s, v_s, dims[0], dims[2], tm, clusters=clusters)
+    return out
 
   def run(self, jobs, timings=None):
     import os
@@ -516,22 +568,14 @@ class AlignPipeline:
 
     def finish(entry):
       gfut, tm, fname = entry
-      fut, state, dims = gfut.result()
-      nx, ny, sim, med, rows, wtm = fut.result()
-      dev = tm.get("device", {})
-      dev.update(wtm.pop("device", {}))
-      tm.update(wtm); tm["device"] = dev
-      _, _, _, _, _, path_out = _block_views(state["mm"], state["lay"], *dims[:4])
-      path = np.array(path_out[:rows * 5]).reshape(rows, 5)
-      del path_out
-      state.clear()
+      out = gfut.result().result()
       try:
         os.unlink(fname)
       except OSError:
         pass
       if timings is not None:
         timings.append(tm)
-      return nx, ny, sim, path, med
+      return out
 
     for k, job in enumerate(jobs):
       tm = {}

@@ -483,7 +483,7 @@ extern "C" int da_match_corr(da_ctx* c, const int32_t* pi, const int32_t* pv, in
 // entries to its right whose weight is not larger, :679-680).
 extern "C" int da_chain(da_ctx* c, const int32_t* pi, const int32_t* pv, const double* pq, int64_t n, double min_len,
                         int32_t* path_i, int32_t* path_v, int64_t* n_path) {
-  if (!c) return DA_ERR_ARG;
+  // c may be NULL: the chain DP is host-only, so CPU worker processes can call it without a device
   if (n < 0 || !n_path || (n > 0 && (!pi || !pv || !pq))) return fail(c, DA_ERR_ARG, "da_chain: bad argument");
   const double t0 = now_ms();
   int32_t vmax = -1;
@@ -519,7 +519,7 @@ extern "C" int da_chain(da_ctx* c, const int32_t* pi, const int32_t* pv, const d
   std::vector<int32_t> chain;
   for (int32_t p = best_all.id; p >= 0; p = pred[p]) chain.push_back(p);
   std::reverse(chain.begin(), chain.end());
-  c->st.chain_ms = now_ms() - t0;
+  if (c) c->st.chain_ms = now_ms() - t0;
   const int64_t capacity = *n_path;
   *n_path = (int64_t)chain.size();
   if ((double)chain.size() < min_len) return fail(c, DA_ERR_MISMATCH, "Alignment failed, are the input files mismatched?");

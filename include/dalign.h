@@ -86,7 +86,8 @@ int da_match_corr(da_ctx* ctx, const int32_t* i, const int32_t* v, int64_t n, fl
 /* ---- stage 2 DP: heaviest chain -------------------------------------------------------------
  * describealign.py:654-656, :674-698: heaviest chain non-decreasing in both coordinates over
  * matches sorted by (i, v).  *n_path in: capacity, out: length.  min_len = the reference's
- * failure bound max(min(Lv,La)/500, 1050) (:698); shorter -> DA_ERR_MISMATCH. */
+ * failure bound max(min(Lv,La)/500, 1050) (:698); shorter -> DA_ERR_MISMATCH.
+ * Host-only: ctx may be NULL (no device needed; then only the return code reports errors). */
 int da_chain(da_ctx* ctx, const int32_t* i, const int32_t* v, const double* q, int64_t n,
              double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path);
 
