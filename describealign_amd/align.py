@@ -408,10 +408,10 @@ def _block_views(buf, lay, le_v, lo_v, le_a, lo_a):
           arr("a_scaled", np.float64, (-1, 3)), arr("v_scaled", np.float64, (-1, 3)))
 
 
-def _proc_mid(fname, n, le_v, lo_v, le_a, lo_a):
+def _proc_mid(fname, fsize, n, le_v, lo_v, le_a, lo_a):
   """Host-only middle of the pipeline for one pair: chain DP, pass 1, LP, clustering."""
   lay, size = _block_layout(n, le_v, lo_v, le_a, lo_a)
-  mm = np.memmap(fname, dtype=np.uint8, mode="r+", shape=(size,))
+  mm = np.memmap(fname, dtype=np.uint8, mode="r+", shape=(fsize,))
   mi, mv, mq, vf, af, a_out, v_out = _block_views(mm, lay, le_v, lo_v, le_a, lo_a)
   tm = {}
   fx, fy, a_s, v_s = _stage_chain_pass1(None, (mi, mv, mq), vf, af, le_v, le_a, tm)
@@ -480,6 +480,7 @@ class AlignPipeline:
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     self._dir = tempfile.mkdtemp(prefix=f"dalign_{os.getpid()}_", dir=shm)
     self._seq = 0
+    self._free = []        # reusable (file name, bytes) blocks: fresh tmpfs pages cost ~0.2 ms per MB
     import sys
     self._old_switch = sys.getswitchinterval()
     sys.setswitchinterval(2e-4)
@@ -524,7 +525,18 @@ class AlignPipeline:
 
     def alloc(n):
       lay, size = _block_layout(n, *dims)
-      mm = np.memmap(fname, dtype=np.uint8, mode="w+", shape=(size,))
+      with self._lock:
+        pick = next((b for b in self._free if b[1] >= size), None)
+        if pick is not None:
+          self._free.remove(pick)
+      if pick is not None:
+        state["fname"], fsize = pick
+        mm = np.memmap(state["fname"], dtype=np.uint8, mode="r+", shape=(fsize,))
+      else:
+        fsize = size + size // 4          # slack so the next pair of similar size fits too
+        state["fname"] = fname
+        mm = np.memmap(fname, dtype=np.uint8, mode="w+", shape=(fsize,))
+      state["fsize"] = fsize
       mi, mv, mq, bvf, baf, _, _ = _block_views(mm, lay, *dims)
       for dst, src in zip(bvf, vf):
         dst[:] = src
@@ -535,7 +547,7 @@ class AlignPipeline:
 
     _stage_gpu_match(ctx, vf, af, self.mode, tm, alloc=alloc)
     state["mm"].flush()
-    mid = self.pool.submit(_proc_mid, fname, state["n"], *dims)
+    mid = self.pool.submit(_proc_mid, state["fname"], state["fsize"], state["n"], *dims)
     # the refine stage is queued when the worker process finishes (no thread blocks on it)
     import concurrent.futures as cf
     done = cf.Future()
@@ -559,6 +571,11 @@ class AlignPipeline:
     ctx = self._thread_ctx()
     _, _, _, _, _, a_s, v_s = _block_views(state["mm"], state["lay"], *dims)
     out = _stage_refine(ctx, dict(median_slope=med), a_s, v_s, dims[0], dims[2], tm, clusters=clusters)
+    del a_s, v_s
+    mm = state.pop("mm")
+    del mm
+    with self._lock:
+      self._free.append((state["fname"], state["fsize"]))
     return out
 
   def run(self, jobs, timings=None):
@@ -569,10 +586,6 @@ class AlignPipeline:
     def finish(entry):
       gfut, tm, fname = entry
       out = gfut.result().result()
-      try:
-        os.unlink(fname)
-      except OSError:
-        pass
       if timings is not None:
         timings.append(tm)
       return out

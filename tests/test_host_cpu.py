@@ -33,6 +33,31 @@ def test_library_exports_every_declared_symbol(lib):
   assert lib.da_abi_version() == _native.ABI_VERSION
 
 
+def test_chain_dp_host_only_matches_reference_and_oracle(lib):
+  """da_chain is host C++ and accepts a NULL context, so it is exercised here without a GPU:
+  against the reference's recorded pass-1 path and against the oracle on tie-heavy input."""
+  from describealign_amd import _native
+  from oracle import dalign_oracle as O
+  g = np.load(os.path.join(GOLD, "align_a40.npz"))
+  pi, pv = _native.chain_host(g["m_i"], g["m_v"], g["m_q"])
+  assert np.array_equal(pi, g["p1_x"]) and np.array_equal(pv, g["p1_y"])
+  rng = np.random.default_rng(11)
+  for trial in range(3):
+    n = 30000
+    i = np.sort(rng.integers(0, 4000, n)); v = rng.integers(0, 900, n) * 4
+    keys = np.unique(i.astype(np.int64) * 100000 + v)
+    i, v = (keys // 100000).astype(np.int32), (keys % 100000).astype(np.int32)
+    q = rng.choice([50.0, 50.0, 25.0, 12.5, 0.75], len(i))        # capped qualities: many equal sums
+    idx = O.chain(i, v, q)
+    pi, pv = _native.chain_host(i, v, q)
+    assert np.array_equal(pi, i[idx]) and np.array_equal(pv, v[idx])
+  with pytest.raises(RuntimeError, match="Alignment failed, are the input files mismatched"):
+    _native.chain_host(np.arange(5, dtype=np.int32), np.arange(5, dtype=np.int32), np.ones(5), min_len=1050)
+  # unsorted input is rejected, not mis-processed
+  with pytest.raises(RuntimeError):
+    _native.chain_host(np.array([3, 1], dtype=np.int32), np.array([0, 0], dtype=np.int32), np.ones(2))
+
+
 def test_no_cpu_fallback_context_fails_loudly():
   import torch
   if torch.cuda.is_available():
