@@ -87,39 +87,7 @@ __global__ __launch_bounds__(FeatCfg<C>::kThreads) void k_features(FeatArgs a, c
   const int64_t s0 = 210 * (f0 - Cfg::kHalo) - Cfg::kFront;      // sample index of LDS slot 0
 
   // ---- stage 0: HBM -> LDS, int16 -> float16 (round to nearest even, as numpy astype) -------
-  for (int t = tid; t < Cfg::kTot / 8; t += Cfg::kThreads) {
-    const int64_t n0 = s0 + 8 * (int64_t)t;
-    uint32_t w[C][4];
-    const bool inside = n0 >= 0 && n0 + 8 <= a.n_energy;
-    if (inside && a.stride_n == 1 && ((reinterpret_cast<uintptr_t>(a.pcm + n0) & 3) == 0) && ((a.stride_c & 1) == 0)) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(a.pcm + c * a.stride_c + n0);
-        const uint4 v = *reinterpret_cast<const uint4*>(q);   // dword-aligned 16-byte load
-        w[c][0] = v.x; w[c][1] = v.y; w[c][2] = v.z; w[c][3] = v.w;
-      }
-    } else if (inside && C == 2 && a.stride_n == 2 && a.stride_c == 1) {
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(a.pcm + 2 * n0);   // interleaved stereo frames
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t fa = q[2 * e], fb = q[2 * e + 1];
-        w[0][e] = (fa & 0xffffu) | (fb << 16);
-        w[C - 1][e] = (fa >> 16) | (fb & 0xffff0000u);
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < C; ++c)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          uint32_t lohi[2];
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const int64_t n = n0 + 2 * e + b;
-            lohi[b] = (n >= 0 && n < a.n_energy) ? (uint16_t)a.pcm[c * a.stride_c + n * a.stride_n] : 0u;
-          }
-          w[c][e] = lohi[0] | (lohi[1] << 16);
-        }
-    }
+  auto convert_store = [&](int t, const uint32_t (&w)[C][4]) {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       uint32_t o[4];
@@ -131,6 +99,64 @@ __global__ __launch_bounds__(FeatCfg<C>::kThreads) void k_features(FeatArgs a, c
         o[e] = *reinterpret_cast<uint32_t*>(&p);
       }
       *reinterpret_cast<uint4*>(smem + 2 * (c * Cfg::kTot + 8 * t)) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  };
+  constexpr int kIters = (Cfg::kTot / 8 + Cfg::kThreads - 1) / Cfg::kThreads;
+  const bool interior = s0 >= 0 && s0 + Cfg::kTot <= a.n_energy && a.stride_n == 1 &&
+                        ((reinterpret_cast<uintptr_t>(a.pcm) & 3) == 0) && ((a.stride_c & 1) == 0);
+  if (interior) {
+    // whole chunk inside the PCM (all but the first/last workgroup): issue every 16-byte load of
+    // this thread first, so one HBM round trip is exposed instead of one per iteration
+    uint32_t w[kIters][C][4];
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+      int t = tid + it * Cfg::kThreads;
+      if (t >= Cfg::kTot / 8) t = Cfg::kTot / 8 - 1;             // duplicate load, result unused
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const uint4 v = *reinterpret_cast<const uint4*>(a.pcm + c * a.stride_c + s0 + 8 * (int64_t)t);
+        w[it][c][0] = v.x; w[it][c][1] = v.y; w[it][c][2] = v.z; w[it][c][3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+      const int t = tid + it * Cfg::kThreads;
+      if (t < Cfg::kTot / 8) convert_store(t, w[it]);
+    }
+  } else {
+    for (int t = tid; t < Cfg::kTot / 8; t += Cfg::kThreads) {
+      const int64_t n0 = s0 + 8 * (int64_t)t;
+      uint32_t w[C][4];
+      const bool inside = n0 >= 0 && n0 + 8 <= a.n_energy;
+      if (inside && a.stride_n == 1 && ((reinterpret_cast<uintptr_t>(a.pcm + n0) & 3) == 0) && ((a.stride_c & 1) == 0)) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const uint4 v = *reinterpret_cast<const uint4*>(a.pcm + c * a.stride_c + n0);   // dword-aligned 16-byte load
+          w[c][0] = v.x; w[c][1] = v.y; w[c][2] = v.z; w[c][3] = v.w;
+        }
+      } else if (inside && C == 2 && a.stride_n == 2 && a.stride_c == 1) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(a.pcm + 2 * n0);   // interleaved stereo frames
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t fa = q[2 * e], fb = q[2 * e + 1];
+          w[0][e] = (fa & 0xffffu) | (fb << 16);
+          w[C - 1][e] = (fa >> 16) | (fb & 0xffff0000u);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            uint32_t lohi[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const int64_t n = n0 + 2 * e + b;
+              lohi[b] = (n >= 0 && n < a.n_energy) ? (uint16_t)a.pcm[c * a.stride_c + n * a.stride_n] : 0u;
+            }
+            w[c][e] = lohi[0] | (lohi[1] << 16);
+          }
+      }
+      convert_store(t, w);
     }
   }
   __syncthreads();
