@@ -60,6 +60,8 @@ def main():
   ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS))
   ap.add_argument("--precision", default=None, choices=["f32", "bf16"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--include-h2d", action="store_true",
+                  help="diagnostic: re-upload the PCM over PCIe inside every step (the PCIe-inclusive rate; never the headline value)")
   ap.add_argument("--gpu-streams", type=int, default=1,
                   help="contexts (HIP streams + host threads) feeding the GPU matching stage; pipelined mode only")
   ap.add_argument("--pipeline", type=int, default=32,
@@ -97,6 +99,9 @@ def main():
 
   def make_job(record):
     def job(c):
+      if args.include_h2d:
+        c.pcm_upload(_native.SIDE_VIDEO, pair.video)
+        c.pcm_upload(_native.SIDE_AUDIO, pair.audio)
       vf = c.features_resident(_native.SIDE_VIDEO)
       s_v = c.stats()
       af = c.features_resident(_native.SIDE_AUDIO)
@@ -193,6 +198,7 @@ def main():
                    "note": "GPU + DP stages of pair k+1 overlap the host LP of pair k; results identical to sequential align()"},
       "counts": {"gemm_pairs": acc["gemm_pairs"] / k, "survivors": acc["survivors"] / k, "matches": acc["matches"] / k},
       "max_offset_err_vs_injected_ms": round(inj_err_ms, 3),
+      "pcm_resident_in_hbm": not args.include_h2d,
       "pcm_h2d_ms_audio_side": round(h2d_ms, 2),
     }
     # HBM traffic of the dominant kernel from the committed PMC profile of this workload (PMC

@@ -386,10 +386,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 1) void k_match_f32(MatchArgs 
 // g is consumed (wave w stages tile w of the group).  Two workgroups per CU = two waves per SIMD,
 // so one wave's VALU epilogue runs under the other's MFMAs.
 // ------------------------------------------------------------------------------------------
-constexpr int kBfGroup = 4;                           // tiles per staged group (= waves per block)
+constexpr int kBfGroup = 4;                           // 32-column tiles per staged group
 constexpr int kBfTileBytes = 9 * 1024;                // 3 features x 3 steps x 64 lanes x 16 B
 constexpr int kBfBufBytes = kBfGroup * kBfTileBytes;  // one group
-constexpr int kBfSurv = 128;                          // survivor staging slots per wave (keeps two workgroups per CU)
+constexpr int kBfSurv = 128;                          // survivor staging slots per consumer wave
+constexpr int kBfConsumers = 8;                       // consumer waves per workgroup (32 video rows each)
+constexpr int kBfProducers = 4;                       // producer waves (one tile of every group each)
+constexpr int kBfBuffers = 3;                         // staged groups in LDS (producers run two groups ahead)
+#ifndef DA_BF_STAGGER
+#define DA_BF_STAGGER 0
+#endif
+constexpr int kBfStagger = DA_BF_STAGGER;             // x64 cycles of delay for the second consumer of each SIMD
+constexpr int kBfThreads = 64 * (kBfConsumers + kBfProducers);
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -410,36 +418,80 @@ __device__ __forceinline__ void stage_tile_bf16(const MatchArgs& a, unsigned cha
 
 #ifdef DA_DBG_STAMPS
 __device__ unsigned long long g_stamps[16];
-#define STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
-#else
-#define STAMP(k) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(256, 2) void k_match_bf16(MatchArgs a) {
-#ifdef DA_DBG_STAMPS
-  unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory");
-#endif
+// Warp-specialised: producer waves never touch the matrix pipe, consumer waves never issue DMA.
+// LDS: [3 buffers][4 tiles][9 KiB] operand fragments, per-column threshold / frame number, and
+// the consumers' survivor staging.  One workgroup per CU, three waves per SIMD.
+__global__ __launch_bounds__(kBfThreads, 3) void k_match_bf16(MatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* s_b = smem;                                                        // [2][kBfGroup][9 KiB]
-  unsigned long long* s_surv = reinterpret_cast<unsigned long long*>(smem + 2 * kBfBufBytes);   // [4][kBfSurv]
-  float* s_thr = reinterpret_cast<float*>(smem + 2 * kBfBufBytes + 4 * kBfSurv * 8);           // [2][kBfGroup][32]
-  int32_t* s_ic = reinterpret_cast<int32_t*>(s_thr + 2 * kBfGroup * 32);                        // [2][kBfGroup][32]
+  unsigned char* s_b = smem;                                                        // [kBfBuffers][kBfGroup][9 KiB]
+  unsigned long long* s_surv = reinterpret_cast<unsigned long long*>(smem + kBfBuffers * kBfBufBytes);     // [consumers][kBfSurv]
+  float* s_thr = reinterpret_cast<float*>(smem + kBfBuffers * kBfBufBytes + kBfConsumers * kBfSurv * 8);   // [kBfBuffers][kBfGroup][32]
+  int32_t* s_ic = reinterpret_cast<int32_t*>(s_thr + kBfBuffers * kBfGroup * 32);                           // [kBfBuffers][kBfGroup][32]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t vt0 = ((int64_t)blockIdx.x * 4 + wave) * 64;              // this wave's first video row
-  SurvSink sk{s_surv + wave * kBfSurv, 0, kBfSurv};
+  const bool producer = wave >= kBfConsumers;
   const int64_t a_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block * 32;
   int64_t a_end = a_begin + (int64_t)a.audio_tiles_per_block * 32;
   if (a_end > a.n_a) a_end = a.n_a;
   if (a_begin >= a_end) return;                                           // uniform per block
+  const int64_t n_groups = (a_end - a_begin + 32 * kBfGroup - 1) / (32 * kBfGroup);
+  auto tile_pos = [&](int64_t g, int w) { return a_begin + (g * kBfGroup + w) * 32; };
 
-  // fixed operand: 2 x 32 video rows, pre-scaled by -1/|V| (rows past the end stay inert)
-  bf16x8 A[2][3][3];
+  if (producer) {
+    // ------------------------------------------------------------------ producer wave
+    // Stages tile `pw` of every group, two groups ahead of the consumers (three LDS buffers), so
+    // the DMA issued in one iteration has a whole iteration to land before it is waited for.
+    const int pw = wave - kBfConsumers;
+    auto fetch_patch = [&](int32_t ic, uint32_t (&pv)[3]) {
+      if (h) { pv[0] = a.nrmpk_a[0][ic]; pv[1] = a.nrmpk_a[1][ic]; pv[2] = a.nrmpk_a[2][ic]; }
+      else { pv[0] = __float_as_uint(a.prod_a[ic]); pv[1] = 0; pv[2] = 0; }
+    };
+    int32_t ic0, ic1 = 0, ic2 = 0;                       // frame numbers of groups g, g+1, g+2
+    uint32_t pv0[3], pv1[3] = {0, 0, 0}, pv2[3] = {0, 0, 0};
+    ic0 = fetch_index(a, tile_pos(0, pw), a_end, r);
+    fetch_patch(ic0, pv0);
+    stage_tile_bf16(a, s_b + 0 * kBfBufBytes + pw * kBfTileBytes, ic0, h);
+    if (n_groups > 1) {
+      ic1 = fetch_index(a, tile_pos(1, pw), a_end, r);
+      fetch_patch(ic1, pv1);
+      stage_tile_bf16(a, s_b + 1 * kBfBufBytes + pw * kBfTileBytes, ic1, h);
+    }
+    ic2 = fetch_index(a, tile_pos(2, pw), a_end, r);
+    for (int64_t g = 0; g < n_groups; ++g) {
+      const int cur = (int)(g % kBfBuffers);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // DMA of group g (and g+1) has landed
+      {
+        unsigned char* tile = s_b + cur * kBfBufBytes + pw * kBfTileBytes;
+        if (h) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int64_t vr = vt0 + 32 * t + r;
+          for (int j = 0; j < 3; ++j)
+            *reinterpret_cast<uint32_t*>(tile + (3 * j + 2) * 1024 + lane * 16 + 4) = pv0[j];
+        } else {
+          s_thr[(cur * kBfGroup + pw) * 32 + r] = ((tile_pos(g, pw) + r) < a_end) ? a.thr * __uint_as_float(pv0[0]) : -__builtin_inff();
+          s_ic[(cur * kBfGroup + pw) * 32 + r] = ic0;
+        }
+      }
+      __syncthreads();                           // group g published; buffer (g+2)%3 = (g-1)%3 is free again
+      if (g + 2 < n_groups) {
+        fetch_patch(ic2, pv2);
+        stage_tile_bf16(a, s_b + (int)((g + 2) % kBfBuffers) * kBfBufBytes + pw * kBfTileBytes, ic2, h);
+      }
+      ic0 = ic1; pv0[0] = pv1[0]; pv0[1] = pv1[1]; pv0[2] = pv1[2];
+      ic1 = ic2; pv1[0] = pv2[0]; pv1[1] = pv2[1]; pv1[2] = pv2[2];
+      ic2 = fetch_index(a, tile_pos(g + 3, pw), a_end, r);
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer wave
+  const int64_t vt0 = ((int64_t)blockIdx.x * kBfConsumers + wave) * 32;   // this wave's 32 video rows
+  SurvSink sk{s_surv + wave * kBfSurv, 0, kBfSurv};
+  bf16x8 A[3][3];
+  {
+    const int64_t vr = vt0 + r;
     const bool vok = vr < a.n_v;
     const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
 #pragma unroll
@@ -454,84 +506,39 @@ __global__ __launch_bounds__(256, 2) void k_match_bf16(MatchArgs a) {
           uint16_t x = 0;
           if (k < kWin) x = f32_to_bf16((float)(p[k] * sc));
           else if (k == 42 || k == 43) x = 0x3F80;            // 1.0: the norm slots
-          A[t][j][s][e] = (short)x;
+          A[j][s][e] = (short)x;
         }
     }
   }
-
-  const int64_t n_groups = (a_end - a_begin + 32 * kBfGroup - 1) / (32 * kBfGroup);
-  // stage group 0 (wave w stages tile w), and fetch the row indices of group 1
-  auto tile_pos = [&](int64_t g, int w) { return a_begin + (g * kBfGroup + w) * 32; };
-  // per-lane patch value of the tile this wave stages: h = 1 lanes need the three packed norms,
-  // h = 0 lanes the column threshold; fetched one group ahead like the row indices
-  auto fetch_patch = [&](int32_t ic, uint32_t (&pv)[3]) {
-    if (h) { pv[0] = a.nrmpk_a[0][ic]; pv[1] = a.nrmpk_a[1][ic]; pv[2] = a.nrmpk_a[2][ic]; }
-    else { pv[0] = __float_as_uint(a.prod_a[ic]); pv[1] = 0; pv[2] = 0; }
-  };
-  int32_t ic_cur = fetch_index(a, tile_pos(0, wave), a_end, r);
-  uint32_t pv_cur[3], pv_nxt[3] = {0, 0, 0};
-  fetch_patch(ic_cur, pv_cur);
-  stage_tile_bf16(a, s_b + wave * kBfTileBytes, ic_cur, h);
-  int32_t ic_nxt = fetch_index(a, tile_pos(1, wave), a_end, r);
+  const int64_t vtile = vt0 >> 5;
   for (int64_t g = 0; g < n_groups; ++g) {
-    const int cur = (int)(g & 1);
-    if (g > 0) { pv_cur[0] = pv_nxt[0]; pv_cur[1] = pv_nxt[1]; pv_cur[2] = pv_nxt[2]; }
-    STAMP(0);
-    // ---- finish staging of group g: wait for this wave's DMA, patch the norm slots, publish
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(1);
-    {
-      unsigned char* tile = s_b + cur * kBfBufBytes + wave * kBfTileBytes;
-      if (h) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          *reinterpret_cast<uint32_t*>(tile + (3 * j + 2) * 1024 + lane * 16 + 4) = pv_cur[j];
-      } else {
-        s_thr[(cur * kBfGroup + wave) * 32 + r] = ((tile_pos(g, wave) + r) < a_end) ? a.thr * __uint_as_float(pv_cur[0]) : -__builtin_inff();
-        s_ic[(cur * kBfGroup + wave) * 32 + r] = ic_cur;
-      }
-    }
-    STAMP(2);
-    __syncthreads();
-    STAMP(3);
-    // ---- start staging group g+1 into the other buffer (its last readers passed the barrier above)
-    ic_cur = ic_nxt;
-    if (g + 1 < n_groups) {
-      fetch_patch(ic_cur, pv_nxt);               // consumed after the next barrier
-      stage_tile_bf16(a, s_b + (cur ^ 1) * kBfBufBytes + wave * kBfTileBytes, ic_cur, h);
-      ic_nxt = fetch_index(a, tile_pos(g + 2, wave), a_end, r);
-    }
-    STAMP(4);
-    // ---- consume group g.  The fragments of tile w+1 are read from LDS right after the MFMAs of
-    // tile w have been issued, so their latency hides under tile w's epilogue.
+    const int cur = (int)(g % kBfBuffers);
+    __syncthreads();                                               // group g is in buffer cur
+    // stagger: the two consumer waves of a SIMD (w and w+4) leave the barrier together and would
+    // run in lockstep -- both on the matrix pipe, then both in the epilogue.  Delaying one of them
+    // by about half an iteration lets one wave's epilogue run under the other's MFMAs.
+    if (kBfStagger > 0 && wave >= kBfConsumers / 2) __builtin_amdgcn_s_sleep(kBfStagger);     // measured: no effect (0, 3, 5, 8 x 64 cycles)
     const unsigned char* gbase = s_b + cur * kBfBufBytes + lane * 16;
     bf16x8 frag[3][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(&frag[j][s]) = *reinterpret_cast<const uint4*>(gbase + (3 * j + s) * 1024);
-    float thr_n = s_thr[(cur * kBfGroup + 0) * 32 + r];                // -inf: column past the end
+    float thr_n = s_thr[(cur * kBfGroup + 0) * 32 + r];            // -inf: column past the end
     int32_t ic_n = s_ic[(cur * kBfGroup + 0) * 32 + r];
 #pragma unroll 1
     for (int w = 0; w < kBfGroup; ++w) {
       if (tile_pos(g, w) >= a_end) break;
-      STAMP(5);
       const float thr_c = thr_n;
       const int32_t ic = ic_n;
-      f32x16 acc[2][3];
+      f32x16 acc[3];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[t][j] = f32x16{0};
+      for (int j = 0; j < 3; ++j) acc[j] = f32x16{0};
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][j][s], frag[j][s], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][j][s], frag[j][s], acc[1][j], 0, 0, 0);
-        }
-      STAMP(6);
-      if (w + 1 < kBfGroup) {
+        for (int s = 0; s < 3; ++s) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][s], frag[j][s], acc[j], 0, 0, 0);
+      if (w + 1 < kBfGroup) {                                      // next tile's fragments: latency hides under the epilogue
         const unsigned char* nt = gbase + (w + 1) * kBfTileBytes;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -540,30 +547,30 @@ __global__ __launch_bounds__(256, 2) void k_match_bf16(MatchArgs a) {
         thr_n = s_thr[(cur * kBfGroup + w + 1) * 32 + r];
         ic_n = s_ic[(cur * kBfGroup + w + 1) * 32 + r];
       }
-      STAMP(7);
+      // rows 15..0: packed products for two rows at a time, then mask = 2*mask + (prod <= thr)
+      // as one compare + one add-with-carry per row (row q ends at bit q)
+      uint32_t mask = 0;
+#ifdef DA_DBG_BF_NOEPI
+      asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][7]), "v"(acc[2][15]), "v"(thr_c), "v"(ic));
+#else
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        // rows 15..0: packed products for two rows at a time, then mask = 2*mask + (prod <= thr)
-        // as one compare + one add-with-carry per row (row q ends at bit q)
-        uint32_t mask = 0;
-#pragma unroll
-        for (int q = 14; q >= 0; q -= 2) {
-          const f32x2 x0 = {acc[t][0][q], acc[t][0][q + 1]};
-          const f32x2 x1 = {acc[t][1][q], acc[t][1][q + 1]};
-          const f32x2 x2 = {acc[t][2][q], acc[t][2][q + 1]};
-          const f32x2 pr = x0 * x1 * x2;
-          asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[1]), "v"(thr_c) : "vcc");
-          asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[0]), "v"(thr_c) : "vcc");
-        }
-        emit_tile(sk, a, lane, h, (vt0 >> 5) + t, mask, ic);
+      for (int q = 14; q >= 0; q -= 2) {
+        const f32x2 x0 = {acc[0][q], acc[0][q + 1]};
+        const f32x2 x1 = {acc[1][q], acc[1][q + 1]};
+        const f32x2 x2 = {acc[2][q], acc[2][q + 1]};
+        const f32x2 pr = x0 * x1 * x2;
+        asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[1]), "v"(thr_c) : "vcc");
+        asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[0]), "v"(thr_c) : "vcc");
       }
-      STAMP(8);
+#endif
+#ifndef DA_DBG_BF_NOEMIT
+      emit_tile(sk, a, lane, h, vtile, mask, ic);
+#else
+      asm volatile("" ::"v"(mask));
+#endif
     }
   }
   sink_flush(sk, a, lane);
-#ifdef DA_DBG_STAMPS
-  if (lane == 0) for (int k = 0; k < 10; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
-#endif
 }
 
 void debug_read_stamps(unsigned long long out[16]) {
@@ -589,16 +596,17 @@ void launch_match_f32(const MatchArgs& a, hipStream_t s) {
 }
 void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   if (a.n_v <= 0 || a.n_a <= 0) return;
-  const int smem = 2 * kBfBufBytes + 4 * kBfSurv * 8 + 2 * kBfGroup * 32 * (4 + 4);
+  const int smem = kBfBuffers * kBfBufBytes + kBfConsumers * kBfSurv * 8 + kBfBuffers * kBfGroup * 32 * (4 + 4);
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     once = true;
   }
-  const int64_t bx = (a.n_v + 255) / 256;                       // 4 waves x 64 video rows per block
+  const int64_t rows_per_block = 32 * kBfConsumers;
+  const int64_t bx = (a.n_v + rows_per_block - 1) / rows_per_block;
   const int64_t atiles = (a.n_a + 31) / 32;
   const int64_t by = (atiles + a.audio_tiles_per_block - 1) / a.audio_tiles_per_block;
-  hipLaunchKernelGGL(k_match_bf16, dim3((unsigned)bx, (unsigned)by), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(k_match_bf16, dim3((unsigned)bx, (unsigned)by), dim3(kBfThreads), smem, s, a);
 }
 
 // diagnostics: the correlations exactly as the GEMM precision forms them, for explicit pairs.
