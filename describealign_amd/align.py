@@ -381,6 +381,20 @@ def _lp_worker(args):
   return lp, time.perf_counter() - t0
 
 
+def _pin_worker(slot_counter, lock, stride):
+  """Give every worker process its own core (spread by `stride` logical CPUs) so concurrent LP
+  solves do not share SMT siblings or migrate."""
+  import os
+  try:
+    with lock:
+      k = slot_counter.value
+      slot_counter.value += 1
+    cpus = sorted(os.sched_getaffinity(0))
+    os.sched_setaffinity(0, {cpus[(k * stride) % len(cpus)]})
+  except Exception:
+    pass
+
+
 # ---- worker-process side of the batch pipeline ---------------------------------------------------
 # Worker processes never touch the GPU (a second process with a device context makes the GPU
 # time-slice between processes, which costs far more than it gains): they run the host-only
@@ -465,7 +479,13 @@ class AlignPipeline:
     saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
     for k in saved:
       os.environ[k] = "1"
-    self.pool = cf.ProcessPoolExecutor(max_workers=self.depth, mp_context=mp.get_context("spawn"))
+    mpc = mp.get_context("spawn")
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    pin = int(os.environ.get("DALIGN_PIN_WORKERS", "1")) and ncpu >= 4 * self.depth
+    init, initargs = (None, ())
+    if pin:
+      init, initargs = _pin_worker, (mpc.Value("i", 0), mpc.Lock(), max(1, (ncpu // 2) // self.depth))
+    self.pool = cf.ProcessPoolExecutor(max_workers=self.depth, mp_context=mpc, initializer=init, initargs=initargs)
     list(self.pool.map(int, range(self.depth)))          # spawn them now, under that environment
     for k, v in saved.items():
       if v is None:
