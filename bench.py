@@ -64,8 +64,8 @@ def main():
                   help="diagnostic: re-upload the PCM over PCIe inside every step (the PCIe-inclusive rate; never the headline value)")
   ap.add_argument("--gpu-streams", type=int, default=1,
                   help="contexts (HIP streams + host threads) feeding the GPU matching stage; pipelined mode only")
-  ap.add_argument("--pipeline", type=int, default=32,
-                  help="host LP worker processes; pair k+1's GPU/DP stages overlap pair k's LP (0 = strictly sequential)")
+  ap.add_argument("--pipeline", type=int, default=-1,
+                  help="host worker processes (chain DP, pass 1, LP); -1 = one per physical core of this rank's share of the host, max 32; 0 = strictly sequential align()")
   args = ap.parse_args()
 
   import torch
@@ -75,6 +75,8 @@ def main():
   device = local_rank if world > 1 else 0
   from describealign_amd import align as A
 
+  if args.pipeline < 0:
+    args.pipeline = A.default_worker_count(int(os.environ.get("LOCAL_WORLD_SIZE", world)))
   wl = WORKLOADS[args.workload]
   prec_name = args.precision or wl["precision"]
   prec = _native.PREC_F32 if prec_name == "f32" else _native.PREC_BF16

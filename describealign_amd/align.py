@@ -381,18 +381,26 @@ def _lp_worker(args):
   return lp, time.perf_counter() - t0
 
 
-def _pin_worker(slot_counter, lock, stride):
-  """Give every worker process its own core (spread by `stride` logical CPUs) so concurrent LP
-  solves do not share SMT siblings or migrate."""
+def _pin_worker(slot_counter, lock, first_slot, stride):
+  """Give every worker process its own core (slots spread by `stride` logical CPUs, offset by the
+  rank's `first_slot`) so concurrent LP solves do not share SMT siblings, migrate, or -- with one
+  rank per GPU on the same host -- pile onto the same cores as another rank's workers."""
   import os
   try:
     with lock:
       k = slot_counter.value
       slot_counter.value += 1
     cpus = sorted(os.sched_getaffinity(0))
-    os.sched_setaffinity(0, {cpus[(k * stride) % len(cpus)]})
+    os.sched_setaffinity(0, {cpus[((first_slot + k) * stride) % len(cpus)]})
   except Exception:
     pass
+
+
+def default_worker_count(local_world: int = 1) -> int:
+  """LP worker processes per rank: one per physical core of this rank's share of the host, at most 32."""
+  import os
+  ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+  return int(max(2, min(32, (ncpu // 2) // max(1, local_world))))
 
 
 # ---- worker-process side of the batch pipeline ---------------------------------------------------
@@ -481,10 +489,13 @@ class AlignPipeline:
       os.environ[k] = "1"
     mpc = mp.get_context("spawn")
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    pin = int(os.environ.get("DALIGN_PIN_WORKERS", "1")) and ncpu >= 4 * self.depth
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    pin = int(os.environ.get("DALIGN_PIN_WORKERS", "1")) and ncpu >= 2 * self.depth * local_world
     init, initargs = (None, ())
     if pin:
-      init, initargs = _pin_worker, (mpc.Value("i", 0), mpc.Lock(), max(1, (ncpu // 2) // self.depth))
+      stride = max(1, ncpu // (self.depth * local_world))
+      init, initargs = _pin_worker, (mpc.Value("i", 0), mpc.Lock(), local_rank * self.depth, stride)
     self.pool = cf.ProcessPoolExecutor(max_workers=self.depth, mp_context=mpc, initializer=init, initargs=initargs)
     list(self.pool.map(int, range(self.depth)))          # spawn them now, under that environment
     for k, v in saved.items():
