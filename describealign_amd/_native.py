@@ -25,7 +25,8 @@ ERR_CAPACITY = -3
 ERR_MISMATCH = -4
 
 EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm_upload",
-           "da_features_resident", "da_features", "da_match", "da_match_fetch", "da_match_corr", "da_chain",
+           "da_features_resident", "da_features", "da_match", "da_match_begin", "da_match_finish", "da_match_fetch",
+           "da_match_corr", "da_chain",
            "da_refine", "da_stats"]
 
 
@@ -73,6 +74,8 @@ def load():
     lib.da_features_resident.argtypes = [vp, i32, vp, i64, P(i64)]
     lib.da_features.argtypes = [vp, vp, i64, i32, i32, vp, i64, P(i64)]
     lib.da_match.argtypes = [vp, vp, i64, P(i64), vp, i64, P(i64), i32, i64, i64, vp, vp, vp, P(i64)]
+    lib.da_match_begin.argtypes = [vp, vp, i64, P(i64), vp, i64, P(i64), i32, i64, i64]
+    lib.da_match_finish.argtypes = [vp, P(i64)]
     lib.da_match_fetch.argtypes = [vp, vp, vp, vp, i64]
     lib.da_match_corr.argtypes = [vp, vp, vp, i64, vp]
     lib.da_chain.argtypes = [vp, vp, vp, vp, i64, C.c_double, vp, vp, P(i64)]
@@ -189,18 +192,24 @@ class Context:
       rows[k, :len(f)] = f
     return rows, (C.c_int64 * 2)(le, lo)
 
-  def match(self, video_features, audio_features, mode: int = MATCH_HASHED, rows=None, capacity=None, alloc=None):
-    """Verified matches (i, v, qual) sorted by (i, v) -- describealign.py:595-673."""
+  def match_begin(self, video_features, audio_features, mode: int = MATCH_HASHED, rows=None):
+    """Enqueue preparation + the similarity GEMM for one pair and return without waiting."""
     vrows, vlen = self._pack_rows(video_features)
     arows, alen = self._pack_rows(audio_features)
     rb, re = (0, -1) if rows is None else rows
-    # phase 1: compute (results stay on the device), learn the count; phase 2: exact-size fetch
+    self._pending_rows = (vrows, arows, vlen, alen)          # must outlive the asynchronous work
+    self._check(self._lib.da_match_begin(self._h, _ptr(vrows), vrows.shape[1], vlen, _ptr(arows), arows.shape[1], alen,
+                                         mode, rb, re))
+
+  def match_finish(self) -> int:
+    """Wait for the GEMM, verify + sort on the device; returns the number of matches (resident)."""
     n = C.c_int64(0)
-    rc = self._lib.da_match(self._h, _ptr(vrows), vrows.shape[1], vlen, _ptr(arows), arows.shape[1], alen,
-                            mode, rb, re, None, None, None, C.byref(n))
-    if rc != ERR_CAPACITY:
-      self._check(rc)
-    k = n.value
+    self._check(self._lib.da_match_finish(self._h, C.byref(n)))
+    self._pending_rows = None
+    return n.value
+
+  def match_fetch(self, k: int, alloc=None):
+    """Copy the k resident matches out (own copy stream: may overlap the next pair's GEMM)."""
     if alloc is None:
       oi = np.empty(k, dtype=np.int32); ov = np.empty(k, dtype=np.int32); oq = np.empty(k, dtype=np.float64)
     else:
@@ -208,6 +217,11 @@ class Context:
     if k:
       self._check(self._lib.da_match_fetch(self._h, _ptr(oi), _ptr(ov), _ptr(oq), k))
     return oi, ov, oq
+
+  def match(self, video_features, audio_features, mode: int = MATCH_HASHED, rows=None, capacity=None, alloc=None):
+    """Verified matches (i, v, qual) sorted by (i, v) -- describealign.py:595-673."""
+    self.match_begin(video_features, audio_features, mode, rows)
+    return self.match_fetch(self.match_finish(), alloc)
 
   def match_corr(self, i, v):
     i = np.ascontiguousarray(i, dtype=np.int32); v = np.ascontiguousarray(v, dtype=np.int32)

@@ -512,6 +512,7 @@ class AlignPipeline:
     self._dir = tempfile.mkdtemp(prefix=f"dalign_{os.getpid()}_", dir=shm)
     self._seq = 0
     self._free = []        # reusable (file name, bytes) blocks: fresh tmpfs pages cost ~0.2 ms per MB
+    self._deferred = {}    # per GPU context: the pair whose matches are finished but not yet copied out
     import sys
     self._old_switch = sys.getswitchinterval()
     sys.setswitchinterval(2e-4)
@@ -547,14 +548,32 @@ class AlignPipeline:
     shutil.rmtree(self._dir, ignore_errors=True)
     sys.setswitchinterval(self._old_switch)
 
-  def _gpu_stage(self, ctx, job, tm, fname):
-    t0 = time.perf_counter()
-    vf, af = job(ctx) if callable(job) else job
-    tm["features_s"] = time.perf_counter() - t0
-    dims = (len(vf[0]), len(vf[1]), len(af[0]), len(af[1]))
-    state = {}
+  def _gpu_stage(self, ctx, job, tm, fname, done):
+    """Features + matching of one pair on this GPU thread.  The copy-out and hand-off of the
+    PREVIOUS pair of this context run between match_begin and match_finish, i.e. under the GEMM."""
+    try:
+      t0 = time.perf_counter()
+      vf, af = job(ctx) if callable(job) else job
+      tm["features_s"] = time.perf_counter() - t0
+      t1 = time.perf_counter()
+      ctx.match_begin(vf, af, self.mode)
+      self._flush_deferred(ctx)
+      n = ctx.match_finish()
+      tm["device"] = ctx.stats()
+      tm["match_s"] = time.perf_counter() - t1
+      tm["n_matches"] = n
+      self._deferred[id(ctx)] = (vf, af, tm, fname, done, n)
+    except BaseException as e:
+      done.set_exception(e)
 
-    def alloc(n):
+  def _flush_deferred(self, ctx):
+    d = self._deferred.pop(id(ctx), None)
+    if d is None:
+      return
+    vf, af, tm, fname, done, n = d
+    try:
+      dims = (len(vf[0]), len(vf[1]), len(af[0]), len(af[1]))
+      state = {}
       lay, size = _block_layout(n, *dims)
       with self._lock:
         pick = next((b for b in self._free if b[1] >= size), None)
@@ -567,32 +586,27 @@ class AlignPipeline:
         fsize = size + size // 4          # slack so the next pair of similar size fits too
         state["fname"] = fname
         mm = np.memmap(fname, dtype=np.uint8, mode="w+", shape=(fsize,))
-      state["fsize"] = fsize
+      state.update(mm=mm, lay=lay, n=n, fsize=fsize)
       mi, mv, mq, bvf, baf, _, _ = _block_views(mm, lay, *dims)
       for dst, src in zip(bvf, vf):
         dst[:] = src
       for dst, src in zip(baf, af):
         dst[:] = src
-      state.update(mm=mm, lay=lay, n=n)
-      return mi, mv, mq
+      ctx.match_fetch(n, alloc=lambda k: (mi, mv, mq))
+      mm.flush()
+      mid = self.pool.submit(_proc_mid, state["fname"], fsize, n, *dims)
 
-    _stage_gpu_match(ctx, vf, af, self.mode, tm, alloc=alloc)
-    state["mm"].flush()
-    mid = self.pool.submit(_proc_mid, state["fname"], state["fsize"], state["n"], *dims)
-    # the refine stage is queued when the worker process finishes (no thread blocks on it)
-    import concurrent.futures as cf
-    done = cf.Future()
+      def on_mid(f):
+        def work():
+          try:
+            done.set_result(self._refine_stage(f.result(), state, dims, tm))
+          except BaseException as e:          # surfaces in finish()
+            done.set_exception(e)
+        self.refine_pool.submit(work)
 
-    def on_mid(f):
-      def work():
-        try:
-          done.set_result(self._refine_stage(f.result(), state, dims, tm))
-        except BaseException as e:          # surfaces in finish()
-          done.set_exception(e)
-      self.refine_pool.submit(work)
-
-    mid.add_done_callback(on_mid)
-    return done
+      mid.add_done_callback(on_mid)
+    except BaseException as e:
+      done.set_exception(e)
 
   def _refine_stage(self, mid_result, state, dims, tm):
     clusters, med, wtm = mid_result
@@ -610,13 +624,14 @@ class AlignPipeline:
     return out
 
   def run(self, jobs, timings=None):
+    import concurrent.futures as cf
     import os
-    pending = []          # (future of gpu stage, tm, fname) in submission order
+    pending = []          # (future of the pair's result, tm) in submission order
     n_gpu = len(self.gpu_ctxs)
 
     def finish(entry):
-      gfut, tm, fname = entry
-      out = gfut.result().result()
+      done, tm = entry
+      out = done.result()
       if timings is not None:
         timings.append(tm)
       return out
@@ -626,8 +641,12 @@ class AlignPipeline:
       g = k % n_gpu
       fname = os.path.join(self._dir, f"pair{self._seq}.bin")
       self._seq += 1
-      pending.append((self.gpu_threads[g].submit(self._gpu_stage, self.gpu_ctxs[g], job, tm, fname), tm, fname))
-      while len(pending) > self.depth + n_gpu:
+      done = cf.Future()
+      self.gpu_threads[g].submit(self._gpu_stage, self.gpu_ctxs[g], job, tm, fname, done)
+      pending.append((done, tm))
+      while len(pending) > self.depth + 2 * n_gpu:
         yield finish(pending.pop(0))
+    for g in range(n_gpu):          # the last pair of every context still has to be copied out
+      self.gpu_threads[g].submit(self._flush_deferred, self.gpu_ctxs[g])
     while pending:
       yield finish(pending.pop(0))

@@ -65,6 +65,13 @@ struct da_ctx {
   DevBuf ascaled, vscaled, band_y, band_q, band_part;
   bool match_ready = false;
   unsigned long long n_match_resident = 0;
+  // state carried from da_match_begin to da_match_finish
+  bool match_pending = false;
+  bool fetch_ready = false;       // results of the last finished match are resident (keys0 / q1)
+  int pend_mode = 0; int64_t pend_nv = 0; size_t pend_cap = 0;
+  hipEvent_t gemm_e0 = nullptr, gemm_e1 = nullptr, prep_e0 = nullptr, prep_e1 = nullptr;
+  hipStream_t copy_stream = nullptr;
+  std::vector<int32_t> h_vlist, h_alist;
   MatchArgs last_match{};
   da_stats_t st{};
 };
@@ -143,6 +150,9 @@ int da_create(int device_id, int precision, da_ctx** out) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return DA_ERR_DEVICE; }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DA_ERR_DEVICE; }
   (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
+  (void)hipEventCreate(&c->gemm_e0); (void)hipEventCreate(&c->gemm_e1);
+  (void)hipEventCreate(&c->prep_e0); (void)hipEventCreate(&c->prep_e1);
+  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DA_ERR_DEVICE; }
   FeatTables T; build_tables(T);
   if (c->tables.ensure(sizeof T) != hipSuccess ||
       hipMemcpy(c->tables.p, &T, sizeof T, hipMemcpyHostToDevice) != hipSuccess) { da_destroy(c); return DA_ERR_DEVICE; }
@@ -172,6 +182,8 @@ void da_destroy(da_ctx* c) {
   for (DevBuf* b : all) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (hipEvent_t e : {c->gemm_e0, c->gemm_e1, c->prep_e0, c->prep_e1}) if (e) (void)hipEventDestroy(e);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -286,25 +298,38 @@ int upload_and_prep(da_ctx* c, Side& s, const float* feat, int64_t stride, const
 
 }  // namespace
 
-extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const int64_t v_lengths[2],
-                        const float* afeat, int64_t a_stride, const int64_t a_lengths[2], int mode,
-                        int64_t row_begin, int64_t row_end, int32_t* out_i, int32_t* out_v, double* out_q,
-                        int64_t* n_out) {
+static int launch_gemm(da_ctx* c, MatchArgs& m, size_t cap) {
+  HIP_TRY(c, c->surv.ensure(sizeof(unsigned long long) * cap));
+  m.out = c->surv.as<unsigned long long>(); m.capacity = cap;
+  HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+  HIP_TRY(c, hipEventRecord(c->gemm_e0, c->stream));
+  if (c->precision == DA_PREC_F32) launch_match_f32(m, c->stream); else launch_match_bf16(m, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(c->gemm_e1, c->stream));
+  c->pend_cap = cap;
+  c->last_match = m;
+  return DA_OK;
+}
+
+extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, const int64_t v_lengths[2],
+                              const float* afeat, int64_t a_stride, const int64_t a_lengths[2], int mode,
+                              int64_t row_begin, int64_t row_end) {
   if (!c) return DA_ERR_ARG;
-  if (!vfeat || !afeat || !v_lengths || !a_lengths || !n_out || (mode != 0 && mode != 1))
+  if (!vfeat || !afeat || !v_lengths || !a_lengths || (mode != 0 && mode != 1))
     return fail(c, DA_ERR_ARG, "da_match: bad argument");
   if (v_lengths[0] > v_stride || a_lengths[0] > a_stride || v_lengths[1] > v_lengths[0] || a_lengths[1] > a_lengths[0])
     return fail(c, DA_ERR_ARG, "da_match: inconsistent lengths");
   HIP_TRY(c, hipSetDevice(c->device));
-  c->match_ready = false;
+  c->match_ready = false; c->match_pending = false;       // fetch_ready is untouched: the previous results stay fetchable
   Side& V = c->side[0]; Side& A = c->side[1];
-  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(c, hipEventRecord(c->prep_e0, c->stream));
   int rc = upload_and_prep(c, V, vfeat, v_stride, v_lengths, 1); if (rc) return rc;
   rc = upload_and_prep(c, A, afeat, a_stride, a_lengths, 0); if (rc) return rc;
-  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(c, hipEventRecord(c->prep_e1, c->stream));
 
   // row lists from the energy rows (describealign.py:629-630, :657-658)
-  std::vector<int32_t> vlist, alist;
+  std::vector<int32_t>& vlist = c->h_vlist; std::vector<int32_t>& alist = c->h_alist;
+  vlist.clear(); alist.clear();
   {
     const int64_t nv = v_lengths[0] - kWin;
     int64_t k = 0;
@@ -351,36 +376,43 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
     if (atiles > 0 && (atiles + tpb - 1) / tpb > 65535) tpb = (atiles + 65534) / 65535;
     m.audio_tiles_per_block = (int)tpb;
   }
-  unsigned long long* d_cnt = c->counters.as<unsigned long long>();
-  m.out_count = d_cnt;
+  m.out_count = c->counters.as<unsigned long long>();
+  c->pend_mode = mode; c->pend_nv = n_v;
+  rc = launch_gemm(c, m, (size_t)std::max(1e6, c->st.gemm_pairs * 4e-3));
+  if (rc) return rc;
+  c->match_pending = true;                      // nothing has been waited for: the GEMM is in flight
+  return DA_OK;
+}
 
+extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
+  if (!c) return DA_ERR_ARG;
+  if (!c->match_pending || !n_out) return fail(c, DA_ERR_STATE, "da_match_finish: no da_match_begin in flight");
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->match_pending = false;
+  c->fetch_ready = false;                                   // verification is about to overwrite the result buffers
+  Side& V = c->side[0]; Side& A = c->side[1];
+  unsigned long long* d_cnt = c->counters.as<unsigned long long>();
+  const int mode = c->pend_mode; const int64_t n_v = c->pend_nv;
   unsigned long long n_surv = 0;
-  size_t cap = (size_t)std::max(1e6, c->st.gemm_pairs * 4e-3);
+  size_t cap = c->pend_cap;
   for (int attempt = 0; attempt < 3; ++attempt) {
-    HIP_TRY(c, c->surv.ensure(sizeof(unsigned long long) * cap));
-    m.out = c->surv.as<unsigned long long>(); m.capacity = cap;
-    HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 64, c->stream));
-    hipEvent_t e0, e1; HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
-    HIP_TRY(c, hipEventRecord(e0, c->stream));
-    if (c->precision == DA_PREC_F32) launch_match_f32(m, c->stream); else launch_match_bf16(m, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(e1, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&n_surv, d_cnt, sizeof n_surv, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1); c->st.gemm_ms = ms;
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, c->gemm_e0, c->gemm_e1); c->st.gemm_ms = ms;
     if (std::getenv("DALIGN_DEBUG_STAMPS")) {
       unsigned long long st[16]; debug_read_stamps(st);
       unsigned long long tot = 0; for (int k = 0; k < 10; ++k) tot += st[k];
       if (tot) { std::fprintf(stderr, "stamps(%%):"); for (int k = 0; k < 10; ++k) std::fprintf(stderr, " %d:%.1f", k, 100.0 * st[k] / tot); std::fprintf(stderr, "  total_cycles_per_wave=%.0f\n", (double)tot); }
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (n_surv <= cap) break;
-    cap = (size_t)(n_surv + n_surv / 16 + 1024);
     if (attempt == 2) return fail(c, DA_ERR_DEVICE, "da_match: survivor list kept overflowing");
+    cap = (size_t)(n_surv + n_surv / 16 + 1024);          // rare: rerun with the exact size
+    MatchArgs m = c->last_match;
+    int rc = launch_gemm(c, m, cap); if (rc) return rc;
   }
-  { float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.prep_ms = ms; }
+  { float ms = 0.f; (void)hipEventElapsedTime(&ms, c->prep_e0, c->prep_e1); c->st.prep_ms = ms; }
   c->st.survivors = (double)n_surv;
-  c->last_match = m; c->match_ready = true;
+  c->match_ready = true;
 
   // exact verification + sort
   unsigned long long n_match = 0;
@@ -399,7 +431,6 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
     v.vlist = c->vlist.as<int32_t>(); v.n_v = n_v; v.n_pairs = d_cnt + 2;
     v.n_out = d_cnt + 1;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    unsigned long long n_pairs = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
       HIP_TRY(c, c->keys0.ensure(sizeof(unsigned long long) * mcap)); HIP_TRY(c, c->keys1.ensure(sizeof(unsigned long long) * mcap));
       HIP_TRY(c, c->q0.ensure(sizeof(double) * mcap)); HIP_TRY(c, c->q1.ensure(sizeof(double) * mcap));
@@ -408,13 +439,11 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
       launch_verify(v, n_surv, c->stream);
       HIP_TRY(c, hipGetLastError());
       HIP_TRY(c, hipMemcpyAsync(&n_match, d_cnt + 1, sizeof n_match, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipMemcpyAsync(&n_pairs, d_cnt + 2, sizeof n_pairs, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       if (n_match <= mcap) break;
       if (attempt == 1) return fail(c, DA_ERR_DEVICE, "da_match: match list kept overflowing");
       mcap = (size_t)n_match + 1024;
     }
-    (void)n_pairs;
     if (n_match > 0) {
       size_t tmp_bytes = 0;
       if (sort_pairs(nullptr, nullptr, nullptr, nullptr, (int64_t)n_match, nullptr, &tmp_bytes, c->stream) != 0)
@@ -423,6 +452,10 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
       if (sort_pairs(c->keys0.as<unsigned long long>(), c->keys1.as<unsigned long long>(), c->q0.as<double>(),
                      c->q1.as<double>(), (int64_t)n_match, c->sort_tmp.p, &tmp_bytes, c->stream) != 0)
         return fail(c, DA_ERR_DEVICE, "da_match: device sort failed");
+      // keys0 is free again after the sort: unpack the sorted keys into two int32 arrays there
+      launch_unpack_keys(c->keys1.as<unsigned long long>(), (int64_t)n_match, c->keys0.as<int32_t>(),
+                         c->keys0.as<int32_t>() + n_match, c->stream);
+      HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -430,31 +463,42 @@ extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const i
   }
   c->st.matches = (double)n_match;
   c->n_match_resident = n_match;
-  if (n_match > 0) {
-    // keys0 is free again after the sort: unpack the sorted keys into two int32 arrays there
-    launch_unpack_keys(c->keys1.as<unsigned long long>(), (int64_t)n_match, c->keys0.as<int32_t>(),
-                       c->keys0.as<int32_t>() + n_match, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-  }
-  const int64_t capacity = *n_out;
+  c->fetch_ready = true;
   *n_out = (int64_t)n_match;
-  if ((int64_t)n_match > capacity) return fail(c, DA_ERR_CAPACITY, "da_match: %llu matches exceed the caller's capacity %lld", n_match, (long long)capacity);
-  return da_match_fetch(c, out_i, out_v, out_q, (int64_t)n_match);
+  return DA_OK;
+}
+
+extern "C" int da_match(da_ctx* c, const float* vfeat, int64_t v_stride, const int64_t v_lengths[2],
+                        const float* afeat, int64_t a_stride, const int64_t a_lengths[2], int mode,
+                        int64_t row_begin, int64_t row_end, int32_t* out_i, int32_t* out_v, double* out_q,
+                        int64_t* n_out) {
+  if (!c) return DA_ERR_ARG;
+  if (!n_out) return fail(c, DA_ERR_ARG, "da_match: bad argument");
+  int rc = da_match_begin(c, vfeat, v_stride, v_lengths, afeat, a_stride, a_lengths, mode, row_begin, row_end);
+  if (rc) return rc;
+  int64_t n_match = 0;
+  rc = da_match_finish(c, &n_match);
+  if (rc) return rc;
+  const int64_t capacity = *n_out;
+  *n_out = n_match;
+  if (n_match > capacity) return fail(c, DA_ERR_CAPACITY, "da_match: %lld matches exceed the caller's capacity %lld", (long long)n_match, (long long)capacity);
+  return da_match_fetch(c, out_i, out_v, out_q, n_match);
 }
 
 extern "C" int da_match_fetch(da_ctx* c, int32_t* out_i, int32_t* out_v, double* out_q, int64_t n) {
   if (!c) return DA_ERR_ARG;
-  if (!c->match_ready) return fail(c, DA_ERR_STATE, "da_match_fetch: call da_match first");
+  if (!c->fetch_ready) return fail(c, DA_ERR_STATE, "da_match_fetch: no finished match is resident");
   if (n < 0 || (uint64_t)n > c->n_match_resident) return fail(c, DA_ERR_ARG, "da_match_fetch: n out of range");
   if (n == 0) return DA_OK;
   if (!out_i || !out_v || !out_q) return fail(c, DA_ERR_ARG, "da_match_fetch: null output");
   HIP_TRY(c, hipSetDevice(c->device));
   const int32_t* d_i = c->keys0.as<int32_t>();
-  HIP_TRY(c, hipMemcpyAsync(out_i, d_i, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(out_v, d_i + c->n_match_resident, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(out_q, c->q1.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // own copy stream: the results are complete (da_match_finish synchronised), so this copy may run
+  // while the next pair's da_match_begin work occupies the compute stream
+  HIP_TRY(c, hipMemcpyAsync(out_i, d_i, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->copy_stream));
+  HIP_TRY(c, hipMemcpyAsync(out_v, d_i + c->n_match_resident, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->copy_stream));
+  HIP_TRY(c, hipMemcpyAsync(out_q, c->q1.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->copy_stream));
+  HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
   return DA_OK;
 }
 

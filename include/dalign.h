@@ -73,6 +73,18 @@ int da_match(da_ctx* ctx,
              int mode, int64_t audio_row_begin, int64_t audio_row_end,
              int32_t* out_i, int32_t* out_v, double* out_q, int64_t* n_out);
 
+/* Split form of da_match for pipelining: da_match_begin uploads the rows, builds the row lists
+ * and ENQUEUES preparation + the similarity GEMM without waiting; da_match_finish waits for it,
+ * verifies, sorts and returns the match count (results stay resident for da_match_fetch).  The
+ * feature row arrays must stay valid until da_match_finish returns.  Between the two calls the
+ * caller may run da_match_fetch for the PREVIOUS pair: it copies on a separate stream and so
+ * overlaps the GEMM.  da_match == begin + finish + fetch. */
+int da_match_begin(da_ctx* ctx,
+                   const float* vfeat, int64_t v_stride, const int64_t v_lengths[2],
+                   const float* afeat, int64_t a_stride, const int64_t a_lengths[2],
+                   int mode, int64_t audio_row_begin, int64_t audio_row_end);
+int da_match_finish(da_ctx* ctx, int64_t* n_matches);
+
 /* Copy out the matches of the most recent da_match (they stay resident on the device until the
  * next da_match): lets a caller run da_match with *n_out = 0 to learn the count (it returns
  * DA_ERR_CAPACITY and the count) and then fetch into exactly sized buffers. */
