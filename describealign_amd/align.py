@@ -400,7 +400,7 @@ def default_worker_count(local_world: int = 1) -> int:
   """LP worker processes per rank: one per physical core of this rank's share of the host, at most 32."""
   import os
   ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-  return int(max(2, min(32, (ncpu // 2) // max(1, local_world))))
+  return int(max(2, min(24, (ncpu // 2) // max(1, local_world))))
 
 
 # ---- worker-process side of the batch pipeline ---------------------------------------------------
