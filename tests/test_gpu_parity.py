@@ -351,3 +351,47 @@ def test_c_abi_argument_errors(ctx, native):
     ctx.chain(mi, mv, mq, min_len=1050)
   n = C.c_int64(0)
   assert lib.da_match_fetch(h, None, None, None, 5) == -1                  # more than resident
+
+
+# ------------------------------------------------------------------------------------ randomized edges
+@pytest.mark.parametrize("seed", range(8))
+def test_features_random_lengths_and_extremes_vs_oracle(ctx, seed):
+  """Ragged lengths in every residue class of 105/210, mono and stereo, full int16 range
+  (including -32768 and runs of equal samples), against the oracle."""
+  from describealign_amd import synth
+  rng = np.random.default_rng(seed)
+  n = int(rng.integers(4000, 400000))
+  n += [0, 1, 104, 105, 106, 209, 211, 315][seed]
+  c = 1 + (seed % 2)
+  base = synth.programme(100 + seed, n).astype(np.int64) * int(rng.integers(1, 4))
+  pcm = np.clip(base, -32768, 32767).astype(np.int16)
+  pcm[rng.integers(0, n, 50)] = -32768
+  pcm[rng.integers(0, n, 50)] = 32767
+  k = int(rng.integers(0, n - 3000)); pcm[k:k + 2500] = 0                 # a silent stretch (sign stays +)
+  k = int(rng.integers(0, n - 3000)); pcm[k:k + 700] = -3                  # constant negative run
+  arr = pcm[None, :] if c == 1 else np.stack([pcm, np.roll(pcm, 37) // 2 * -1])
+  arr = np.ascontiguousarray(arr.astype(np.int16))
+  rows = ctx.features(arr)
+  want = O.features(arr)
+  for kk, (f, r) in enumerate(zip(rows, want)):
+    assert f.shape == r.shape, (kk, f.shape, r.shape)
+    np.testing.assert_allclose(f, np.asarray(r, dtype=np.float32), rtol=3e-5, atol=3e-5, err_msg=f"row {kk} n={n} c={c}")
+
+
+def test_refine_vs_oracle_on_ten_minute_pair(ctx):
+  """da_refine (banded extension kernels + second DP) against the oracle's restatement, fed with
+  the oracle's own pass-1 / LP / cluster intermediates for the 600 s pair (16+ clusters,
+  ~3e5 banded points) -- a much larger instance than the a40 golden."""
+  pair = cases.align_case("e600")
+  vf, af = O.features(pair.video), O.features(pair.audio)
+  st = {}
+  ox, oy, osim, opath, omed = O.align(vf, af, vf[0], af[0], stages=st)
+  cl = st["clusters"]
+  x0 = np.array([c[0][0] for c in cl]); x1 = np.array([c[0][-1] for c in cl])
+  off = np.array([c[1] for c in cl]); slo = np.array([c[2] for c in cl])
+  path, npts = ctx.refine(st["a_scaled"], st["v_scaled"], x0, x1, off, slo)
+  assert npts == sum(len(p) for p in st["points"])
+  want = opath.copy(); want[:, :2] *= 210.0
+  assert path.shape == want.shape
+  np.testing.assert_allclose(path[:, :3], want[:, :3], atol=1e-6)
+  np.testing.assert_allclose(path[:, 3:], want[:, 3:], atol=2e-3)
