@@ -62,3 +62,55 @@ def align_case(name: str) -> synth.SynthPair:
   if name == "mismatch":
     return synth.unrelated_pair(31, 120.0, 130.0)
   return synth.make_pair(**ALIGN_CASES[name])
+
+
+# --------------------------------------------------------------------------- --stretch_audio cases
+# name: (channels, seconds of video, seconds of audio, seeds, node times).  Node times are
+# (audio_desc_times, video_times) as align() would return them; the slopes are chosen so that
+# every branch of the reference's replace_aligned_segments (describealign.py:387-416) is taken:
+#   |1-slope| <= .005            -> quadratic resampling
+#   offset >= 10000 samples      -> stretch with the 10 base lags
+#   1000 < offset < 10000        -> 18 lags
+#   offset <= 1000               -> every lag 30..511
+#   dy < 2 s or |1-slope| > .1   -> left untouched
+STRETCH_CASES = {
+  "mix_stereo": dict(channels=2, video_seconds=18.5, audio_seconds=19.0, seed=41,
+                     video_times=[0.0, 3.0, 7.0, 8.5, 17.0, 18.4],
+                     audio_times=[0.3, 3.303, 7.383, 8.858, 17.103, 18.553]),
+  "fine_mono":  dict(channels=1, video_seconds=16.0, audio_seconds=16.5, seed=43,
+                     video_times=[0.25, 3.25, 6.25, 11.25, 13.75, 15.9],
+                     audio_times=[0.10, 3.118, 6.100, 11.100, 14.100, 16.2491]),
+  "edge_mono":  dict(channels=1, video_seconds=9.0, audio_seconds=8.905, seed=45,      # AD 220 samples shorter than its last
+                     video_times=[0.0, 4.0, 8.9],                                       # node says: resampling reads past the
+                     audio_times=[0.0, 4.004, 8.91]),                                   # end of the data (zeros)
+}
+
+
+def stretch_case(name: str):
+  """-> (video int16 (C,N), audio int16 (C,M), audio_times, video_times)."""
+  c = STRETCH_CASES[name]
+  sr = synth.SAMPLE_RATE
+  nv, na = int(c["video_seconds"] * sr), int(c["audio_seconds"] * sr)
+  ch = c["channels"]
+  vid = [synth.programme(c["seed"], nv)]
+  aud = [(synth.programme(c["seed"] + 1, na).astype(np.int64) * 5) // 8]      # quieter AD: loudness matching scales the video
+  if ch == 2:
+    vid.append((7 * vid[0].astype(np.int64)) // 8 + (synth._noise_i16(c["seed"], 30, 0, nv).astype(np.int64) >> 4))
+    aud.append((3 * synth.programme(c["seed"] + 2, na).astype(np.int64)) // 2)    # louder AD channel: the AD is scaled
+  vid = np.clip(np.stack(vid), -32767, 32767).astype(np.int16)
+  aud = np.clip(np.stack(aud), -32767, 32767).astype(np.int16)
+  return vid, aud, np.array(c["audio_times"], dtype=np.float64), np.array(c["video_times"], dtype=np.float64)
+
+
+def stretch_case_f16(name: str):
+  """float16 inputs for replace_aligned_segments as combine() hands them over: PCM held as
+  float16 (describealign.py:156) after a per-channel loudness gain (:1144-1148; fixed gains here
+  so the fixture does not depend on a reduction order)."""
+  vid, aud, x, y = stretch_case(name)
+  v, a = vid.astype(np.float16), aud.astype(np.float16)
+  for c in range(v.shape[0]):
+    if c == 0:
+      v[c] /= np.float64(1.1861478)
+    else:
+      a[c] *= np.float64(0.5779034)
+  return v, a, x, y

@@ -10,6 +10,9 @@ values are recorded.  Intermediates are read from the live `align` frame with a
 
   python tests/golden/make_golden.py [case ...]
 
+`stretch:<case>` records replace_aligned_segments (describealign.py:230-416) on the
+STRETCH_CASES inputs: the float16 bits of every replaced interval and each jump schedule.
+
 Outputs tests/golden/*.npz (+ report text for e180) and tests/golden/index.json.
 """
 from __future__ import annotations
@@ -187,10 +190,71 @@ def gen_align(name: str, deep: bool):
   return meta, cap
 
 
+class StretchProbe:
+  """Records the jump schedule of every call of the reference's nested `stretch`
+  (describealign.py:298-385) from its frame at return."""
+
+  def __init__(self):
+    self.schedules = []
+
+  def _global(self, frame, event, arg):
+    if event == "call" and frame.f_code.co_name == "stretch" and frame.f_code.co_filename == REF_FILE:
+      return self._local
+    return None
+
+  def _local(self, frame, event, arg):
+    if event == "return":
+      L = frame.f_locals
+      self.schedules.append(np.stack([np.asarray(L["jump_input_indices"]), np.asarray(L["jump_distances"])], axis=1)
+                            .astype(np.int64))
+    return self._local
+
+
+def gen_stretch(name):
+  """replace_aligned_segments (describealign.py:230-416) on a STRETCH_CASES input: records the
+  float16 bit patterns of every replaced interval and the jump schedules."""
+  t0 = time.time()
+  v, a, x, y = cases.stretch_case_f16(name)
+  before = v.copy()
+  probe = StretchProbe()
+  sys.settrace(probe._global)
+  try:
+    ref.replace_aligned_segments(v, a, x, y, False)
+  finally:
+    sys.settrace(None)
+  print()
+  ys = (y * ref.AUDIO_SAMPLE_RATE).astype(int)
+  out = {}
+  kept = []
+  for k in range(len(ys) - 1):
+    sl = slice(int(ys[k]), int(ys[k + 1]))
+    if not np.array_equal(v[:, sl].view(np.uint16), before[:, sl].view(np.uint16)):
+      out[f"seg{k}"] = v[:, sl].view(np.uint16).copy()
+      kept.append(k)
+  for k, s in enumerate(probe.schedules):
+    out[f"sched{k}"] = s
+  untouched = np.ones(v.shape[1], dtype=bool)
+  for k in kept:
+    untouched[int(ys[k]):int(ys[k + 1])] = False
+  assert np.array_equal(v[:, untouched].view(np.uint16), before[:, untouched].view(np.uint16))
+  # the same input with no_pitch_correction=True (every kept interval is resampled)
+  v2 = before.copy()
+  ref.replace_aligned_segments(v2, a, x, y, True)
+  print()
+  out["npc_sha1"] = np.frombuffer(bytes.fromhex(cases.sha1_of(v2.view(np.uint16))), dtype=np.uint8)
+  np.savez_compressed(os.path.join(HERE, f"stretch_{name}.npz"), **out)
+  meta = dict(sha1_inputs=cases.sha1_of(before.view(np.uint16), a.view(np.uint16)), replaced_intervals=kept,
+              n_schedules=len(probe.schedules), jumps_per_schedule=[int(len(s)) for s in probe.schedules],
+              sha1_output=cases.sha1_of(v.view(np.uint16)), seconds_reference=round(time.time() - t0, 2))
+  print(f"[stretch {name}] replaced={kept} schedules={meta['jumps_per_schedule']} ({meta['seconds_reference']} s)")
+  return meta
+
+
 def main(argv):
   idx_path = os.path.join(HERE, "index.json")
   index = json.load(open(idx_path)) if os.path.exists(idx_path) else {}
-  want = argv or ["features", "a40", "e180", "e180s", "e600", "rate2", "mismatch", "e1320"]
+  want = argv or (["features", "a40", "e180", "e180s", "e600", "rate2", "mismatch", "e1320"] +
+                  ["stretch:" + n for n in cases.STRETCH_CASES])
   index["reference_version"] = ref.__version__
   index["numpy"] = np.__version__
   import scipy
@@ -199,6 +263,8 @@ def main(argv):
     if name == "features":
       index["features"] = gen_features()
       print("[features] done")
+    elif name.startswith("stretch:"):
+      index.setdefault("stretch", {})[name[8:]] = gen_stretch(name[8:])
     else:
       meta, _ = gen_align(name, deep=(name == "a40"))
       index.setdefault("align", {})[name] = meta

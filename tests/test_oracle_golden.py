@@ -122,3 +122,48 @@ def test_mismatched_pair_raises():
   vf, af = O.features(pair.video), O.features(pair.audio)
   with pytest.raises(RuntimeError, match="Alignment failed"):
     O.align(vf, af, vf[0], af[0])
+
+
+# --------------------------------------------------------------------------- --stretch_audio path
+
+from oracle import stretch_oracle as SO  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(cases.STRETCH_CASES))
+def test_stretch_oracle_matches_reference(name):
+  """replace_aligned_segments (describealign.py:230-416): float16 bit patterns of every replaced
+  interval and every jump schedule, as recorded from the reference."""
+  g = np.load(os.path.join(GOLD, f"stretch_{name}.npz"))
+  meta = INDEX["stretch"][name]
+  v, a, x, y = cases.stretch_case_f16(name)
+  assert cases.sha1_of(v.view(np.uint16), a.view(np.uint16)) == meta["sha1_inputs"], "synthetic generator drifted"
+  before = v.copy()
+  plan = SO.segment_plan(x, y, False)
+  sched = SO.replace_aligned_segments(v, a, x, y, False)
+  assert len(sched) == meta["n_schedules"]
+  for k, s in enumerate(sched):
+    assert np.array_equal(s, g[f"sched{k}"]), f"jump schedule {k}"
+  for k, (kind, x0, x1, y0, y1) in enumerate(plan):
+    if k in meta["replaced_intervals"]:
+      assert kind != "skip"
+      assert np.array_equal(v[:, y0:y1].view(np.uint16), g[f"seg{k}"]), f"interval {k} ({kind})"
+    else:
+      assert np.array_equal(v[:, y0:y1].view(np.uint16), before[:, y0:y1].view(np.uint16))
+  assert cases.sha1_of(v.view(np.uint16)) == meta["sha1_output"]
+  # no_pitch_correction: every kept interval goes through the resampler
+  v2 = before.copy()
+  assert SO.replace_aligned_segments(v2, a, x, y, True) == []
+  assert cases.sha1_of(v2.view(np.uint16)) == bytes(g["npc_sha1"]).hex()
+
+
+def test_stretch_chunk_plan_covers_every_window_once():
+  """correlation_chunks (describealign.py:253-270): the windows handed out by successive chunks
+  are consecutive, start at 0 and reach n // 512."""
+  for n in (1535, 2048, 29286, 29287, 26112 + 25088, 100000, 529200, 3 * 25088 + 29286, 3 * 25088 + 29287):
+    nxt = 0
+    for begin, end, lo, hi in SO.correlation_chunks(n):
+      assert begin % SO.WINDOW == 0 and end <= n
+      assert begin // SO.WINDOW + lo == nxt
+      nxt = begin // SO.WINDOW + hi
+      assert end - begin >= 3 * SO.WINDOW - 1
+    assert nxt == n // SO.WINDOW, n
