@@ -15,7 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdalign.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 PREC_F32, PREC_BF16 = 0, 1
 SIDE_VIDEO, SIDE_AUDIO = 0, 1
@@ -27,13 +27,15 @@ ERR_MISMATCH = -4
 EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm_upload",
            "da_features_resident", "da_features", "da_match", "da_match_begin", "da_match_finish", "da_match_fetch",
            "da_match_corr", "da_chain",
-           "da_refine", "da_stats"]
+           "da_refine", "da_stats", "da_replace_segments", "da_stretch_resident", "da_stretch_schedule"]
 
 
 class Stats(C.Structure):
   _fields_ = [(n, C.c_double) for n in (
       "features_ms", "features_bytes", "prep_ms", "gemm_ms", "gemm_pairs", "gemm_flops", "verify_ms",
-      "survivors", "matches", "chain_ms", "refine_kernel_ms", "refine_dp_ms", "refine_points", "h2d_ms")]
+      "survivors", "matches", "chain_ms", "refine_kernel_ms", "refine_dp_ms", "refine_points", "h2d_ms",
+      "resample_ms", "resample_points", "resample_bytes", "correlate_ms", "correlate_windows", "viterbi_ms",
+      "splice_ms", "splice_points", "stretch_prepare_ms", "stretch_finish_ms")]
 
   def as_dict(self):
     return {n: getattr(self, n) for n, _ in self._fields_}
@@ -81,6 +83,9 @@ def load():
     lib.da_chain.argtypes = [vp, vp, vp, vp, i64, C.c_double, vp, vp, P(i64)]
     lib.da_refine.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, vp, i32, C.c_double, vp, P(i64), P(i64)]
     lib.da_stats.argtypes = [vp, P(Stats)]
+    lib.da_replace_segments.argtypes = [vp, vp, i64, vp, i64, i32, vp, vp, i32, i32]
+    lib.da_stretch_resident.argtypes = [vp, vp, vp, i32, i32, vp, i64, vp]
+    lib.da_stretch_schedule.argtypes = [vp, i32, vp, P(i64)]
     if lib.da_abi_version() != ABI_VERSION:
       raise ImportError("libdalign.so ABI version mismatch; rebuild it")
     _lib = lib
@@ -120,6 +125,7 @@ class Context:
     self.precision = precision
     self.device = device
     self._n = {}
+    self._channels = {}
 
   def close(self):
     if getattr(self, "_h", None) is not None and self._h:
@@ -161,6 +167,7 @@ class Context:
     pcm = np.ascontiguousarray(pcm)
     self._check(self._lib.da_pcm_upload(self._h, side, _ptr(pcm), n, channels, planar))
     self._n[side] = n
+    self._channels[side] = channels
     return n, channels
 
   def features_resident(self, side: int, download: bool = True):
@@ -256,6 +263,55 @@ class Context:
       self._check(rc)
       return path[:rows.value].copy(), npts.value
     raise RuntimeError("da_refine: capacity negotiation failed")
+
+  # ---- audio replacement (--stretch_audio) ---------------------------------------------------
+  @staticmethod
+  def _nodes(audio_times, video_times):
+    at = np.ascontiguousarray(audio_times, dtype=np.float64); vt = np.ascontiguousarray(video_times, dtype=np.float64)
+    if at.ndim != 1 or at.shape != vt.shape:
+      raise ValueError("audio_times and video_times must be 1-D arrays of equal length")
+    return at, vt
+
+  def replace_segments(self, video_arr, audio_desc_arr, audio_desc_times, video_times, no_pitch_correction=False):
+    """replace_aligned_segments (describealign.py:230-416): float16 (C, N) arrays, `video_arr`
+    is modified in place like the reference's."""
+    if video_arr.dtype != np.float16 or audio_desc_arr.dtype != np.float16 or video_arr.ndim != 2 or \
+       audio_desc_arr.ndim != 2 or video_arr.shape[0] != audio_desc_arr.shape[0]:
+      raise ValueError("video_arr and audio_desc_arr must be float16 (C, N) arrays with equal C")
+    if not video_arr.flags.c_contiguous:
+      raise ValueError("video_arr must be C-contiguous (it is updated in place)")
+    aud = np.ascontiguousarray(audio_desc_arr)
+    at, vt = self._nodes(audio_desc_times, video_times)
+    self._check(self._lib.da_replace_segments(self._h, _ptr(video_arr), video_arr.shape[1], _ptr(aud), aud.shape[1],
+                                              video_arr.shape[0], _ptr(at), _ptr(vt), len(at), int(bool(no_pitch_correction))))
+
+  def stretch_resident(self, audio_desc_times, video_times, no_pitch_correction=False):
+    """The --stretch_audio block of combine() (describealign.py:1135-1153, :136) on the PCM uploaded
+    with pcm_upload for both sides.  Returns (int16 (N, C) interleaved frames, loudness factors)."""
+    at, vt = self._nodes(audio_desc_times, video_times)
+    n = self._n[SIDE_VIDEO]
+    fac = np.zeros(2, dtype=np.float64)
+    out = np.empty((n, 2), dtype=np.int16)                  # sized for stereo; trimmed below
+    self._check(self._lib.da_stretch_resident(self._h, _ptr(at), _ptr(vt), len(at), int(bool(no_pitch_correction)),
+                                              _ptr(out), n, _ptr(fac)))
+    ch = self._channels.get(SIDE_VIDEO, 2)
+    return out.reshape(-1)[:n * ch].reshape(n, ch), fac[:ch]
+
+  def stretch_schedules(self):
+    """Jump schedules [(input index, signed distance)] of the stretched intervals of the last call."""
+    n = C.c_int64(0)
+    self._check(self._lib.da_stretch_schedule(self._h, -1, None, C.byref(n)))
+    out = []
+    for k in range(n.value):
+      m = C.c_int64(0)
+      rc = self._lib.da_stretch_schedule(self._h, k, None, C.byref(m))
+      if rc not in (0, ERR_CAPACITY):
+        self._check(rc)
+      buf = np.empty((max(m.value, 1), 2), dtype=np.int64)
+      cap = C.c_int64(m.value)
+      self._check(self._lib.da_stretch_schedule(self._h, k, _ptr(buf), C.byref(cap)))
+      out.append(buf[:cap.value].copy())
+    return out
 
   def stats(self) -> dict:
     s = Stats()

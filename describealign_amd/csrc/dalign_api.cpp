@@ -3,6 +3,7 @@
 // between the kernels.  Compiled with hipcc for gfx950; there is no CPU compute backend.
 #include "../../include/dalign.h"
 #include "dalign_common.h"
+#include "dalign_stretch.h"
 
 #include <algorithm>
 #include <chrono>
@@ -74,6 +75,9 @@ struct da_ctx {
   std::vector<int32_t> h_vlist, h_alist;
   MatchArgs last_match{};
   da_stats_t st{};
+  // audio replacement (--stretch_audio)
+  da::StretchState* stretch = nullptr;
+  DevBuf st_video, st_audio, st_out;
 };
 
 namespace {
@@ -131,7 +135,7 @@ void build_tables(FeatTables& T) {
 
 extern "C" {
 
-int da_abi_version(void) { return 1; }
+int da_abi_version(void) { return 2; }
 
 const char* da_last_error(const da_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -180,6 +184,8 @@ void da_destroy(da_ctx* c) {
                    &c->q0, &c->q1, &c->sort_tmp, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
                    &c->band_y, &c->band_q, &c->band_part};
   for (DevBuf* b : all) b->release();
+  c->st_video.release(); c->st_audio.release(); c->st_out.release();
+  da::stretch_destroy(c->stretch); c->stretch = nullptr;
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (hipEvent_t e : {c->gemm_e0, c->gemm_e1, c->prep_e0, c->prep_e1}) if (e) (void)hipEventDestroy(e);
@@ -766,5 +772,102 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
   if (rows_out > capacity) return fail(c, DA_ERR_CAPACITY, "da_refine: %lld rows exceed capacity %lld", (long long)rows_out, (long long)capacity);
   if (rows_out && !path) return fail(c, DA_ERR_ARG, "da_refine: null path");
   std::memcpy(path, out.data(), sizeof(double) * out.size());
+  return DA_OK;
+}
+
+
+// ------------------------------------------------------------------------ audio replacement
+namespace {
+
+void stretch_stats(da_ctx* c, const da::StretchTimes& t) {
+  c->st.resample_ms = t.resample_ms; c->st.resample_points = t.resample_points; c->st.resample_bytes = t.resample_bytes;
+  c->st.correlate_ms = t.correlate_ms; c->st.correlate_windows = t.correlate_windows;
+  c->st.viterbi_ms = t.viterbi_ms; c->st.splice_ms = t.splice_ms; c->st.splice_points = t.splice_points;
+}
+
+int check_nodes(da_ctx* c, const double* at, const double* vt, int n_nodes, const char* who) {
+  if (!at || !vt || n_nodes < 2) return fail(c, DA_ERR_ARG, "%s: need at least two nodes", who);
+  return DA_OK;
+}
+
+}  // namespace
+
+extern "C" int da_replace_segments(da_ctx* c, uint16_t* video, int64_t n_video, const uint16_t* audio, int64_t n_audio,
+                                   int channels, const double* audio_times, const double* video_times, int n_nodes,
+                                   int no_pitch_correction) {
+  if (!c) return DA_ERR_ARG;
+  if (!video || !audio || n_video <= 0 || n_audio <= 0 || (channels != 1 && channels != 2))
+    return fail(c, DA_ERR_ARG, "da_replace_segments: bad argument");
+  if (int rc = check_nodes(c, audio_times, video_times, n_nodes, "da_replace_segments")) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->stretch) c->stretch = da::stretch_create();
+  const size_t vb = sizeof(uint16_t) * (size_t)n_video * channels, ab = sizeof(uint16_t) * (size_t)n_audio * channels;
+  HIP_TRY(c, c->st_video.ensure(vb)); HIP_TRY(c, c->st_audio.ensure(ab));
+  HIP_TRY(c, hipMemcpyAsync(c->st_video.p, video, vb, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->st_audio.p, audio, ab, hipMemcpyHostToDevice, c->stream));
+  da::StretchTimes t;
+  std::string err;
+  const int rc = da::stretch_replace(c->stretch, c->stream, c->st_video.as<uint16_t>(), n_video, c->st_audio.as<uint16_t>(),
+                                     n_audio, channels, audio_times, video_times, n_nodes, no_pitch_correction != 0, t, err);
+  if (rc) { (void)hipStreamSynchronize(c->stream); return fail(c, rc, "%s", err.c_str()); }
+  stretch_stats(c, t);
+  HIP_TRY(c, hipMemcpyAsync(video, c->st_video.p, vb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return DA_OK;
+}
+
+extern "C" int da_stretch_resident(da_ctx* c, const double* audio_times, const double* video_times, int n_nodes,
+                                   int no_pitch_correction, int16_t* out, int64_t out_capacity_frames, double* factors) {
+  if (!c) return DA_ERR_ARG;
+  if (int rc = check_nodes(c, audio_times, video_times, n_nodes, "da_stretch_resident")) return rc;
+  Side& sv = c->side[DA_SIDE_VIDEO];
+  Side& sa = c->side[DA_SIDE_AUDIO];
+  if (sv.channels == 0 || sa.channels == 0) return fail(c, DA_ERR_STATE, "da_stretch_resident: upload PCM for both sides first");
+  if (sv.channels != sa.channels) return fail(c, DA_ERR_ARG, "da_stretch_resident: channel counts differ (%d vs %d)", sv.channels, sa.channels);
+  if (!out || out_capacity_frames < sv.n) return fail(c, DA_ERR_CAPACITY, "da_stretch_resident: output needs %lld frames", (long long)sv.n);
+  if (sv.n <= 0 || sa.n <= 0) return fail(c, DA_ERR_ARG, "da_stretch_resident: empty PCM");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->stretch) c->stretch = da::stretch_create();
+  const int C = sv.channels;
+  HIP_TRY(c, c->st_video.ensure(sizeof(uint16_t) * (size_t)sv.n * C));
+  HIP_TRY(c, c->st_audio.ensure(sizeof(uint16_t) * (size_t)sa.n * C));
+  HIP_TRY(c, c->st_out.ensure(sizeof(int16_t) * (size_t)sv.n * C));
+  std::string err;
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  if (da::stretch_load_pcm(c->stream, sv.pcm.as<int16_t>(), sv.n, C, sv.planar, c->st_video.as<uint16_t>()) ||
+      da::stretch_load_pcm(c->stream, sa.pcm.as<int16_t>(), sa.n, C, sa.planar, c->st_audio.as<uint16_t>()))
+    return fail(c, DA_ERR_DEVICE, "da_stretch_resident: PCM conversion launch failed");
+  double f[2] = {0, 0};
+  int rc = da::stretch_match_loudness(c->stretch, c->stream, c->st_video.as<uint16_t>(), sv.n, c->st_audio.as<uint16_t>(),
+                                      sa.n, C, f, err);
+  if (rc) return fail(c, rc, "%s", err.c_str());
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  if (factors) for (int k = 0; k < C; ++k) factors[k] = f[k];
+  da::StretchTimes t;
+  rc = da::stretch_replace(c->stretch, c->stream, c->st_video.as<uint16_t>(), sv.n, c->st_audio.as<uint16_t>(), sa.n, C,
+                           audio_times, video_times, n_nodes, no_pitch_correction != 0, t, err);
+  if (rc) { (void)hipStreamSynchronize(c->stream); return fail(c, rc, "%s", err.c_str()); }
+  stretch_stats(c, t);
+  float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.stretch_prepare_ms = ms;
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  rc = da::stretch_finish(c->stretch, c->stream, c->st_video.as<uint16_t>(), sv.n, C, c->st_out.as<int16_t>(), err);
+  if (rc) return fail(c, rc, "%s", err.c_str());
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out, c->st_out.p, sizeof(int16_t) * (size_t)sv.n * C, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.stretch_finish_ms = ms;
+  return DA_OK;
+}
+
+extern "C" int da_stretch_schedule(da_ctx* c, int k, int64_t* pairs, int64_t* n) {
+  if (!c || !n) return DA_ERR_ARG;
+  const int count = da::stretch_schedule_count(c->stretch);
+  if (k == -1) { *n = count; return DA_OK; }
+  const std::vector<int64_t>* s = da::stretch_schedule(c->stretch, k);
+  if (!s) return fail(c, DA_ERR_ARG, "da_stretch_schedule: interval %d of %d", k, count);
+  const int64_t need = (int64_t)s->size() / 2;
+  if (*n < need || (need && !pairs)) { *n = need; return fail(c, DA_ERR_CAPACITY, "da_stretch_schedule: %lld pairs", (long long)need); }
+  if (need) std::memcpy(pairs, s->data(), sizeof(int64_t) * s->size());
+  *n = need;
   return DA_OK;
 }

@@ -1,0 +1,865 @@
+// Audio replacement path (--stretch_audio) for gfx950: describealign.py:230-416, :1135-1153.
+//
+//   resampling   k_spline_solve  one thread per (1e5-point block, channel): Thomas solve of the
+//                                quadratic-spline collocation system (scipy make_interp_spline k=2)
+//                k_spline_eval   one thread per output sample: de Boor basis x 3 coefficients
+//   stretching   k_chunk_rms     thread per chunk of 50 windows: sliding 512-sums of the power,
+//                                epsilon = 1e-4 max(1, max), rms                     (:272-279)
+//                k_lag_table     thread per (chunk, lag): lag products, sliding 512-sums in the
+//                                reference's summation order, Pearson correlation, arg-max per
+//                                window                                              (:280-296, :321-322)
+//                k_viterbi       one workgroup per stretched interval: (window, drift) Viterbi with
+//                                the 3 x 3073 cost history in LDS, back-pointers in HBM, then the
+//                                back-track and the copy plan                       (:311-368)
+//                k_splice        one thread per output sample: run copy + Hann cross-fades (:369-385)
+//   bracket      k_moments / k_scale (:1135-1148), k_absmax / k_finish (:1153, :136)
+//
+// All of it is HBM/latency-bound byte and fp64 work; nothing here is GEMM-shaped.
+#include "dalign_stretch.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/dalign.h"
+
+namespace da {
+
+namespace {
+
+constexpr int kSW = 512;                  // window_size                     (:251, :298)
+constexpr int kMaxDrift = 3 * kSW;        // max_drift                       (:298)
+constexpr int kND = 2 * kMaxDrift + 1;    // drift_window_size = 3073        (:299)
+constexpr int kCached = 50;               // max_cached_chunks               (:254)
+constexpr int kResChunk = 100000;         // chunk_size                      (:234)
+constexpr int kMinOffset = 30;            // MIN_STRETCH_OFFSET              (:36)
+constexpr int kRate = 44100;              // AUDIO_SAMPLE_RATE               (:31)
+constexpr int kMaxLags = 512;
+
+typedef _Float16 half_t;
+
+// float64 -> float16 with a single rounding (numpy's astype does the same): round to odd in
+// float32 first, then the hardware's round-to-nearest-even float32 -> float16.
+__device__ __forceinline__ half_t to_half(double x) {
+  float f = (float)x;
+  const double back = (double)f;
+  if (back != x && fabsf(f) != INFINITY) {
+    uint32_t u = __float_as_uint(f);
+    if (fabs(back) > fabs(x)) u -= 1u;
+    u |= 1u;
+    f = __uint_as_float(u);
+  }
+  return (half_t)f;
+}
+
+struct DBuf {
+  void* p = nullptr; size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    const size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    cap = want; return hipSuccess;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ------------------------------------------------------------------------------------ bracket
+
+__global__ void k_i16_to_f16(const int16_t* __restrict__ pcm, int64_t n, int channels, int64_t stride_c,
+                             int64_t stride_n, half_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int c = 0; c < channels; ++c) out[(int64_t)c * n + i] = (half_t)(float)pcm[c * stride_c + i * stride_n];   // (:156)
+}
+
+// per block: sum(x) over all channels and sum(x^2) per channel, float64 (:1137-1139)
+__global__ void __launch_bounds__(256) k_moments(const half_t* __restrict__ x, int64_t n, int channels,
+                                                 double* __restrict__ partials /* [blocks][3] */) {
+  double s = 0, q0 = 0, q1 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double a = (double)x[i];
+    s += a; q0 += a * a;
+    if (channels == 2) { const double b = (double)x[n + i]; s += b; q1 += b * b; }
+  }
+  __shared__ double red[3][256];
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = q0; red[2][threadIdx.x] = q1;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w)
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 3; ++k) partials[3 * blockIdx.x + k] = red[k][0];
+}
+
+// x = float16(float64(x) / f) or float16(float64(x) * f)  (:1144-1148: float16 array op float64 scalar)
+__global__ void k_scale(half_t* __restrict__ x, int64_t n, double f, int divide) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double a = (double)x[i];
+  x[i] = to_half(divide ? a / f : a * f);
+}
+
+__global__ void __launch_bounds__(256) k_absmax(const half_t* __restrict__ x, int64_t n, unsigned int* __restrict__ out) {
+  unsigned int m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned short b = reinterpret_cast<const unsigned short*>(x)[i] & 0x7fffu;    // |x| as ordered bits
+    m = m > b ? m : b;
+  }
+  __shared__ unsigned int red[256];
+  red[threadIdx.x] = m; __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + w] ? red[threadIdx.x] : red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMax(out, red[0]);
+}
+
+// (:1153) video *= float16(32766 / max|video|) in float16 arithmetic, then (:136) int16, interleaved
+__global__ void k_finish(const half_t* __restrict__ x, int64_t n, int channels, const unsigned int* __restrict__ peak_bits,
+                         int16_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned short pb = (unsigned short)*peak_bits;
+  const half_t peak = *reinterpret_cast<const half_t*>(&pb);
+  const half_t top = (half_t)32766.0f;                                  // 32768 in float16
+  const half_t gain = (half_t)((float)top / (float)peak);
+  for (int c = 0; c < channels; ++c) {
+    const half_t v = (half_t)((float)x[(int64_t)c * n + i] * (float)gain);
+    // numpy's float16 -> int16 cast goes through int32 and wraps: the reference's own peak sample
+    // (32768 after the float16 rescale) comes out as -32768; same here
+    const int32_t wide = (int32_t)(float)v;
+    out[i * channels + c] = (int16_t)(wide & 0xffff);
+  }
+}
+
+// ------------------------------------------------------------------------------------ resampling
+
+struct ResChunk {          // one block of <= 1e5 output points of one resampled interval (:234-243)
+  int64_t out_abs;         // absolute video sample index of its first point
+  int64_t first;           // index of its first point within the interval (k of the linspace)
+  int32_t count;           // points in the block
+  int32_t n;               // the spline runs through audio samples [b0, b0 + n)
+  int64_t b0;
+  int64_t coef_off;        // offset in doubles of its coefficients [channel][n]
+  double start, step;      // np.linspace(x0, x1, num, endpoint=False): p_k = k * step + start
+};
+
+// knot j (0 .. n+2) of make_interp_spline(k=2) through x = b0 .. b0+n-1: end points tripled,
+// mid-points in between with the first and last mid-point removed.
+__device__ __forceinline__ double knot(int64_t j, int32_t n, int64_t b0) {
+  if (j <= 2) return (double)b0;
+  if (j >= n) return (double)(b0 + n - 1);
+  return (double)(b0 + j - 3) + 1.5;
+}
+
+__device__ __forceinline__ int32_t knot_interval(double x, int32_t n, int64_t b0) {
+  const double u = x - (double)b0;
+  if (u < 1.5) return 2;
+  const int64_t e = (int64_t)floor(u - 1.5) + 3;
+  return (int32_t)(e < n - 1 ? e : n - 1);
+}
+
+// de Boor's recurrence for the three quadratic B-splines that are non-zero on knot interval ell
+__device__ __forceinline__ void basis3(double x, int32_t ell, int32_t n, int64_t b0, double (&h)[3]) {
+  h[0] = 1.0; h[1] = 0.0; h[2] = 0.0;
+#pragma unroll
+  for (int j = 1; j <= 2; ++j) {
+    double hh0 = h[0], hh1 = h[1];
+    h[0] = 0.0;
+#pragma unroll
+    for (int m = 1; m <= j; ++m) {
+      const double xb = knot(ell + m, n, b0), xa = knot(ell + m - j, n, b0);
+      if (xb == xa) { h[m] = 0.0; continue; }
+      const double w = (m == 1 ? hh0 : hh1) / (xb - xa);
+      h[m - 1] = h[m - 1] + w * (xb - x);
+      h[m] = w * (x - xa);
+    }
+  }
+}
+
+// collocation row i: the spline basis at x = b0 + i restricted to columns i-1, i, i+1
+__device__ __forceinline__ void colloc_row(int32_t i, int32_t n, int64_t b0, double& lo, double& di, double& up) {
+  if (i >= 3 && i < n - 3) { lo = 0.125; di = 0.75; up = 0.125; return; }
+  const double x = (double)(b0 + i);
+  const int32_t ell = knot_interval(x, n, b0);
+  double h[3]; basis3(x, ell, n, b0, h);
+  lo = di = up = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int32_t col = ell - 2 + a;
+    if (col == i - 1) lo = h[a]; else if (col == i) di = h[a]; else if (col == i + 1) up = h[a];
+  }
+}
+
+constexpr int kFront = 24;     // rows after which the eliminated super-diagonal has reached its fixed point
+
+__global__ void __launch_bounds__(64) k_spline_solve(const ResChunk* __restrict__ chunks, int n_chunks, int channels,
+                                                     const half_t* __restrict__ audio, int64_t n_audio,
+                                                     double* __restrict__ coef) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_chunks * channels) return;
+  const ResChunk ck = chunks[t / channels];
+  const int ch = t % channels;
+  const int32_t n = ck.n;
+  const half_t* y = audio + (int64_t)ch * n_audio + ck.b0;
+  double* c = coef + ck.coef_off + (int64_t)ch * n;
+  // forward elimination; rows kFront .. n-4 are identical, so their pivot is computed once
+  double cp_front[kFront];
+  double tail[3] = {0.0, 0.0, 0.0};              // pivots of the last three rows
+  double cp = 0.0, dp = 0.0, cp_mid = 0.0, w_mid = 0.0;
+  for (int32_t i = 0; i < n; ++i) {
+    double w;
+    if (i >= kFront && i < n - 3) {
+      w = w_mid; cp = cp_mid;
+      dp = ((double)y[i] - 0.125 * dp) * w;
+    } else {
+      double lo, di, up; colloc_row(i, n, ck.b0, lo, di, up);
+      w = 1.0 / (di - lo * cp);
+      dp = ((double)y[i] - lo * dp) * w;
+      cp = up * w;
+      if (i < kFront) cp_front[i] = cp;
+      if (i >= n - 3) tail[i - (n - 3)] = cp;
+      if (i == kFront - 1) { cp_mid = 0.125 / (0.75 - 0.125 * cp); w_mid = 1.0 / (0.75 - 0.125 * cp); }
+    }
+    c[i] = dp;
+  }
+  // back substitution
+  double next = c[n - 1];
+  for (int32_t i = n - 2; i >= 0; --i) {
+    double p;
+    if (i >= n - 3) p = tail[i - (n - 3)];
+    else if (i < kFront) p = cp_front[i];
+    else p = cp_mid;
+    next = c[i] - p * next;
+    c[i] = next;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_spline_eval(const ResChunk* __restrict__ chunks, int channels,
+                                                     const double* __restrict__ coef, half_t* __restrict__ video,
+                                                     int64_t n_video) {
+  const ResChunk ck = chunks[blockIdx.y];
+  const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= ck.count) return;
+  const double x = (double)(ck.first + k) * ck.step + ck.start;         // y = arange * step; y += start
+  const bool inside = !(x < (double)ck.b0) && !(x > (double)(ck.b0 + ck.n - 1));
+  int32_t ell = 2; double h[3] = {0, 0, 0};
+  if (inside) { ell = knot_interval(x, ck.n, ck.b0); basis3(x, ell, ck.n, ck.b0, h); }
+  for (int ch = 0; ch < channels; ++ch) {
+    double v = 0.0;
+    if (inside) {
+      const double* c = coef + ck.coef_off + (int64_t)ch * ck.n + (ell - 2);
+      v = h[0] * c[0];
+      v = v + h[1] * c[1];
+      v = v + h[2] * c[2];
+    }
+    video[(int64_t)ch * n_video + ck.out_abs + k] = to_half(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------ stretching
+
+// The reference forms every sliding 512-sum as a difference of one float64 running sum over the
+// chunk (np.cumsum, strictly sequential; :275-277, :283-284).  In quiet passages that running sum
+// absorbs small products entirely, correlations come out as exactly 1.0 and np.argmax picks the
+// first of many ties -- so the jump positions depend on the rounding of that particular sum.
+// These kernels therefore keep the reference's order of operations: one thread walks one chunk
+// sequentially with two running sums 512 elements apart (cs[p+511] and cs[p-1], both accumulated
+// in the same order as the reference's single sum, hence bit-identical to it).  Parallelism is
+// over (chunk, lag): 10-482 lags x one chunk per 25 088 samples.
+
+struct CorrChunk {            // a chunk of <= 57 windows (:253-270)
+  int64_t begin, end;         // samples of the interval it is computed from
+  int64_t rms_off;            // offset of its rms[0 .. end-begin-511) in the rms array
+  int32_t w_lo, w_hi;         // local windows it hands out
+};
+
+__device__ __forceinline__ float power_at(const half_t* __restrict__ s, int64_t t, int channels, int64_t ch_stride) {
+  const float a = (float)s[t];
+  float r = a * a;
+  if (channels == 2) { const float b = (float)s[ch_stride + t]; r = r + b * b; }
+  return r;
+}
+
+// thread per chunk: rms[p] = sqrt(E[p] + eps), E[p] = sum_{k<512} power[p+k], eps = 1e-4 max(1, max E)  (:272-279)
+__global__ void __launch_bounds__(64) k_chunk_rms(const half_t* __restrict__ seg, int channels, int64_t ch_stride,
+                                                  const CorrChunk* __restrict__ chunks, int n_chunks,
+                                                  double* __restrict__ rms_all, double* __restrict__ eps_all) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_chunks) return;
+  const CorrChunk ck = chunks[c];
+  const half_t* s = seg + ck.begin;
+  const int64_t P = ck.end - ck.begin - kSW + 1;
+  double* rms = rms_all + ck.rms_off;
+  double hi = 0.0, lo = 0.0, mx = 0.0;
+  for (int t = 0; t < kSW - 1; ++t) hi += (double)power_at(s, t, channels, ch_stride);
+  for (int64_t p = 0; p < P; ++p) {
+    hi += (double)power_at(s, p + kSW - 1, channels, ch_stride);
+    const double e = p ? hi - lo : hi;
+    rms[p] = e;
+    mx = e > mx ? e : mx;
+    lo += (double)power_at(s, p, channels, ch_stride);
+  }
+  const double eps = 1e-4 * (mx > 1.0 ? mx : 1.0);
+  eps_all[c] = eps;
+  for (int64_t p = 0; p < P; ++p) rms[p] = sqrt(rms[p] + eps);
+}
+
+struct JumpArgs {
+  const half_t* seg; int channels; int64_t ch_stride;
+  const double* rms; const CorrChunk* chunks; const double* eps; int n_chunks;
+  const int32_t* lags; int n_lags; int backwards;
+  int64_t n_windows;
+  int16_t* where; double* loss;                 // [n_windows][n_lags]
+};
+
+__global__ void k_fill_table(int16_t* __restrict__ where, double* __restrict__ loss, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { where[i] = 0; loss[i] = INFINITY; }        // np.argmax of an all -inf column is 0, its loss 1 - (-inf)
+}
+
+__device__ __forceinline__ float lag_product(const half_t* __restrict__ s, int64_t t, int lag, int channels, int64_t ch_stride) {
+  float r = (float)s[t + lag] * (float)s[t];
+  if (channels == 2) r = r + (float)s[ch_stride + t + lag] * (float)s[ch_stride + t];
+  return r;
+}
+
+// thread per (chunk, lag): Pearson correlation of the window at q with the window at q + lag for
+// every q of the chunk, arg-max and 1 - max per 512-position window (:280-296, :321-322).
+__global__ void __launch_bounds__(64) k_lag_table(const JumpArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.n_chunks * a.n_lags) return;
+  const int c = t / a.n_lags, j = t % a.n_lags;
+  const CorrChunk ck = a.chunks[c];
+  const int lag = a.lags[j];
+  const double eps = a.eps[c];
+  const half_t* s = a.seg + ck.begin;
+  const double* rms = a.rms + ck.rms_off;
+  const int64_t P = ck.end - ck.begin - kSW + 1;
+  const int64_t Q = P - lag;                               // window starts q with q + lag still inside
+  if (Q <= 0) return;
+  const int64_t w0 = ck.begin / kSW;
+  double hi = 0.0, lo = 0.0;
+  for (int u = 0; u < kSW - 1; ++u) hi += (double)lag_product(s, u, lag, a.channels, a.ch_stride);
+  int64_t cur_w = -1; double best = -INFINITY; int best_u = 0;
+  auto flush = [&]() {
+    if (cur_w >= ck.w_lo && cur_w < ck.w_hi && w0 + cur_w < a.n_windows && best != -INFINITY) {
+      a.where[(w0 + cur_w) * a.n_lags + j] = (int16_t)best_u;
+      a.loss[(w0 + cur_w) * a.n_lags + j] = 1.0 - best;
+    }
+  };
+  for (int64_t q = 0; q < Q; ++q) {
+    hi += (double)lag_product(s, q + kSW - 1, lag, a.channels, a.ch_stride);
+    const double dots = (q ? hi - lo : hi) + eps;
+    lo += (double)lag_product(s, q, lag, a.channels, a.ch_stride);
+    const int64_t p = a.backwards ? q + lag : q;          // row of the reference's matrix this value lands in
+    const double first = a.backwards ? rms[q] : rms[q + lag];
+    const double corr = (dots / first) / rms[p];
+    const int64_t w = p / kSW;
+    if (w != cur_w) { flush(); cur_w = w; best = -INFINITY; best_u = 0; }
+    if (corr > best) { best = corr; best_u = (int)(p - w * kSW); }
+  }
+  flush();
+}
+
+struct SegDesc {             // one stretched interval
+  int64_t n_in, n_out, total, n_windows;
+  int n_lags, lag_off;
+  int64_t table_off;         // offset into where/loss  (n_windows * n_lags entries)
+  int64_t back_off;          // offset into the back-pointer array (n_windows * 3073 entries)
+  int64_t plan_off;          // offset into the copy plan arrays (n_windows + 2 entries)
+};
+
+__device__ __forceinline__ int64_t floordiv(int64_t a, int64_t b) {     // Python's // for b > 0
+  int64_t q = a / b;
+  if ((a % b != 0) && (a < 0)) --q;
+  return q;
+}
+__device__ __forceinline__ int64_t offset_at(int64_t total, int64_t nw, int64_t w) {       // (:310-311)
+  const int64_t c = w < 0 ? 0 : (w > nw - 1 ? nw - 1 : w);
+  return floordiv(total * c, nw - 1);
+}
+__device__ __forceinline__ int64_t offset_step(int64_t total, int64_t nw, int64_t w) {     // (:316-317)
+  const int64_t d = offset_at(total, nw, w) - offset_at(total, nw, w - 1);
+  return d < 0 ? -d : d;
+}
+
+// One workgroup per stretched interval.  LDS: cost history [3][3073] f64, loss row, lags.
+__global__ void __launch_bounds__(1024) k_viterbi(const SegDesc* __restrict__ segs, const int32_t* __restrict__ lags_all,
+                                                  const int16_t* __restrict__ where_all, const double* __restrict__ loss_all,
+                                                  int16_t* __restrict__ back_all, int64_t* __restrict__ plan_in,
+                                                  int64_t* __restrict__ plan_out, int64_t* __restrict__ sched,
+                                                  int32_t* __restrict__ counts) {
+  extern __shared__ double lds[];
+  double* hist = lds;                          // [3][kND]
+  double* lrow = lds + 3 * kND;                // [kMaxLags]
+  int32_t* lags = reinterpret_cast<int32_t*>(lrow + kMaxLags);   // [kMaxLags]
+  const SegDesc sd = segs[blockIdx.x];
+  const int J = sd.n_lags;
+  const int64_t nw = sd.n_windows;
+  const double* loss = loss_all + sd.table_off;
+  const int16_t* where = where_all + sd.table_off;
+  int16_t* back = back_all + sd.back_off;
+  for (int d = threadIdx.x; d < 3 * kND; d += blockDim.x) hist[d] = INFINITY;
+  for (int k = threadIdx.x; k < J; k += blockDim.x) lags[k] = lags_all[sd.lag_off + k];
+  __syncthreads();
+  if (threadIdx.x == 0) { hist[1 * kND + kMaxDrift] = 0.0; hist[2 * kND + kMaxDrift] = 0.0; }      // (:320)
+  int64_t prev_step = 0;
+  for (int64_t w = 0; w < nw; ++w) {
+    for (int k = threadIdx.x; k < J; k += blockDim.x) lrow[k] = loss[w * J + k];
+    __syncthreads();
+    const int64_t step = offset_step(sd.total, nw, w);
+    const int64_t two = step + prev_step;
+    const double* h1 = hist + ((w + 2) % 3) * kND;       // (w-1) % 3
+    const double* h2 = hist + ((w + 1) % 3) * kND;       // (w-2) % 3
+    double* hw = hist + (w % 3) * kND;
+    for (int d = threadIdx.x; d < kND; d += blockDim.x) {
+      double best = (d < kND - step) ? h1[d + step] : INFINITY;            // no jump (:333-334)
+      int pick = 0;
+      for (int k = 0; k < J; ++k) {
+        const int lag = lags[k];
+        const int64_t cut = two - lag;
+        if (d >= lag && d < kND - (cut > 0 ? cut : 0)) {                   // (:335-342)
+          const double v = h2[d - lag + two] + lrow[k];
+          if (v < best) { best = v; pick = k + 1; }
+        }
+      }
+      hw[d] = best;
+      back[w * kND + d] = (int16_t)pick;
+    }
+    prev_step = step;
+    __syncthreads();
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  // back-track (:346-362); the schedule is written backwards into sched, then reversed in place
+  int64_t* sc = sched + 2 * sd.plan_off;
+  int64_t drift = kMaxDrift;
+  int32_t K = 0;
+  bool skip = false, bad = false;
+  for (int64_t w = nw - 1; w >= 0; --w) {
+    drift += offset_step(sd.total, nw, w + 1);
+    if (skip) { skip = false; continue; }
+    if (drift < 0 || drift >= kND) { bad = true; break; }
+    const int k = (int)back[w * kND + drift] - 1;
+    if (k < 0) continue;
+    const int lag = lags[k];
+    sc[2 * K] = w * kSW + (int64_t)where[w * J + k];
+    sc[2 * K + 1] = sd.total > 0 ? -(int64_t)lag : (int64_t)lag;          // (:366-367)
+    drift -= lag;
+    skip = true;
+    ++K;
+  }
+  for (int32_t i = 0; i < K / 2; ++i) {
+    const int32_t o = K - 1 - i;
+    const int64_t a0 = sc[2 * i], a1 = sc[2 * i + 1];
+    sc[2 * i] = sc[2 * o]; sc[2 * i + 1] = sc[2 * o + 1];
+    sc[2 * o] = a0; sc[2 * o + 1] = a1;
+  }
+  // copy plan (:370-376): run m copies input [in[m], ...) to output [out[m], out[m+1])
+  int64_t* pin = plan_in + sd.plan_off;
+  int64_t* pout = plan_out + sd.plan_off;
+  int64_t start = 0, ostart = 0;
+  for (int32_t m = 0; m <= K; ++m) {
+    const int64_t end = m < K ? sc[2 * m] : sd.n_in;
+    pin[m] = start; pout[m] = ostart;
+    ostart += end - start;
+    if (m < K) start = sc[2 * m] + sc[2 * m + 1];
+  }
+  pout[K + 1] = ostart;
+  counts[2 * blockIdx.x] = K;
+  counts[2 * blockIdx.x + 1] = bad ? 1 : 0;
+}
+
+struct SpliceArgs {
+  const half_t* seg; int64_t n_in; int64_t in_stride;      // audio + x0, channel stride
+  half_t* out; int64_t n_out; int64_t out_stride;          // video + y0
+  int channels;
+  const int64_t* pin; const int64_t* pout; const int32_t* count;   // copy plan of this interval
+  const double* rise; const double* fall;                  // hann(1025)[:512], [512:1024]
+};
+
+__global__ void __launch_bounds__(256) k_splice(const SpliceArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t M = a.count[0] + 1;                        // runs
+  if (t >= a.n_out || t >= a.pout[M]) return;
+  int32_t lo = 0, hi = M - 1;                              // largest m with pout[m] <= t
+  while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (a.pout[mid] <= t) lo = mid; else hi = mid - 1; }
+  const int32_t m = lo;
+  const int64_t u = t - a.pout[m];
+  for (int ch = 0; ch < a.channels; ++ch) {
+    const half_t* s = a.seg + (int64_t)ch * a.in_stride;
+    half_t val;
+    if (u >= kSW) {
+      const int64_t src = a.pin[m] + u;                    // out[oa+W : ob+W] = seg[a+W : b+W]   (:385)
+      if (src >= a.n_in) continue;
+      val = s[src];
+    } else {
+      // the 512 samples after a jump: what the previous run left there, faded out, plus this run faded in
+      int32_t m0 = m;
+      while (m0 > 0 && t - a.pout[m0 - 1] < kSW) --m0;
+      const int64_t bsrc = m0 == 0 ? t : a.pin[m0 - 1] + (t - a.pout[m0 - 1]);
+      half_t acc = bsrc < a.n_in ? s[bsrc] : (half_t)0.0f;
+      for (int32_t mm = m0; mm <= m; ++mm) {
+        const int64_t uu = t - a.pout[mm];
+        const int64_t src = a.pin[mm] + uu;
+        acc = to_half((double)acc * a.fall[uu]);                                             // (:383)
+        const double add = (src < a.n_in ? (double)s[src] : 0.0) * a.rise[uu];
+        acc = to_half((double)acc + add);                                                    // (:384)
+      }
+      val = acc;
+    }
+    a.out[(int64_t)ch * a.out_stride + t] = val;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ host side
+
+struct StretchState {
+  DBuf res_chunks, coef;
+  DBuf energy, corr_chunks, eps, lags, where, loss, back, segs, plan_in, plan_out, sched, counts;
+  DBuf hann, partials, peak;
+  bool hann_ready = false;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::vector<std::vector<int64_t>> schedules;       // per stretched interval: idx0, dist0, idx1, dist1, ...
+};
+
+StretchState* stretch_create() {
+  StretchState* s = new StretchState();
+  (void)hipEventCreate(&s->e0); (void)hipEventCreate(&s->e1);
+  return s;
+}
+
+void stretch_destroy(StretchState* s) {
+  if (!s) return;
+  DBuf* all[] = {&s->res_chunks, &s->coef, &s->energy, &s->corr_chunks, &s->eps, &s->lags, &s->where, &s->loss,
+                 &s->back, &s->segs, &s->plan_in, &s->plan_out, &s->sched, &s->counts, &s->hann, &s->partials, &s->peak};
+  for (DBuf* b : all) b->release();
+  if (s->e0) (void)hipEventDestroy(s->e0);
+  if (s->e1) (void)hipEventDestroy(s->e1);
+  delete s;
+}
+
+const std::vector<int64_t>* stretch_schedule(const StretchState* s, int k) {
+  if (!s || k < 0 || k >= (int)s->schedules.size()) return nullptr;
+  return &s->schedules[k];
+}
+int stretch_schedule_count(const StretchState* s) { return s ? (int)s->schedules.size() : 0; }
+
+namespace {
+
+int sfail(std::string& err, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  err = buf;
+  return code;
+}
+
+#define S_TRY(call)                                                                              \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return sfail(err, DA_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct Interval { int kind; int64_t x0, x1, y0, y1; };     // kind 0 skip, 1 resample, 2 stretch
+
+std::vector<int32_t> lag_list(int64_t total) {              // (:303-308)
+  static const int32_t base[10] = {506, 451, 284, 410, 480, 379, 308, 430, 265, 494};
+  const int64_t mag = total < 0 ? -total : total;
+  std::vector<int32_t> l;
+  if (mag >= 10000) { l.assign(base, base + 10); return l; }
+  if (mag > 1000) {
+    l.assign(base, base + 10);
+    for (int b = 0; b < 8; ++b) l.push_back(kMinOffset + (1 << b) - 1);
+    return l;
+  }
+  for (int v = kMinOffset; v < kSW; ++v) l.push_back(v);
+  return l;
+}
+
+std::vector<CorrChunk> corr_chunks(int64_t n) {             // (:253-270)
+  const double limit = (kCached + 2) * 1.1 * kSW;
+  std::vector<CorrChunk> out;
+  int64_t begin = 0, off = 0;
+  int32_t lo = 0;
+  while (true) {
+    const bool last = (double)(n - begin) <= limit;
+    CorrChunk c{};
+    c.begin = begin; c.end = last ? n : begin + (int64_t)(kCached + 1) * kSW;
+    c.rms_off = off; c.w_lo = lo; c.w_hi = last ? (int32_t)((n - begin) / kSW) : kCached;
+    off += c.end - c.begin - kSW + 1;
+    out.push_back(c);
+    if (last) return out;
+    begin += (int64_t)(kCached - 1) * kSW;
+    lo = 1;
+  }
+}
+
+float elapsed(hipEvent_t a, hipEvent_t b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+
+int ensure_hann(StretchState* s, hipStream_t stream, std::string& err) {
+  if (s->hann_ready) return 0;
+  // scipy.signal.windows.hann(1025): 0.5 + 0.5 cos(fac), fac = linspace(-pi, pi, 1025)
+  const double pi = 3.141592653589793;
+  std::vector<double> w(2 * kSW);
+  const double step = (pi - (-pi)) / (2 * kSW);
+  for (int k = 0; k < 2 * kSW; ++k) w[k] = 0.5 + 0.5 * std::cos((double)k * step + (-pi));
+  S_TRY(s->hann.ensure(sizeof(double) * 2 * kSW));
+  S_TRY(hipMemcpyAsync(s->hann.p, w.data(), sizeof(double) * 2 * kSW, hipMemcpyHostToDevice, stream));
+  S_TRY(hipStreamSynchronize(stream));
+  s->hann_ready = true;
+  return 0;
+}
+
+}  // namespace
+
+int stretch_load_pcm(hipStream_t stream, const int16_t* d_pcm, int64_t n, int channels, int planar, uint16_t* d_out) {
+  if (n <= 0) return 0;
+  const int64_t sc = planar ? n : 1, sn = planar ? 1 : channels;
+  hipLaunchKernelGGL(k_i16_to_f16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_pcm, n, channels, sc, sn,
+                     reinterpret_cast<half_t*>(d_out));
+  return hipGetLastError() == hipSuccess ? 0 : DA_ERR_DEVICE;
+}
+
+int stretch_match_loudness(StretchState* s, hipStream_t stream, uint16_t* d_video, int64_t n_video, uint16_t* d_audio,
+                           int64_t n_audio, int channels, double* factors, std::string& err) {
+  const int blocks = 1024;
+  S_TRY(s->partials.ensure(sizeof(double) * 3 * blocks * 2));
+  double* pv = s->partials.as<double>();
+  double* pa = pv + 3 * blocks;
+  hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<half_t*>(d_video), n_video, channels, pv);
+  hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<half_t*>(d_audio), n_audio, channels, pa);
+  S_TRY(hipGetLastError());
+  std::vector<double> h(3 * blocks * 2);
+  S_TRY(hipMemcpyAsync(h.data(), pv, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream));
+  S_TRY(hipStreamSynchronize(stream));
+  auto spread = [&](const double* p, int64_t n, double* out) {           // low_ram_std (:1137-1139)
+    double sum = 0, q[2] = {0, 0};
+    for (int b = 0; b < blocks; ++b) { sum += p[3 * b]; q[0] += p[3 * b + 1]; q[1] += p[3 * b + 2]; }
+    const double cnt = (double)n * channels;
+    const double avg = sum / cnt;
+    for (int c = 0; c < channels; ++c) out[c] = std::sqrt(q[c] / cnt - avg * avg);
+  };
+  double sv[2], sa[2];
+  spread(h.data(), n_video, sv); spread(h.data() + 3 * blocks, n_audio, sa);
+  for (int c = 0; c < channels; ++c) {
+    const double f = sv[c] / sa[c];
+    factors[c] = f;
+    if (f > 1) {                                                         // (:1144-1148)
+      hipLaunchKernelGGL(k_scale, dim3((unsigned)((n_video + 255) / 256)), dim3(256), 0, stream,
+                         reinterpret_cast<half_t*>(d_video) + (int64_t)c * n_video, n_video, f, 1);
+    } else {
+      hipLaunchKernelGGL(k_scale, dim3((unsigned)((n_audio + 255) / 256)), dim3(256), 0, stream,
+                         reinterpret_cast<half_t*>(d_audio) + (int64_t)c * n_audio, n_audio, f, 0);
+    }
+  }
+  S_TRY(hipGetLastError());
+  return 0;
+}
+
+int stretch_finish(StretchState* s, hipStream_t stream, uint16_t* d_video, int64_t n_video, int channels,
+                   int16_t* d_out_interleaved, std::string& err) {
+  S_TRY(s->peak.ensure(64));
+  S_TRY(hipMemsetAsync(s->peak.p, 0, 4, stream));
+  hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, stream, reinterpret_cast<half_t*>(d_video), n_video * channels,
+                     s->peak.as<unsigned int>());
+  hipLaunchKernelGGL(k_finish, dim3((unsigned)((n_video + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<half_t*>(d_video), n_video, channels, s->peak.as<unsigned int>(), d_out_interleaved);
+  S_TRY(hipGetLastError());
+  return 0;
+}
+
+int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, int64_t n_video, const uint16_t* d_audio_u,
+                    int64_t n_audio, int channels, const double* audio_times, const double* video_times, int n_nodes,
+                    bool no_pitch_correction, StretchTimes& tm, std::string& err) {
+  half_t* d_video = reinterpret_cast<half_t*>(d_video_u);
+  const half_t* d_audio = reinterpret_cast<const half_t*>(d_audio_u);
+  s->schedules.clear();
+  if (int rc = ensure_hann(s, stream, err)) return rc;
+  // ---- interval plan (:387-411)
+  std::vector<int64_t> xs(n_nodes), ys(n_nodes);
+  for (int i = 0; i < n_nodes; ++i) { xs[i] = (int64_t)(audio_times[i] * kRate); ys[i] = (int64_t)(video_times[i] * kRate); }
+  std::vector<Interval> plan;
+  for (int i = 0; i + 1 < n_nodes; ++i) {
+    const int64_t dx = xs[i + 1] - xs[i], dy = ys[i + 1] - ys[i];
+    const double slope = (double)dx / (double)dy;
+    Interval iv{0, xs[i], xs[i + 1], ys[i], ys[i + 1]};
+    if (dy < 2 * kRate || std::fabs(1 - slope) > 0.1) iv.kind = 0;
+    else if (no_pitch_correction || std::fabs(1 - slope) <= 0.005 || std::llabs(dy - dx) < kMinOffset) iv.kind = 1;
+    else iv.kind = 2;
+    if (iv.kind != 0) {
+      if (iv.y0 < 0 || iv.y1 > n_video) return sfail(err, DA_ERR_ARG, "replace: video interval [%lld, %lld) outside the %lld video samples", (long long)iv.y0, (long long)iv.y1, (long long)n_video);
+      if (iv.kind == 2 && (iv.x0 < 0 || iv.x1 > n_audio)) return sfail(err, DA_ERR_ARG, "replace: audio interval [%lld, %lld) outside the %lld audio samples", (long long)iv.x0, (long long)iv.x1, (long long)n_audio);
+    }
+    plan.push_back(iv);
+  }
+
+  // ---- resampled intervals (:233-244, :412-414)
+  {
+    std::vector<ResChunk> chunks;
+    int64_t coef_total = 0;
+    double points = 0;
+    for (const Interval& iv : plan) {
+      if (iv.kind != 1) continue;
+      const int64_t num = iv.y1 - iv.y0;
+      const double start = (double)iv.x0, step = ((double)iv.x1 - (double)iv.x0) / (double)num;
+      for (int64_t first = 0; first < num; first += kResChunk) {
+        ResChunk c{};
+        c.first = first; c.count = (int32_t)std::min<int64_t>(kResChunk, num - first);
+        c.out_abs = iv.y0 + first; c.start = start; c.step = step;
+        const double p_first = (double)first * step + start;
+        const double p_last = (double)(first + c.count - 1) * step + start;
+        const int64_t b0 = std::max<int64_t>((int64_t)(p_first - 2), 0);
+        const int64_t b1 = std::min<int64_t>((int64_t)(p_last + 2), n_audio);
+        if (b1 - b0 < 3) return sfail(err, DA_ERR_ARG, "replace: resampling interval reads outside the audio (samples %lld..%lld of %lld)", (long long)b0, (long long)b1, (long long)n_audio);
+        c.b0 = b0; c.n = (int32_t)(b1 - b0); c.coef_off = coef_total;
+        coef_total += (int64_t)c.n * channels;
+        chunks.push_back(c);
+      }
+      points += (double)num;
+    }
+    tm.resample_points = points;
+    tm.resample_bytes = points * channels * 2.0 /*written*/ + (double)coef_total * 2.0 /*read once*/;
+    if (!chunks.empty()) {
+      S_TRY(s->res_chunks.ensure(sizeof(ResChunk) * chunks.size()));
+      S_TRY(s->coef.ensure(sizeof(double) * (size_t)coef_total));
+      S_TRY(hipMemcpyAsync(s->res_chunks.p, chunks.data(), sizeof(ResChunk) * chunks.size(), hipMemcpyHostToDevice, stream));
+      S_TRY(hipEventRecord(s->e0, stream));
+      const int threads = (int)chunks.size() * channels;
+      hipLaunchKernelGGL(k_spline_solve, dim3((threads + 63) / 64), dim3(64), 0, stream, s->res_chunks.as<ResChunk>(),
+                         (int)chunks.size(), channels, d_audio, n_audio, s->coef.as<double>());
+      hipLaunchKernelGGL(k_spline_eval, dim3((kResChunk + 255) / 256, (unsigned)chunks.size()), dim3(256), 0, stream,
+                         s->res_chunks.as<ResChunk>(), channels, s->coef.as<double>(), d_video, n_video);
+      S_TRY(hipGetLastError());
+      S_TRY(hipEventRecord(s->e1, stream));
+      S_TRY(hipStreamSynchronize(stream));
+      tm.resample_ms = elapsed(s->e0, s->e1);
+    }
+  }
+
+  // ---- stretched intervals (:298-385)
+  std::vector<const Interval*> st;
+  for (const Interval& iv : plan) if (iv.kind == 2) st.push_back(&iv);
+  if (st.empty()) return 0;
+  const int NS = (int)st.size();
+  std::vector<SegDesc> segs(NS);
+  std::vector<int32_t> lags_all;
+  std::vector<std::vector<CorrChunk>> chunk_lists(NS);
+  int64_t table_total = 0, back_total = 0, plan_total = 0, energy_max = 0; size_t chunks_max = 0;
+  for (int k = 0; k < NS; ++k) {
+    const Interval& iv = *st[k];
+    SegDesc& d = segs[k];
+    d.n_in = iv.x1 - iv.x0; d.n_out = iv.y1 - iv.y0; d.total = d.n_out - d.n_in; d.n_windows = d.n_in / kSW;
+    if (d.n_in < 3 * kSW - 1 || d.n_windows < 2) return sfail(err, DA_ERR_ARG, "Invalid state in Pearson generator.");
+    const std::vector<int32_t> l = lag_list(d.total);
+    d.n_lags = (int)l.size(); d.lag_off = (int)lags_all.size();
+    lags_all.insert(lags_all.end(), l.begin(), l.end());
+    d.table_off = table_total; table_total += d.n_windows * d.n_lags;
+    d.back_off = back_total; back_total += d.n_windows * kND;
+    d.plan_off = plan_total; plan_total += d.n_windows + 2;
+    chunk_lists[k] = corr_chunks(d.n_in);
+    energy_max = std::max(energy_max, chunk_lists[k].back().rms_off + (chunk_lists[k].back().end - chunk_lists[k].back().begin));
+    chunks_max = std::max(chunks_max, chunk_lists[k].size());
+  }
+  S_TRY(s->segs.ensure(sizeof(SegDesc) * NS));
+  S_TRY(s->lags.ensure(sizeof(int32_t) * lags_all.size()));
+  S_TRY(s->where.ensure(sizeof(int16_t) * (size_t)table_total));
+  S_TRY(s->loss.ensure(sizeof(double) * (size_t)table_total));
+  S_TRY(s->back.ensure(sizeof(int16_t) * (size_t)back_total));
+  S_TRY(s->plan_in.ensure(sizeof(int64_t) * (size_t)plan_total));
+  S_TRY(s->plan_out.ensure(sizeof(int64_t) * (size_t)plan_total));
+  S_TRY(s->sched.ensure(sizeof(int64_t) * 2 * (size_t)plan_total));
+  S_TRY(s->counts.ensure(sizeof(int32_t) * 2 * NS));
+  S_TRY(s->energy.ensure(sizeof(double) * (size_t)energy_max));
+  S_TRY(s->corr_chunks.ensure(sizeof(CorrChunk) * chunks_max));
+  S_TRY(s->eps.ensure(sizeof(double) * chunks_max));
+  S_TRY(hipMemcpyAsync(s->segs.p, segs.data(), sizeof(SegDesc) * NS, hipMemcpyHostToDevice, stream));
+  S_TRY(hipMemcpyAsync(s->lags.p, lags_all.data(), sizeof(int32_t) * lags_all.size(), hipMemcpyHostToDevice, stream));
+
+  S_TRY(hipEventRecord(s->e0, stream));
+  double windows = 0, cbytes = 0;
+  hipLaunchKernelGGL(k_fill_table, dim3((unsigned)((table_total + 255) / 256)), dim3(256), 0, stream, s->where.as<int16_t>(),
+                     s->loss.as<double>(), table_total);
+  for (int k = 0; k < NS; ++k) {
+    const Interval& iv = *st[k];
+    const SegDesc& d = segs[k];
+    const half_t* seg = d_audio + iv.x0;
+    const int nc = (int)chunk_lists[k].size();
+    S_TRY(hipMemcpyAsync(s->corr_chunks.p, chunk_lists[k].data(), sizeof(CorrChunk) * nc, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_chunk_rms, dim3((nc + 63) / 64), dim3(64), 0, stream, seg, channels, n_audio,
+                       s->corr_chunks.as<CorrChunk>(), nc, s->energy.as<double>(), s->eps.as<double>());
+    JumpArgs ja{};
+    ja.seg = seg; ja.channels = channels; ja.ch_stride = n_audio;
+    ja.rms = s->energy.as<double>(); ja.chunks = s->corr_chunks.as<CorrChunk>(); ja.eps = s->eps.as<double>();
+    ja.n_chunks = nc;
+    ja.lags = s->lags.as<int32_t>() + d.lag_off; ja.n_lags = d.n_lags; ja.backwards = d.total > 0 ? 1 : 0;
+    ja.n_windows = d.n_windows;
+    ja.where = s->where.as<int16_t>() + d.table_off; ja.loss = s->loss.as<double>() + d.table_off;
+    hipLaunchKernelGGL(k_lag_table, dim3((nc * d.n_lags + 63) / 64), dim3(64), 0, stream, ja);
+    S_TRY(hipGetLastError());
+    // the chunk list / rms buffers are reused by the next interval: stream order keeps them apart
+    windows += (double)d.n_windows * d.n_lags;
+    cbytes += (double)d.n_in * channels * 2.0 * (1 + d.n_lags);
+  }
+  S_TRY(hipEventRecord(s->e1, stream));
+  S_TRY(hipStreamSynchronize(stream));
+  tm.correlate_ms = elapsed(s->e0, s->e1); tm.correlate_windows = windows; tm.correlate_bytes = cbytes;
+
+  const size_t lds_bytes = sizeof(double) * (3 * kND + kMaxLags) + sizeof(int32_t) * kMaxLags;
+  S_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_viterbi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  S_TRY(hipEventRecord(s->e0, stream));
+  hipLaunchKernelGGL(k_viterbi, dim3(NS), dim3(1024), lds_bytes, stream, s->segs.as<SegDesc>(), s->lags.as<int32_t>(),
+                     s->where.as<int16_t>(), s->loss.as<double>(), s->back.as<int16_t>(), s->plan_in.as<int64_t>(),
+                     s->plan_out.as<int64_t>(), s->sched.as<int64_t>(), s->counts.as<int32_t>());
+  S_TRY(hipGetLastError());
+  S_TRY(hipEventRecord(s->e1, stream));
+  std::vector<int32_t> counts(2 * NS);
+  S_TRY(hipMemcpyAsync(counts.data(), s->counts.p, sizeof(int32_t) * 2 * NS, hipMemcpyDeviceToHost, stream));
+  S_TRY(hipStreamSynchronize(stream));
+  tm.viterbi_ms = elapsed(s->e0, s->e1);
+  for (int k = 0; k < NS; ++k) {
+    if (counts[2 * k + 1]) return sfail(err, DA_ERR_STATE, "replace: drift left the +/-%d sample window while back-tracking interval %d", kMaxDrift, k);
+    if (counts[2 * k] == 0) return sfail(err, DA_ERR_STATE, "replace: no jump schedule found for interval %d", k);   // the reference fails indexing an empty array (:367)
+  }
+
+  S_TRY(hipEventRecord(s->e0, stream));
+  double spoints = 0;
+  for (int k = 0; k < NS; ++k) {
+    const Interval& iv = *st[k];
+    const SegDesc& d = segs[k];
+    SpliceArgs sa{};
+    sa.seg = d_audio + iv.x0; sa.n_in = d.n_in; sa.in_stride = n_audio;
+    sa.out = d_video + iv.y0; sa.n_out = d.n_out; sa.out_stride = n_video; sa.channels = channels;
+    sa.pin = s->plan_in.as<int64_t>() + d.plan_off; sa.pout = s->plan_out.as<int64_t>() + d.plan_off;
+    sa.count = s->counts.as<int32_t>() + 2 * k;
+    sa.rise = s->hann.as<double>(); sa.fall = s->hann.as<double>() + kSW;
+    hipLaunchKernelGGL(k_splice, dim3((unsigned)((d.n_out + 255) / 256)), dim3(256), 0, stream, sa);
+    spoints += (double)d.n_out;
+  }
+  S_TRY(hipGetLastError());
+  S_TRY(hipEventRecord(s->e1, stream));
+  // schedules for the caller / tests
+  s->schedules.resize(NS);
+  for (int k = 0; k < NS; ++k) {
+    s->schedules[k].resize(2 * (size_t)counts[2 * k]);
+    if (counts[2 * k])
+      S_TRY(hipMemcpyAsync(s->schedules[k].data(), s->sched.as<int64_t>() + 2 * segs[k].plan_off,
+                           sizeof(int64_t) * 2 * (size_t)counts[2 * k], hipMemcpyDeviceToHost, stream));
+  }
+  S_TRY(hipStreamSynchronize(stream));
+  tm.splice_ms = elapsed(s->e0, s->e1); tm.splice_points = spoints;
+  return 0;
+}
+
+}  // namespace da

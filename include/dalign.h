@@ -113,6 +113,33 @@ int da_refine(da_ctx* ctx, const double* a_scaled, int64_t La, const double* v_s
               const double* cl_slope, int n_clusters, double min_len,
               double* path, int64_t* n_rows, int64_t* n_points);
 
+/* ---- audio replacement (--stretch_audio) ------------------------------------------------------
+ * replace_aligned_segments (describealign.py:230-416): for every interval between consecutive
+ * nodes (audio_times[k], video_times[k]) in seconds, the video's audio is replaced by the audio
+ * description -- resampled with the chunked quadratic spline of :233-244 when the rate change is
+ * inaudible (or no_pitch_correction), otherwise stretched pitch-preservingly by the lag
+ * correlation + drift Viterbi + Hann cross-fade splice of :246-385; intervals shorter than 2 s or
+ * with |1 - rate| > 0.1 are left alone.  video / audio are IEEE float16 (C, n) planar arrays, the
+ * representation the reference holds PCM in (:156); video is updated in place. */
+int da_replace_segments(da_ctx* ctx, uint16_t* video_f16, int64_t n_video, const uint16_t* audio_f16,
+                        int64_t n_audio, int channels, const double* audio_times,
+                        const double* video_times, int n_nodes, int no_pitch_correction);
+
+/* The whole --stretch_audio block of combine() (describealign.py:1135-1153) plus the int16
+ * serialisation of :136 on the PCM resident in the two side slots (da_pcm_upload; DA_SIDE_VIDEO is
+ * the track that receives the description): loudness matching, da_replace_segments, peak
+ * normalisation to +/-32766, int16, interleaved frames as ffmpeg's s16le input wants them.
+ * out receives n_video * channels samples; factors (optional) the per-channel loudness ratios. */
+int da_stretch_resident(da_ctx* ctx, const double* audio_times, const double* video_times, int n_nodes,
+                        int no_pitch_correction, int16_t* out, int64_t out_capacity_frames,
+                        double* factors);
+
+/* Jump schedule of the k-th stretched interval of the most recent replace call: pairs
+ * (input sample index, signed jump distance) as in best_jumps (:362-367).  *n in: capacity in
+ * pairs, out: pairs.  k out of range -> DA_ERR_ARG; da_stretch_schedule(ctx, -1, NULL, n) returns
+ * the number of stretched intervals in *n. */
+int da_stretch_schedule(da_ctx* ctx, int k, int64_t* pairs, int64_t* n);
+
 /* ---- timing / roofline counters of the most recent calls ------------------------------------ */
 typedef struct da_stats_t {
   double features_ms;        /* device time of the feature kernel (HIP events), last call */
@@ -129,6 +156,17 @@ typedef struct da_stats_t {
   double refine_dp_ms;       /* host second DP */
   double refine_points;
   double h2d_ms;             /* last da_pcm_upload */
+  /* audio replacement (ABI v2) */
+  double resample_ms;        /* spline solve + evaluation kernels */
+  double resample_points;    /* output samples resampled (per channel) */
+  double resample_bytes;     /* algorithmic bytes: float16 read once + float16 written */
+  double correlate_ms;       /* window energy + lag correlation / arg-max kernels */
+  double correlate_windows;  /* (window, lag) pairs evaluated */
+  double viterbi_ms;         /* drift Viterbi + back-track */
+  double splice_ms;          /* run copy + cross-fades */
+  double splice_points;
+  double stretch_prepare_ms; /* int16 -> float16 + loudness matching (da_stretch_resident) */
+  double stretch_finish_ms;  /* peak normalisation + int16 interleave */
 } da_stats_t;
 
 int da_stats(const da_ctx* ctx, da_stats_t* out);

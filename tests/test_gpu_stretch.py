@@ -1,0 +1,145 @@
+"""Parity of the audio replacement path (--stretch_audio; describealign.py:230-416, :1135-1153)
+through the C ABI against fixtures recorded from the reference and against the oracle.
+Needs a real MI355X: run with `pytest -m gpu`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import stretch_oracle as SO
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+INDEX = json.load(open(os.path.join(GOLD, "index.json")))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+  from describealign_amd import _native
+  c = _native.Context(0, _native.PREC_F32)
+  yield c
+  c.close()
+
+
+def _bits(a):
+  return np.ascontiguousarray(a).view(np.uint16)
+
+
+def _canon(a):
+  """float16 bit patterns with -0 folded onto +0.  Inside digital silence the spline rings at
+  ~1e-20, which rounds to a zero whose sign depends on the last bit of the banded solve (LAPACK's
+  LU in scipy, a Thomas recurrence on the GPU); every other value is compared bit for bit, and
+  the int16 output of the path is identical either way."""
+  b = _bits(a).copy()
+  b[(b & 0x7fff) == 0] = 0
+  return b
+
+
+def _report(got, want, what):
+  """float16 arrays must agree bit for bit; on failure say how far apart they are."""
+  if np.array_equal(_canon(got), _canon(want)):
+    return
+  bad = np.flatnonzero((_canon(got) != _canon(want)).any(axis=0))
+  d = np.abs(got[:, bad].astype(np.float64) - want[:, bad].astype(np.float64))
+  raise AssertionError(f"{what}: {len(bad)} of {got.shape[1]} samples differ, first at {bad[:5]}, max |diff| {d.max()}")
+
+
+@pytest.mark.parametrize("name", list(cases.STRETCH_CASES))
+def test_replace_segments_matches_reference_fixture(ctx, name):
+  """Jump schedules identical, every replaced interval identical float16 bits, untouched
+  intervals untouched."""
+  g = np.load(os.path.join(GOLD, f"stretch_{name}.npz"))
+  meta = INDEX["stretch"][name]
+  v, a, x, y = cases.stretch_case_f16(name)
+  before = v.copy()
+  ctx.replace_segments(v, a, x, y, False)
+  sched = ctx.stretch_schedules()
+  assert len(sched) == meta["n_schedules"]
+  for k, s in enumerate(sched):
+    assert np.array_equal(s, g[f"sched{k}"]), f"jump schedule {k}: {s.tolist()} vs {g[f'sched{k}'].tolist()}"
+  for k, (kind, x0, x1, y0, y1) in enumerate(SO.segment_plan(x, y, False)):
+    if k in meta["replaced_intervals"]:
+      _report(v[:, y0:y1], g[f"seg{k}"].view(np.float16), f"{name} interval {k} ({kind})")
+    else:
+      assert np.array_equal(_bits(v[:, y0:y1]), _bits(before[:, y0:y1])), f"interval {k} should be untouched"
+
+
+@pytest.mark.parametrize("name", list(cases.STRETCH_CASES))
+def test_replace_segments_without_pitch_correction(ctx, name):
+  """no_pitch_correction: every kept interval is resampled.  The oracle's output for this input is
+  pinned to the reference by sha1 in tests/test_oracle_golden.py."""
+  v, a, x, y = cases.stretch_case_f16(name)
+  want = v.copy()
+  SO.replace_aligned_segments(want, a, x, y, True)
+  ctx.replace_segments(v, a, x, y, True)
+  assert ctx.stretch_schedules() == []
+  _report(v, want, name)
+
+
+@pytest.mark.parametrize("name", ["mix_stereo", "edge_mono"])
+def test_stretch_resident_matches_oracle(ctx, name):
+  """The whole --stretch_audio block from int16 PCM to int16 interleaved frames."""
+  vid, aud, x, y = cases.stretch_case(name)
+  v, a = vid.astype(np.float16), aud.astype(np.float16)
+  want_f = SO.match_loudness(v, a)
+  SO.replace_aligned_segments(v, a, x, y, False)
+  SO.normalise_peak(v)
+  want = v.astype(np.int16).T
+  ctx.pcm_upload(0, vid); ctx.pcm_upload(1, aud)
+  got, fac = ctx.stretch_resident(x, y, False)
+  np.testing.assert_allclose(fac, want_f, rtol=1e-12)
+  assert got.shape == want.shape
+  nbad = int((got != want).sum())
+  assert nbad == 0, f"{nbad} of {want.size} samples differ; max |diff| {np.abs(got.astype(int) - want.astype(int)).max()}"
+  # interleaved upload gives the same result
+  ctx.pcm_upload(0, np.ascontiguousarray(vid.T)); ctx.pcm_upload(1, np.ascontiguousarray(aud.T))
+  got2, _ = ctx.stretch_resident(x, y, False)
+  assert np.array_equal(got, got2)
+
+
+def test_resample_many_blocks_vs_oracle(ctx):
+  """A 12 s interval is 6 blocks of 1e5 points, each with its own spline end conditions."""
+  rng = np.random.default_rng(7)
+  n = 14 * 44100
+  a = (rng.standard_normal((2, n)) * 4000).astype(np.float16)
+  v = np.zeros((2, n), dtype=np.float16)
+  x = np.array([0.25, 12.28, 13.9]); y = np.array([0.5, 12.5, 13.8])
+  want = v.copy()
+  SO.replace_aligned_segments(want, a, x, y, False)
+  ctx.replace_segments(v, a, x, y, False)
+  _report(v, want, "random stereo")
+
+
+def test_stretch_random_intervals_vs_oracle(ctx):
+  """Both directions and all three lag sets on noise with silent stretches (ties in the arg-max)."""
+  rng = np.random.default_rng(11)
+  n = 20 * 44100
+  a = (rng.standard_normal((1, n)) * 3000).astype(np.float16)
+  a[:, 3 * 44100:4 * 44100] = 0                               # digital silence inside a stretched interval
+  env = np.clip(np.sin(np.arange(n) / 9000.0), 0, 1) ** 2
+  a = (a.astype(np.float32) * env.astype(np.float32)).astype(np.float16)
+  v = np.zeros((1, n), dtype=np.float16)
+  y = np.array([0.0, 6.0, 9.0, 15.5, 19.0]); x = np.array([0.1, 6.25, 9.232, 15.6, 19.12])
+  kinds = [p[0] for p in SO.segment_plan(x, y, False)]
+  assert kinds.count("stretch") >= 3, kinds
+  want = v.copy()
+  want_s = SO.replace_aligned_segments(want, a, x, y, False)
+  ctx.replace_segments(v, a, x, y, False)
+  got_s = ctx.stretch_schedules()
+  assert len(got_s) == len(want_s)
+  for k, (g_, w_) in enumerate(zip(got_s, want_s)):
+    assert np.array_equal(g_, w_), f"schedule {k}"
+  _report(v, want, "random mono")
+
+
+def test_replace_segments_errors(ctx):
+  v = np.zeros((1, 44100 * 5), dtype=np.float16); a = np.zeros((1, 44100 * 5), dtype=np.float16)
+  with pytest.raises(RuntimeError, match="outside"):
+    ctx.replace_segments(v, a, np.array([0.0, 6.03]), np.array([0.0, 6.0]), True)     # video interval past the end
+  with pytest.raises(RuntimeError, match="two nodes"):
+    ctx.replace_segments(v, a, np.array([0.0]), np.array([0.0]), False)
+  with pytest.raises(ValueError):
+    ctx.replace_segments(v.astype(np.float32), a, np.array([0.0, 3.0]), np.array([0.0, 3.0]), False)
