@@ -141,6 +141,9 @@ __global__ void k_finish(const half_t* __restrict__ x, int64_t n, int channels, 
 
 // ------------------------------------------------------------------------------------ resampling
 
+constexpr int kFront = 24;     // rows after which the eliminated super-diagonal has reached its fixed point
+constexpr int kFusedMinRows = 64;   // shorter splines take the sequential kernels, longer ones k_resample_tile
+
 struct ResChunk {          // one block of <= 1e5 output points of one resampled interval (:234-243)
   int64_t out_abs;         // absolute video sample index of its first point
   int64_t first;           // index of its first point within the interval (k of the linspace)
@@ -153,13 +156,13 @@ struct ResChunk {          // one block of <= 1e5 output points of one resampled
 
 // knot j (0 .. n+2) of make_interp_spline(k=2) through x = b0 .. b0+n-1: end points tripled,
 // mid-points in between with the first and last mid-point removed.
-__device__ __forceinline__ double knot(int64_t j, int32_t n, int64_t b0) {
+__host__ __device__ __forceinline__ double knot(int64_t j, int32_t n, int64_t b0) {
   if (j <= 2) return (double)b0;
   if (j >= n) return (double)(b0 + n - 1);
   return (double)(b0 + j - 3) + 1.5;
 }
 
-__device__ __forceinline__ int32_t knot_interval(double x, int32_t n, int64_t b0) {
+__host__ __device__ __forceinline__ int32_t knot_interval(double x, int32_t n, int64_t b0) {
   const double u = x - (double)b0;
   if (u < 1.5) return 2;
   const int64_t e = (int64_t)floor(u - 1.5) + 3;
@@ -167,7 +170,7 @@ __device__ __forceinline__ int32_t knot_interval(double x, int32_t n, int64_t b0
 }
 
 // de Boor's recurrence for the three quadratic B-splines that are non-zero on knot interval ell
-__device__ __forceinline__ void basis3(double x, int32_t ell, int32_t n, int64_t b0, double (&h)[3]) {
+__host__ __device__ __forceinline__ void basis3(double x, int32_t ell, int32_t n, int64_t b0, double (&h)[3]) {
   h[0] = 1.0; h[1] = 0.0; h[2] = 0.0;
 #pragma unroll
   for (int j = 1; j <= 2; ++j) {
@@ -185,7 +188,7 @@ __device__ __forceinline__ void basis3(double x, int32_t ell, int32_t n, int64_t
 }
 
 // collocation row i: the spline basis at x = b0 + i restricted to columns i-1, i, i+1
-__device__ __forceinline__ void colloc_row(int32_t i, int32_t n, int64_t b0, double& lo, double& di, double& up) {
+__host__ __device__ __forceinline__ void colloc_row(int32_t i, int32_t n, int64_t b0, double& lo, double& di, double& up) {
   if (i >= 3 && i < n - 3) { lo = 0.125; di = 0.75; up = 0.125; return; }
   const double x = (double)(b0 + i);
   const int32_t ell = knot_interval(x, n, b0);
@@ -198,7 +201,6 @@ __device__ __forceinline__ void colloc_row(int32_t i, int32_t n, int64_t b0, dou
   }
 }
 
-constexpr int kFront = 24;     // rows after which the eliminated super-diagonal has reached its fixed point
 
 __global__ void __launch_bounds__(64) k_spline_solve(const ResChunk* __restrict__ chunks, int n_chunks, int channels,
                                                      const half_t* __restrict__ audio, int64_t n_audio,
@@ -208,6 +210,7 @@ __global__ void __launch_bounds__(64) k_spline_solve(const ResChunk* __restrict_
   const ResChunk ck = chunks[t / channels];
   const int ch = t % channels;
   const int32_t n = ck.n;
+  if (n >= kFusedMinRows) return;                  // solved tile-wise by k_resample_tile
   const half_t* y = audio + (int64_t)ch * n_audio + ck.b0;
   double* c = coef + ck.coef_off + (int64_t)ch * n;
   // forward elimination; rows kFront .. n-4 are identical, so their pivot is computed once
@@ -247,7 +250,7 @@ __global__ void __launch_bounds__(256) k_spline_eval(const ResChunk* __restrict_
                                                      int64_t n_video) {
   const ResChunk ck = chunks[blockIdx.y];
   const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= ck.count) return;
+  if (k >= ck.count || ck.n >= kFusedMinRows) return;
   const double x = (double)(ck.first + k) * ck.step + ck.start;         // y = arange * step; y += start
   const bool inside = !(x < (double)ck.b0) && !(x > (double)(ck.b0 + ck.n - 1));
   int32_t ell = 2; double h[3] = {0, 0, 0};
@@ -264,6 +267,136 @@ __global__ void __launch_bounds__(256) k_spline_eval(const ResChunk* __restrict_
   }
 }
 
+// ---- fused tile kernel --------------------------------------------------------------------
+// The collocation matrix is (1/8, 3/4, 1/8) away from the first/last three rows, so the solution
+// at row i depends on the data at distance d with weight ~0.17^d.  A workgroup therefore solves a
+// TILE of 4096 coefficient rows independently of the rest of the block: every thread runs the
+// Thomas recurrences over its own 16 rows after a 20-row warm-up (error < 1e-15 relative; at the
+// true ends of the spline the exact boundary rows are used instead), coefficients stay in LDS, and
+// the same workgroup evaluates the output points that fall on its rows.  HBM traffic is the float16
+// samples read once and the float16 result written once.
+constexpr int kTileRows = 4096;          // coefficient rows solved per workgroup
+constexpr int kTileStep = kTileRows - 2; // consecutive tiles overlap by two rows (a point needs c[ell-2..ell])
+constexpr int kOwn = 16;                 // rows per thread
+constexpr int kWarm = 20;                // warm-up rows
+constexpr int kApron = 32;               // forward-pass rows beyond the tile (warm-up of the backward pass)
+constexpr int kMaxTiles = 27;            // ceil((1.1e5 + 4) / 4094): the rate is within +-10 % (:33)
+
+struct SplineRows {            // tabulated on the host with the same recurrences (n >= kFusedMinRows)
+  double lo_front[kFront], w_front[kFront], cp_front[kFront];
+  double lo_tail[3], w_tail[3], cp_tail[3];
+  double w_mid, cp_mid;
+};
+
+__device__ __forceinline__ int pad_y(int r) { return r + 2 * (r >> 4); }       // float16 index, conflict-free per 16-row owner
+__device__ __forceinline__ int pad_c(int r) { return r + (r >> 4); }           // float64 index
+
+__global__ void __launch_bounds__(256) k_resample_tile(const ResChunk* __restrict__ chunks, const half_t* __restrict__ audio,
+                                                       int64_t n_audio, half_t* __restrict__ video, int64_t n_video,
+                                                       const SplineRows R) {
+  const ResChunk ck = chunks[blockIdx.y];
+  const int32_t n = ck.n;
+  const int32_t R0 = (int32_t)blockIdx.x * kTileStep - 2;            // first coefficient row of the tile
+  if (n < kFusedMinRows || R0 + 2 >= n) return;
+  const int ch = blockIdx.z;
+  constexpr int kRowsY = kTileRows + kApron + kWarm;                  // rows [R0 - kWarm, R0 + 4128)
+  __shared__ half_t ys[kRowsY + 2 * (kRowsY / 16) + 8];
+  __shared__ double cs[kTileRows + kApron + (kTileRows + kApron) / 16 + 4];
+  const half_t* y = audio + (int64_t)ch * n_audio + ck.b0;
+  const int32_t ybase = R0 - kWarm;
+  for (int r = threadIdx.x; r < kRowsY; r += 256) {
+    const int32_t row = ybase + r;
+    ys[pad_y(r)] = (row >= 0 && row < n) ? y[row] : (half_t)0.0f;
+  }
+  __syncthreads();
+  // ---- forward elimination: task j owns rows [R0 + 16 j, +16)
+  for (int task = threadIdx.x; task < (kTileRows + kApron) / kOwn; task += 256) {
+    const int32_t lo_row = R0 + kOwn * task;
+    int32_t first = lo_row < 0 ? 0 : lo_row;
+    const int32_t last = lo_row + kOwn < n ? lo_row + kOwn : n;     // exclusive
+    if (first >= last) continue;
+    int32_t s0 = first - kWarm;
+    if (s0 < kFront) s0 = 0;                                         // reach the true first rows instead of guessing
+    double dp = 0.0;
+    for (int32_t i = s0; i < last; ++i) {
+      double lo, w;
+      if (i < kFront) { lo = R.lo_front[i]; w = R.w_front[i]; }
+      else if (i >= n - 3) { lo = R.lo_tail[i - (n - 3)]; w = R.w_tail[i - (n - 3)]; }
+      else { lo = 0.125; w = R.w_mid; }
+      dp = ((double)ys[pad_y(i - ybase)] - lo * dp) * w;
+      if (i >= first) cs[pad_c(i - R0)] = dp;
+    }
+  }
+  __syncthreads();
+  // ---- back substitution over the tile's own rows (dp of the rows to the right is in LDS)
+  double cown[kOwn];
+  {
+    const int task = threadIdx.x;
+    const int32_t lo_row = R0 + kOwn * task;
+    const int32_t first = lo_row < 0 ? 0 : lo_row;
+    const int32_t last = lo_row + kOwn < n ? lo_row + kOwn : n;
+    if (first < last) {
+      int32_t e = last + kWarm;
+      if (e > n) e = n;
+      if (e > R0 + kTileRows + kApron) e = R0 + kTileRows + kApron;
+      double next = 0.0;
+      auto pivot = [&](int32_t i) { return i < kFront ? R.cp_front[i] : (i >= n - 3 ? R.cp_tail[i - (n - 3)] : R.cp_mid); };
+      for (int32_t i = e - 1; i >= last; --i) next = cs[pad_c(i - R0)] - pivot(i) * next;       // warm-up
+#pragma unroll
+      for (int k = kOwn - 1; k >= 0; --k) {
+        const int32_t i = lo_row + k;
+        if (i >= first && i < last) { next = cs[pad_c(i - R0)] - pivot(i) * next; cown[k] = next; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kOwn; ++k) {
+      const int32_t i = lo_row + k;
+      if (i >= first && i < last) cs[pad_c(i - R0)] = cown[k];
+    }
+  }
+  __syncthreads();
+  // ---- evaluate the points whose knot interval ell lies in [E0, E1)
+  const int32_t E0 = R0 + 2 < 2 ? 2 : R0 + 2;
+  const int32_t E1 = R0 + kTileRows < n ? R0 + kTileRows : n;
+  auto x_of = [&](int64_t k) { return (double)(ck.first + k) * ck.step + ck.start; };   // y = arange * step; y += start
+  auto count_below = [&](double X) -> int64_t {                      // number of points with x_k < X
+    double est = ceil((X - ck.start) / ck.step) - (double)ck.first;
+    int64_t k = est < 0 ? 0 : (est > (double)ck.count ? (int64_t)ck.count : (int64_t)est);
+    while (k > 0 && !(x_of(k - 1) < X)) --k;
+    while (k < ck.count && x_of(k) < X) ++k;
+    return k;
+  };
+  const int64_t k0 = E0 <= 2 ? 0 : count_below((double)ck.b0 + (double)E0 - 1.5);
+  const int64_t k1 = E1 >= n ? (int64_t)ck.count : count_below((double)ck.b0 + (double)E1 - 1.5);
+  half_t* out = video + (int64_t)ch * n_video + ck.out_abs;
+  for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
+    const double x = x_of(k);
+    double v = 0.0;
+    if (!(x < (double)ck.b0) && !(x > (double)(ck.b0 + n - 1))) {
+      const int32_t ell = knot_interval(x, n, ck.b0);
+      double h[3];
+      if (ell >= 5 && ell <= n - 4) {
+        // interior knots are one apart: de Boor's divisions are by 1 and 2 (exact as multiplications)
+        const double t0 = (double)(ck.b0 + ell - 3) + 1.5;           // knot(ell)
+        const double a = x - t0, b = (t0 + 1.0) - x;                 // x - t[ell], t[ell+1] - x
+        const double w1 = 0.5 * b, w2 = 0.5 * a;                     // h1 / (t[ell+1]-t[ell-1]), h2 / (t[ell+2]-t[ell])
+        h[0] = w1 * b;
+        h[1] = w1 * (x - (t0 - 1.0));
+        h[1] = h[1] + w2 * ((t0 + 2.0) - x);
+        h[2] = w2 * a;
+      } else {
+        basis3(x, ell, n, ck.b0, h);
+      }
+      const int r = ell - 2 - R0;
+      v = h[0] * cs[pad_c(r)];
+      v = v + h[1] * cs[pad_c(r + 1)];
+      v = v + h[2] * cs[pad_c(r + 2)];
+    }
+    out[k] = to_half(v);
+  }
+}
+
 // ------------------------------------------------------------------------------------ stretching
 
 // The reference forms every sliding 512-sum as a difference of one float64 running sum over the
@@ -275,55 +408,22 @@ __global__ void __launch_bounds__(256) k_spline_eval(const ResChunk* __restrict_
 // in the same order as the reference's single sum, hence bit-identical to it).  Parallelism is
 // over (chunk, lag): 10-482 lags x one chunk per 25 088 samples.
 
-struct CorrChunk {            // a chunk of <= 57 windows (:253-270)
-  int64_t begin, end;         // samples of the interval it is computed from
+struct SegDesc {             // one stretched interval
+  int64_t in_off;            // x0: first audio sample of the interval
+  int64_t n_in, n_out, total, n_windows;
+  int n_lags, lag_off;
+  int64_t table_off;         // offset into where/loss  (n_windows * n_lags entries)
+  int64_t back_off;          // offset into the back-pointer array (n_windows * 3073 entries)
+  int64_t plan_off;          // offset into the copy plan arrays (n_windows + 2 entries)
+};
+
+struct CorrChunk {            // a chunk of <= 57 windows (:253-270), all intervals in one list
+  int64_t begin, end;         // samples of its interval it is computed from
   int64_t rms_off;            // offset of its rms[0 .. end-begin-511) in the rms array
   int32_t w_lo, w_hi;         // local windows it hands out
+  int32_t seg;                // which stretched interval
+  int32_t pad_;
 };
-
-__device__ __forceinline__ float power_at(const half_t* __restrict__ s, int64_t t, int channels, int64_t ch_stride) {
-  const float a = (float)s[t];
-  float r = a * a;
-  if (channels == 2) { const float b = (float)s[ch_stride + t]; r = r + b * b; }
-  return r;
-}
-
-// thread per chunk: rms[p] = sqrt(E[p] + eps), E[p] = sum_{k<512} power[p+k], eps = 1e-4 max(1, max E)  (:272-279)
-__global__ void __launch_bounds__(64) k_chunk_rms(const half_t* __restrict__ seg, int channels, int64_t ch_stride,
-                                                  const CorrChunk* __restrict__ chunks, int n_chunks,
-                                                  double* __restrict__ rms_all, double* __restrict__ eps_all) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n_chunks) return;
-  const CorrChunk ck = chunks[c];
-  const half_t* s = seg + ck.begin;
-  const int64_t P = ck.end - ck.begin - kSW + 1;
-  double* rms = rms_all + ck.rms_off;
-  double hi = 0.0, lo = 0.0, mx = 0.0;
-  for (int t = 0; t < kSW - 1; ++t) hi += (double)power_at(s, t, channels, ch_stride);
-  for (int64_t p = 0; p < P; ++p) {
-    hi += (double)power_at(s, p + kSW - 1, channels, ch_stride);
-    const double e = p ? hi - lo : hi;
-    rms[p] = e;
-    mx = e > mx ? e : mx;
-    lo += (double)power_at(s, p, channels, ch_stride);
-  }
-  const double eps = 1e-4 * (mx > 1.0 ? mx : 1.0);
-  eps_all[c] = eps;
-  for (int64_t p = 0; p < P; ++p) rms[p] = sqrt(rms[p] + eps);
-}
-
-struct JumpArgs {
-  const half_t* seg; int channels; int64_t ch_stride;
-  const double* rms; const CorrChunk* chunks; const double* eps; int n_chunks;
-  const int32_t* lags; int n_lags; int backwards;
-  int64_t n_windows;
-  int16_t* where; double* loss;                 // [n_windows][n_lags]
-};
-
-__global__ void k_fill_table(int16_t* __restrict__ where, double* __restrict__ loss, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { where[i] = 0; loss[i] = INFINITY; }        // np.argmax of an all -inf column is 0, its loss 1 - (-inf)
-}
 
 __device__ __forceinline__ float lag_product(const half_t* __restrict__ s, int64_t t, int lag, int channels, int64_t ch_stride) {
   float r = (float)s[t + lag] * (float)s[t];
@@ -331,51 +431,138 @@ __device__ __forceinline__ float lag_product(const half_t* __restrict__ s, int64
   return r;
 }
 
-// thread per (chunk, lag): Pearson correlation of the window at q with the window at q + lag for
-// every q of the chunk, arg-max and 1 - max per 512-position window (:280-296, :321-322).
-__global__ void __launch_bounds__(64) k_lag_table(const JumpArgs a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.n_chunks * a.n_lags) return;
-  const int c = t / a.n_lags, j = t % a.n_lags;
-  const CorrChunk ck = a.chunks[c];
-  const int lag = a.lags[j];
-  const double eps = a.eps[c];
-  const half_t* s = a.seg + ck.begin;
-  const double* rms = a.rms + ck.rms_off;
-  const int64_t P = ck.end - ck.begin - kSW + 1;
-  const int64_t Q = P - lag;                               // window starts q with q + lag still inside
-  if (Q <= 0) return;
-  const int64_t w0 = ck.begin / kSW;
-  double hi = 0.0, lo = 0.0;
-  for (int u = 0; u < kSW - 1; ++u) hi += (double)lag_product(s, u, lag, a.channels, a.ch_stride);
-  int64_t cur_w = -1; double best = -INFINITY; int best_u = 0;
-  auto flush = [&]() {
-    if (cur_w >= ck.w_lo && cur_w < ck.w_hi && w0 + cur_w < a.n_windows && best != -INFINITY) {
-      a.where[(w0 + cur_w) * a.n_lags + j] = (int16_t)best_u;
-      a.loss[(w0 + cur_w) * a.n_lags + j] = 1.0 - best;
-    }
-  };
-  for (int64_t q = 0; q < Q; ++q) {
-    hi += (double)lag_product(s, q + kSW - 1, lag, a.channels, a.ch_stride);
-    const double dots = (q ? hi - lo : hi) + eps;
-    lo += (double)lag_product(s, q, lag, a.channels, a.ch_stride);
-    const int64_t p = a.backwards ? q + lag : q;          // row of the reference's matrix this value lands in
-    const double first = a.backwards ? rms[q] : rms[q + lag];
-    const double corr = (dots / first) / rms[p];
-    const int64_t w = p / kSW;
-    if (w != cur_w) { flush(); cur_w = w; best = -INFINITY; best_u = 0; }
-    if (corr > best) { best = corr; best_u = (int)(p - w * kSW); }
+// One wavefront per running sum.  Element block m = products [512 m, 512 m + 512): all lanes
+// fetch them (coalesced) into LDS, lane 0 extends the float64 running sum over them in order and
+// leaves cs[t] in a ring of the last 2048 elements; the lanes then share the per-position work.
+constexpr int kRing = 2048;
+
+__device__ __forceinline__ void extend_running_sum(const half_t* __restrict__ s, int64_t n_prod, int lag, int channels,
+                                                   int64_t ch_stride, int64_t m, float* stage, double* ring, double& cs) {
+  const int lane = threadIdx.x;
+  const int64_t t0 = m * kSW;
+#pragma unroll
+  for (int k = 0; k < kSW / 64; ++k) {
+    const int64_t t = t0 + lane + 64 * k;
+    stage[lane + 64 * k] = t < n_prod ? lag_product(s, t, lag, channels, ch_stride) : 0.f;
   }
-  flush();
+  __syncthreads();                 // one-wavefront workgroup: orders the LDS traffic, costs nothing
+  if (lane == 0) {
+    double acc = cs;
+    const int64_t cnt = n_prod - t0 < kSW ? n_prod - t0 : kSW;
+    int64_t k = 0;
+    for (; k + 16 <= cnt; k += 16) {               // LDS reads up front, then the dependent chain of adds
+      float v[16]; double c[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = stage[k + e];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc += (double)v[e]; c[e] = acc; }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ring[(t0 + k + e) & (kRing - 1)] = c[e];
+    }
+    for (; k < cnt; ++k) { acc += (double)stage[k]; ring[(t0 + k) & (kRing - 1)] = acc; }
+    cs = acc;
+  }
+  __syncthreads();
 }
 
-struct SegDesc {             // one stretched interval
-  int64_t n_in, n_out, total, n_windows;
-  int n_lags, lag_off;
-  int64_t table_off;         // offset into where/loss  (n_windows * n_lags entries)
-  int64_t back_off;          // offset into the back-pointer array (n_windows * 3073 entries)
-  int64_t plan_off;          // offset into the copy plan arrays (n_windows + 2 entries)
-};
+// wave per chunk: rms[p] = sqrt(E[p] + eps), E[p] = sum_{k<512} power[p+k], eps = 1e-4 max(1, max E)  (:272-279)
+__global__ void __launch_bounds__(64) k_chunk_rms(const half_t* __restrict__ audio, int channels, int64_t ch_stride,
+                                                  const SegDesc* __restrict__ segs, const CorrChunk* __restrict__ chunks,
+                                                  double* __restrict__ rms_all, double* __restrict__ eps_all) {
+  __shared__ float stage[kSW];
+  __shared__ double ring[kRing];
+  const CorrChunk ck = chunks[blockIdx.x];
+  const half_t* s = audio + segs[ck.seg].in_off + ck.begin;
+  const int64_t L = ck.end - ck.begin;
+  const int64_t P = L - kSW + 1;
+  double* rms = rms_all + ck.rms_off;
+  const int lane = threadIdx.x;
+  double cs = 0.0, mx = 0.0;
+  const int64_t n_blocks = (L + kSW - 1) / kSW;
+  for (int64_t m = 0; m < n_blocks; ++m) {
+    extend_running_sum(s, L, 0, channels, ch_stride, m, stage, ring, cs);
+    // positions whose window ends inside this element block: p + 511 in [512 m, 512 m + 512)
+    for (int k = lane; k < kSW; k += 64) {
+      const int64_t p = m * kSW + k - (kSW - 1);
+      if (p >= 0 && p < P) {
+        const double hi = ring[(p + kSW - 1) & (kRing - 1)];
+        const double e = p ? hi - ring[(p - 1) & (kRing - 1)] : hi;
+        rms[p] = e;
+        mx = e > mx ? e : mx;
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+  const double eps = 1e-4 * (mx > 1.0 ? mx : 1.0);
+  if (lane == 0) eps_all[blockIdx.x] = eps;
+  __threadfence();
+  __syncthreads();
+  for (int64_t p = lane; p < P; p += 64) rms[p] = sqrt(rms[p] + eps);
+}
+
+__global__ void k_fill_table(int16_t* __restrict__ where, double* __restrict__ loss, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { where[i] = 0; loss[i] = INFINITY; }        // np.argmax of an all -inf column is 0, its loss 1 - (-inf)
+}
+
+// wave per (chunk, lag): Pearson correlation of the window at q with the window at q + lag for
+// every q of the chunk, arg-max and 1 - max per 512-position window (:280-296, :321-322).
+__global__ void __launch_bounds__(64) k_lag_table(const half_t* __restrict__ audio, int channels, int64_t ch_stride,
+                                                  const SegDesc* __restrict__ segs, const CorrChunk* __restrict__ chunks,
+                                                  const int32_t* __restrict__ lags_all, const double* __restrict__ rms_all,
+                                                  const double* __restrict__ eps_all, int16_t* __restrict__ where_all,
+                                                  double* __restrict__ loss_all) {
+  __shared__ float stage[kSW];
+  __shared__ double ring[kRing];
+  const CorrChunk ck = chunks[blockIdx.x];
+  const SegDesc sd = segs[ck.seg];
+  const int j = blockIdx.y;
+  if (j >= sd.n_lags) return;
+  const int lag = lags_all[sd.lag_off + j];
+  const bool backwards = sd.total > 0;
+  const double eps = eps_all[blockIdx.x];
+  const half_t* s = audio + sd.in_off + ck.begin;
+  const double* rms = rms_all + ck.rms_off;
+  const int64_t L = ck.end - ck.begin;
+  const int64_t P = L - kSW + 1;
+  const int64_t Q = P - lag;                               // window starts q with q + lag still inside
+  if (Q <= 0) return;
+  const int64_t n_prod = L - lag;                          // lag products of the chunk
+  const int64_t w0 = ck.begin / kSW;
+  const int lane = threadIdx.x;
+  const int off = backwards ? lag : 0;                     // row p of the reference's matrix is q + off
+  const int64_t n_win = (Q + off + kSW - 1) / kSW;         // windows that contain at least one row
+  const int64_t n_blocks = (n_prod + kSW - 1) / kSW;
+  double cs = 0.0;
+  int64_t made = 0;                                        // element blocks already summed
+  for (int64_t w = 0; w < n_win; ++w) {
+    // rows p in [512 w, 512 w + 512) need running sums up to element p - off + 511 < 512 (w + 2)
+    while (made < n_blocks && made <= w + 1) { extend_running_sum(s, n_prod, lag, channels, ch_stride, made, stage, ring, cs); ++made; }
+    const bool wanted = w >= ck.w_lo && w < ck.w_hi && w0 + w < sd.n_windows;
+    if (!wanted) continue;
+    double best = -INFINITY; int best_u = kSW;
+#pragma unroll
+    for (int k = 0; k < kSW / 64; ++k) {
+      const int u = lane + 64 * k;                         // ascending per lane: first maximum kept by '>'
+      const int64_t q = w * kSW + u - off;
+      if (q >= 0 && q < Q) {
+        const double hi = ring[(q + kSW - 1) & (kRing - 1)];
+        const double dots = (q ? hi - ring[(q - 1) & (kRing - 1)] : hi) + eps;
+        const double ra = rms[q], rb = rms[q + lag];
+        const double corr = backwards ? (dots / ra) / rb : (dots / rb) / ra;   // (dots / rms[other window]) / rms[p]
+        if (corr > best) { best = corr; best_u = u; }
+      }
+    }
+    for (int sh = 32; sh > 0; sh >>= 1) {
+      const double ob = __shfl_xor(best, sh); const int ou = __shfl_xor(best_u, sh);
+      if (ob > best || (ob == best && ou < best_u)) { best = ob; best_u = ou; }
+    }
+    if (lane == 0 && best != -INFINITY) {
+      where_all[sd.table_off + (w0 + w) * sd.n_lags + j] = (int16_t)best_u;
+      loss_all[sd.table_off + (w0 + w) * sd.n_lags + j] = 1.0 - best;
+    }
+  }
+}
 
 __device__ __forceinline__ int64_t floordiv(int64_t a, int64_t b) {     // Python's // for b > 0
   int64_t q = a / b;
@@ -399,41 +586,80 @@ __global__ void __launch_bounds__(1024) k_viterbi(const SegDesc* __restrict__ se
                                                   int32_t* __restrict__ counts) {
   extern __shared__ double lds[];
   double* hist = lds;                          // [3][kND]
-  double* lrow = lds + 3 * kND;                // [kMaxLags]
-  int32_t* lags = reinterpret_cast<int32_t*>(lrow + kMaxLags);   // [kMaxLags]
+  double* lrow = lds + 3 * kND;                // [2][kMaxLags]: loss row of this window / the next one
+  int32_t* lags = reinterpret_cast<int32_t*>(lrow + 2 * kMaxLags);   // [kMaxLags]
+  __shared__ int64_t sstep[2];
   const SegDesc sd = segs[blockIdx.x];
   const int J = sd.n_lags;
   const int64_t nw = sd.n_windows;
   const double* loss = loss_all + sd.table_off;
   const int16_t* where = where_all + sd.table_off;
   int16_t* back = back_all + sd.back_off;
-  for (int d = threadIdx.x; d < 3 * kND; d += blockDim.x) hist[d] = INFINITY;
-  for (int k = threadIdx.x; k < J; k += blockDim.x) lags[k] = lags_all[sd.lag_off + k];
+  const int tid = threadIdx.x;
+  for (int d = tid; d < 3 * kND; d += blockDim.x) hist[d] = INFINITY;
+  if (tid < J) { lags[tid] = lags_all[sd.lag_off + tid]; lrow[tid] = loss[tid]; }
+  if (tid == 0) sstep[0] = offset_step(sd.total, nw, 0);
   __syncthreads();
-  if (threadIdx.x == 0) { hist[1 * kND + kMaxDrift] = 0.0; hist[2 * kND + kMaxDrift] = 0.0; }      // (:320)
+  if (tid == 0) { hist[1 * kND + kMaxDrift] = 0.0; hist[2 * kND + kMaxDrift] = 0.0; }      // (:320)
+  __syncthreads();
+  // drift states of this thread: tid, tid + 1024, tid + 2048; state 3072 is thread 0's extra
+  constexpr int kSlots = 3;
   int64_t prev_step = 0;
   for (int64_t w = 0; w < nw; ++w) {
-    for (int k = threadIdx.x; k < J; k += blockDim.x) lrow[k] = loss[w * J + k];
-    __syncthreads();
-    const int64_t step = offset_step(sd.total, nw, w);
-    const int64_t two = step + prev_step;
+    const int cur = (int)(w & 1);
+    // the next window's loss row and drift step are fetched while this window is processed
+    double nxt = 0.0; int64_t nstep = 0;
+    if (tid < J && w + 1 < nw) nxt = loss[(w + 1) * J + tid];
+    if (tid == 0) nstep = offset_step(sd.total, nw, w + 1);
+    const int step = (int)sstep[cur];
+    const int two = step + (int)prev_step;
     const double* h1 = hist + ((w + 2) % 3) * kND;       // (w-1) % 3
     const double* h2 = hist + ((w + 1) % 3) * kND;       // (w-2) % 3
     double* hw = hist + (w % 3) * kND;
-    for (int d = threadIdx.x; d < kND; d += blockDim.x) {
-      double best = (d < kND - step) ? h1[d + step] : INFINITY;            // no jump (:333-334)
-      int pick = 0;
-      for (int k = 0; k < J; ++k) {
-        const int lag = lags[k];
-        const int64_t cut = two - lag;
-        if (d >= lag && d < kND - (cut > 0 ? cut : 0)) {                   // (:335-342)
-          const double v = h2[d - lag + two] + lrow[k];
-          if (v < best) { best = v; pick = k + 1; }
+    const double* lr = lrow + cur * kMaxLags;
+    double best[kSlots]; int pick[kSlots];
+#pragma unroll
+    for (int m = 0; m < kSlots; ++m) {
+      const int d = tid + 1024 * m;
+      best[m] = (d < kND - step) ? h1[d + step] : INFINITY;                // no jump (:333-334)
+      pick[m] = 0;
+    }
+    for (int k = 0; k < J; ++k) {
+      const int lag = lags[k];
+      const double lk = lr[k];
+      const int cut = two - lag;
+      const int hi_d = kND - (cut > 0 ? cut : 0);
+      const int shift = two - lag;
+#pragma unroll
+      for (int m = 0; m < kSlots; ++m) {
+        const int d = tid + 1024 * m;
+        if (d >= lag && d < hi_d) {                                        // (:335-342)
+          const double v = h2[d + shift] + lk;
+          if (v < best[m]) { best[m] = v; pick[m] = k + 1; }
         }
       }
-      hw[d] = best;
-      back[w * kND + d] = (int16_t)pick;
     }
+#pragma unroll
+    for (int m = 0; m < kSlots; ++m) {
+      const int d = tid + 1024 * m;
+      hw[d] = best[m]; back[w * kND + d] = (int16_t)pick[m];
+    }
+    if (tid == 0) {
+      const int d = kND - 1;
+      double b = (d < kND - step) ? h1[d + step] : INFINITY;
+      int pk = 0;
+      for (int k = 0; k < J; ++k) {
+        const int lag = lags[k];
+        const int cut = two - lag;
+        if (d >= lag && d < kND - (cut > 0 ? cut : 0)) {
+          const double v = h2[d + cut] + lr[k];
+          if (v < b) { b = v; pk = k + 1; }
+        }
+      }
+      hw[d] = b; back[w * kND + d] = (int16_t)pk;
+    }
+    if (tid < J) lrow[(cur ^ 1) * kMaxLags + tid] = nxt;
+    if (tid == 0) sstep[cur ^ 1] = nstep;
     prev_step = step;
     __syncthreads();
   }
@@ -588,22 +814,45 @@ std::vector<int32_t> lag_list(int64_t total) {              // (:303-308)
   return l;
 }
 
-std::vector<CorrChunk> corr_chunks(int64_t n) {             // (:253-270)
+// appends the chunks of one interval of n samples (:253-270) to the flat list
+void corr_chunks(int64_t n, int32_t seg, int64_t& rms_total, std::vector<CorrChunk>& out) {
   const double limit = (kCached + 2) * 1.1 * kSW;
-  std::vector<CorrChunk> out;
-  int64_t begin = 0, off = 0;
+  int64_t begin = 0;
   int32_t lo = 0;
   while (true) {
     const bool last = (double)(n - begin) <= limit;
     CorrChunk c{};
     c.begin = begin; c.end = last ? n : begin + (int64_t)(kCached + 1) * kSW;
-    c.rms_off = off; c.w_lo = lo; c.w_hi = last ? (int32_t)((n - begin) / kSW) : kCached;
-    off += c.end - c.begin - kSW + 1;
+    c.rms_off = rms_total; c.w_lo = lo; c.w_hi = last ? (int32_t)((n - begin) / kSW) : kCached;
+    c.seg = seg;
+    rms_total += c.end - c.begin - kSW + 1;
     out.push_back(c);
-    if (last) return out;
+    if (last) return;
     begin += (int64_t)(kCached - 1) * kSW;
     lo = 1;
   }
+}
+
+SplineRows spline_rows() {
+  // any n >= kFusedMinRows gives the same first kFront and last three rows
+  const int32_t n = 4 * kFront; const int64_t b0 = 0;
+  SplineRows R{};
+  double cp = 0.0;
+  for (int i = 0; i < kFront; ++i) {
+    double lo, di, up; colloc_row(i, n, b0, lo, di, up);
+    const double w = 1.0 / (di - lo * cp);
+    cp = up * w;
+    R.lo_front[i] = lo; R.w_front[i] = w; R.cp_front[i] = cp;
+  }
+  for (int it = 0; it < 64; ++it) cp = 0.125 / (0.75 - 0.125 * cp);          // the fixed point
+  R.cp_mid = cp; R.w_mid = 1.0 / (0.75 - 0.125 * cp);
+  for (int t = 0; t < 3; ++t) {
+    double lo, di, up; colloc_row(n - 3 + t, n, b0, lo, di, up);
+    const double w = 1.0 / (di - lo * cp);
+    cp = up * w;
+    R.lo_tail[t] = lo; R.w_tail[t] = w; R.cp_tail[t] = cp;
+  }
+  return R;
 }
 
 float elapsed(hipEvent_t a, hipEvent_t b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, a, b); return ms; }
@@ -733,14 +982,22 @@ int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, in
     tm.resample_bytes = points * channels * 2.0 /*written*/ + (double)coef_total * 2.0 /*read once*/;
     if (!chunks.empty()) {
       S_TRY(s->res_chunks.ensure(sizeof(ResChunk) * chunks.size()));
-      S_TRY(s->coef.ensure(sizeof(double) * (size_t)coef_total));
+      int64_t small_total = 0; bool any_small = false;
+      for (ResChunk& c : chunks)
+        if (c.n < kFusedMinRows) { c.coef_off = small_total; small_total += (int64_t)c.n * channels; any_small = true; }
+      S_TRY(s->coef.ensure(sizeof(double) * (size_t)(small_total + 8)));
       S_TRY(hipMemcpyAsync(s->res_chunks.p, chunks.data(), sizeof(ResChunk) * chunks.size(), hipMemcpyHostToDevice, stream));
       S_TRY(hipEventRecord(s->e0, stream));
-      const int threads = (int)chunks.size() * channels;
-      hipLaunchKernelGGL(k_spline_solve, dim3((threads + 63) / 64), dim3(64), 0, stream, s->res_chunks.as<ResChunk>(),
-                         (int)chunks.size(), channels, d_audio, n_audio, s->coef.as<double>());
-      hipLaunchKernelGGL(k_spline_eval, dim3((kResChunk + 255) / 256, (unsigned)chunks.size()), dim3(256), 0, stream,
-                         s->res_chunks.as<ResChunk>(), channels, s->coef.as<double>(), d_video, n_video);
+      static const SplineRows rows = spline_rows();
+      hipLaunchKernelGGL(k_resample_tile, dim3(kMaxTiles, (unsigned)chunks.size(), channels), dim3(256), 0, stream,
+                         s->res_chunks.as<ResChunk>(), d_audio, n_audio, d_video, n_video, rows);
+      if (any_small) {
+        const int threads = (int)chunks.size() * channels;
+        hipLaunchKernelGGL(k_spline_solve, dim3((threads + 63) / 64), dim3(64), 0, stream, s->res_chunks.as<ResChunk>(),
+                           (int)chunks.size(), channels, d_audio, n_audio, s->coef.as<double>());
+        hipLaunchKernelGGL(k_spline_eval, dim3((kResChunk + 255) / 256, (unsigned)chunks.size()), dim3(256), 0, stream,
+                           s->res_chunks.as<ResChunk>(), channels, s->coef.as<double>(), d_video, n_video);
+      }
       S_TRY(hipGetLastError());
       S_TRY(hipEventRecord(s->e1, stream));
       S_TRY(hipStreamSynchronize(stream));
@@ -755,23 +1012,28 @@ int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, in
   const int NS = (int)st.size();
   std::vector<SegDesc> segs(NS);
   std::vector<int32_t> lags_all;
-  std::vector<std::vector<CorrChunk>> chunk_lists(NS);
-  int64_t table_total = 0, back_total = 0, plan_total = 0, energy_max = 0; size_t chunks_max = 0;
+  std::vector<CorrChunk> chunks;
+  int64_t table_total = 0, back_total = 0, plan_total = 0, rms_total = 0;
+  int max_lags = 0;
+  double windows = 0, cbytes = 0;
   for (int k = 0; k < NS; ++k) {
     const Interval& iv = *st[k];
     SegDesc& d = segs[k];
+    d.in_off = iv.x0;
     d.n_in = iv.x1 - iv.x0; d.n_out = iv.y1 - iv.y0; d.total = d.n_out - d.n_in; d.n_windows = d.n_in / kSW;
     if (d.n_in < 3 * kSW - 1 || d.n_windows < 2) return sfail(err, DA_ERR_ARG, "Invalid state in Pearson generator.");
     const std::vector<int32_t> l = lag_list(d.total);
     d.n_lags = (int)l.size(); d.lag_off = (int)lags_all.size();
+    max_lags = std::max(max_lags, d.n_lags);
     lags_all.insert(lags_all.end(), l.begin(), l.end());
     d.table_off = table_total; table_total += d.n_windows * d.n_lags;
     d.back_off = back_total; back_total += d.n_windows * kND;
     d.plan_off = plan_total; plan_total += d.n_windows + 2;
-    chunk_lists[k] = corr_chunks(d.n_in);
-    energy_max = std::max(energy_max, chunk_lists[k].back().rms_off + (chunk_lists[k].back().end - chunk_lists[k].back().begin));
-    chunks_max = std::max(chunks_max, chunk_lists[k].size());
+    corr_chunks(d.n_in, k, rms_total, chunks);
+    windows += (double)d.n_windows * d.n_lags;
+    cbytes += (double)d.n_in * channels * 2.0 * (1 + d.n_lags);
   }
+  const int NC = (int)chunks.size();
   S_TRY(s->segs.ensure(sizeof(SegDesc) * NS));
   S_TRY(s->lags.ensure(sizeof(int32_t) * lags_all.size()));
   S_TRY(s->where.ensure(sizeof(int16_t) * (size_t)table_total));
@@ -781,42 +1043,28 @@ int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, in
   S_TRY(s->plan_out.ensure(sizeof(int64_t) * (size_t)plan_total));
   S_TRY(s->sched.ensure(sizeof(int64_t) * 2 * (size_t)plan_total));
   S_TRY(s->counts.ensure(sizeof(int32_t) * 2 * NS));
-  S_TRY(s->energy.ensure(sizeof(double) * (size_t)energy_max));
-  S_TRY(s->corr_chunks.ensure(sizeof(CorrChunk) * chunks_max));
-  S_TRY(s->eps.ensure(sizeof(double) * chunks_max));
+  S_TRY(s->energy.ensure(sizeof(double) * (size_t)rms_total));
+  S_TRY(s->corr_chunks.ensure(sizeof(CorrChunk) * NC));
+  S_TRY(s->eps.ensure(sizeof(double) * NC));
   S_TRY(hipMemcpyAsync(s->segs.p, segs.data(), sizeof(SegDesc) * NS, hipMemcpyHostToDevice, stream));
   S_TRY(hipMemcpyAsync(s->lags.p, lags_all.data(), sizeof(int32_t) * lags_all.size(), hipMemcpyHostToDevice, stream));
+  S_TRY(hipMemcpyAsync(s->corr_chunks.p, chunks.data(), sizeof(CorrChunk) * NC, hipMemcpyHostToDevice, stream));
 
+  // all intervals in one launch each: wavefront per chunk, then wavefront per (chunk, lag)
   S_TRY(hipEventRecord(s->e0, stream));
-  double windows = 0, cbytes = 0;
   hipLaunchKernelGGL(k_fill_table, dim3((unsigned)((table_total + 255) / 256)), dim3(256), 0, stream, s->where.as<int16_t>(),
                      s->loss.as<double>(), table_total);
-  for (int k = 0; k < NS; ++k) {
-    const Interval& iv = *st[k];
-    const SegDesc& d = segs[k];
-    const half_t* seg = d_audio + iv.x0;
-    const int nc = (int)chunk_lists[k].size();
-    S_TRY(hipMemcpyAsync(s->corr_chunks.p, chunk_lists[k].data(), sizeof(CorrChunk) * nc, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_chunk_rms, dim3((nc + 63) / 64), dim3(64), 0, stream, seg, channels, n_audio,
-                       s->corr_chunks.as<CorrChunk>(), nc, s->energy.as<double>(), s->eps.as<double>());
-    JumpArgs ja{};
-    ja.seg = seg; ja.channels = channels; ja.ch_stride = n_audio;
-    ja.rms = s->energy.as<double>(); ja.chunks = s->corr_chunks.as<CorrChunk>(); ja.eps = s->eps.as<double>();
-    ja.n_chunks = nc;
-    ja.lags = s->lags.as<int32_t>() + d.lag_off; ja.n_lags = d.n_lags; ja.backwards = d.total > 0 ? 1 : 0;
-    ja.n_windows = d.n_windows;
-    ja.where = s->where.as<int16_t>() + d.table_off; ja.loss = s->loss.as<double>() + d.table_off;
-    hipLaunchKernelGGL(k_lag_table, dim3((nc * d.n_lags + 63) / 64), dim3(64), 0, stream, ja);
-    S_TRY(hipGetLastError());
-    // the chunk list / rms buffers are reused by the next interval: stream order keeps them apart
-    windows += (double)d.n_windows * d.n_lags;
-    cbytes += (double)d.n_in * channels * 2.0 * (1 + d.n_lags);
-  }
+  hipLaunchKernelGGL(k_chunk_rms, dim3(NC), dim3(64), 0, stream, d_audio, channels, n_audio, s->segs.as<SegDesc>(),
+                     s->corr_chunks.as<CorrChunk>(), s->energy.as<double>(), s->eps.as<double>());
+  hipLaunchKernelGGL(k_lag_table, dim3(NC, max_lags), dim3(64), 0, stream, d_audio, channels, n_audio,
+                     s->segs.as<SegDesc>(), s->corr_chunks.as<CorrChunk>(), s->lags.as<int32_t>(), s->energy.as<double>(),
+                     s->eps.as<double>(), s->where.as<int16_t>(), s->loss.as<double>());
+  S_TRY(hipGetLastError());
   S_TRY(hipEventRecord(s->e1, stream));
   S_TRY(hipStreamSynchronize(stream));
   tm.correlate_ms = elapsed(s->e0, s->e1); tm.correlate_windows = windows; tm.correlate_bytes = cbytes;
 
-  const size_t lds_bytes = sizeof(double) * (3 * kND + kMaxLags) + sizeof(int32_t) * kMaxLags;
+  const size_t lds_bytes = sizeof(double) * (3 * kND + 2 * kMaxLags) + sizeof(int32_t) * kMaxLags;
   S_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_viterbi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   S_TRY(hipEventRecord(s->e0, stream));
   hipLaunchKernelGGL(k_viterbi, dim3(NS), dim3(1024), lds_bytes, stream, s->segs.as<SegDesc>(), s->lags.as<int32_t>(),
