@@ -8,7 +8,10 @@ bitstream-filter command line the reference issues.
 A directory batch shards across GPUs with no collectives: pair k goes to GPU k % gpus, one
 worker process per GPU (`--gpus`).
 
-Out of scope here: --stretch_audio (replace_aligned_segments), the GUI.
+--stretch_audio (replace_aligned_segments, :230-416, and the loudness / peak handling around it,
+:1135-1153) runs on the GPU as well: the PCM uploaded for the feature kernels stays resident and
+only the finished int16 track is copied back.  Out of scope: the GUI, the ffprobe-based
+"is the first track already AD" check (:460-462; the original track is always titled "original").
 """
 from __future__ import annotations
 
@@ -92,6 +95,39 @@ def _mux_command(ffmpeg, video_file, audio_desc_file, output_filename, setts_cmd
           output_filename, "-y"]
 
 
+def _replaced_media_command(ffmpeg, output_filename, video_file):
+  """ffmpeg argv for the --stretch_audio output (same options as :468-487): the new stereo track is
+  piped in as s16le and either stored on its own (audio-only input) or muxed in front of the
+  original streams."""
+  head = [ffmpeg, "-f", "s16le", "-acodec", "pcm_s16le", "-ac", "2", "-ar", str(media.AUDIO_SAMPLE_RATE), "-i", "pipe:"]
+  if video_file is None:
+    return head + ["-loglevel", "error", output_filename, "-y"]
+  return head + ["-dn", "-i", video_file, "-map", "0", "-map", "1",
+                 "-acodec", "copy", "-vcodec", "copy", "-scodec", "copy", "-max_interleave_delta", "0",
+                 "-loglevel", "error", "-c:a:0", "aac", "-disposition:a:0", "default+visual_impaired+descriptions",
+                 "-metadata:s:a:0", "title=AD", "-disposition:a:1", "original", "-metadata:s:a:1", "title=original",
+                 output_filename, "-y"]
+
+
+def _write_replaced_media(ffmpeg, output_filename, frames, video_file):
+  """write_replaced_media_to_disk with a media array (:468-487).  Without an ffmpeg binary the
+  track is written as a .wav next to where the output would have gone."""
+  if frames.shape[1] == 1:
+    frames = np.repeat(frames, 2, axis=1)
+  if ffmpeg is None:
+    wav = os.path.splitext(output_filename)[0] + ".wav"
+    media.write_wav(wav, np.ascontiguousarray(frames.T))
+    return f"(no ffmpeg binary on PATH; replaced audio track written to {wav})"
+  argv = _replaced_media_command(ffmpeg, output_filename, video_file)
+  res = subprocess.run(argv, input=np.ascontiguousarray(frames).tobytes(), capture_output=True)
+  if res.returncode != 0 or len(res.stderr) > 0:
+    print("  ERROR: ffmpeg failed to write output file: " + output_filename)
+    print("FFmpeg error:")
+    print(res.stderr.decode("utf-8", "replace"))
+    raise RuntimeError("FFmpeg error.")
+  return subprocess.list2cmdline(argv).replace('\\', '/')
+
+
 def process_pair(video_file, audio_desc_file, has_audio_extension, ctx, stretch_audio=False, prepend="ad_",
                  no_pitch_correction=False, output_dir=default_output_dir, alignment_dir=default_alignment_dir):
   """One iteration of the reference's per-pair loop (:1077-1174)."""
@@ -101,8 +137,6 @@ def process_pair(video_file, audio_desc_file, has_audio_extension, ctx, stretch_
   print(f" {output_filename}")
   if (not stretch_audio) & has_audio_extension:
     raise RuntimeError("Argument --stretch_audio is required when both inputs are audio files.")
-  if stretch_audio:
-    raise NotImplementedError("--stretch_audio (replace_aligned_segments) is outside this build's scope")
   if os.path.exists(output_filename) and os.path.getsize(output_filename) > 1e5:
     print("   output file already exists, skipping...")
     return None
@@ -110,7 +144,7 @@ def process_pair(video_file, audio_desc_file, has_audio_extension, ctx, stretch_
   print("  reading video file...\r", end='')
   video_arr = media.parse_audio_from_file(video_file, num_channels)
   print("  computing video features... \r", end='')
-  video_features = ctx.features(video_arr, _native.SIDE_VIDEO)
+  video_features = ctx.features(video_arr, _native.SIDE_VIDEO)      # the PCM stays resident on the GPU
   del video_arr
   print("  reading audio file...       \r", end='')
   audio_desc_arr = media.parse_audio_from_file(audio_desc_file, num_channels)
@@ -130,7 +164,15 @@ def process_pair(video_file, audio_desc_file, has_audio_extension, ctx, stretch_
   setts_cmd = report.encode_fit_as_ffmpeg_expr(audio_desc_times, video_times, video_offset)
   ffmpeg_command = ""
   ffmpeg = media.find_ffmpeg()
-  if ffmpeg is not None and not has_audio_extension:
+  if stretch_audio:
+    # :1135-1159 -- loudness matching, replace_aligned_segments, peak normalisation and the int16
+    # interleave all run on the PCM already resident on the GPU; only the finished track comes back
+    print("  stretching audio...                         \r", end='')
+    frames, _ = ctx.stretch_resident(audio_desc_times, video_times, no_pitch_correction)
+    print("  processing output file...                   \r", end='')
+    ffmpeg_command = _write_replaced_media(ffmpeg, output_filename, frames,
+                                           None if has_audio_extension else video_file)
+  elif ffmpeg is not None and not has_audio_extension:
     print("  processing output file...                   \r", end='')
     # without ffprobe's key-frame table the cut point is the offset itself
     argv = _mux_command(ffmpeg, video_file, audio_desc_file, output_filename, setts_cmd, video_offset,

@@ -143,3 +143,30 @@ def test_replace_segments_errors(ctx):
     ctx.replace_segments(v, a, np.array([0.0]), np.array([0.0]), False)
   with pytest.raises(ValueError):
     ctx.replace_segments(v.astype(np.float32), a, np.array([0.0, 3.0]), np.array([0.0, 3.0]), False)
+
+
+def test_combine_stretch_audio_end_to_end(ctx, tmp_path):
+  """python -m describealign_amd.combine --stretch_audio on two stereo .wav files: the written track
+  equals the oracle's replace pipeline run with the nodes the alignment found."""
+  import wave
+  from describealign_amd import combine, media, synth
+  pair = synth.make_pair(seed=21, video_seconds=40.0, jumps=([0.0, 20.0], [5.0, 2.0]), channels=2)
+  vfile, afile = str(tmp_path / "show.wav"), str(tmp_path / "show_ad.wav")
+  media.write_wav(vfile, pair.video); media.write_wav(afile, pair.audio)
+  out_dir, plot_dir = str(tmp_path / "out"), str(tmp_path / "plots")
+  os.makedirs(out_dir); os.makedirs(plot_dir)
+  res = combine.process_pair(vfile, afile, True, ctx, stretch_audio=True, output_dir=out_dir, alignment_dir=plot_dir)
+  x, y = res["audio_desc_times"], res["video_times"]
+  offs = np.round(np.asarray(x) - np.asarray(y), 1)
+  assert 5.0 in offs and 7.0 in offs, offs                        # the two injected offsets
+  v, a = pair.video.astype(np.float16), pair.audio.astype(np.float16)
+  SO.match_loudness(v, a)
+  SO.replace_aligned_segments(v, a, x, y, False)
+  SO.normalise_peak(v)
+  want = v.astype(np.int16)
+  if media.find_ffmpeg() is None:
+    with wave.open(os.path.join(out_dir, "ad_show.wav"), "rb") as w:
+      got = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, 2).T
+    assert np.array_equal(got, want)
+  text = open(res["report"]).read()
+  assert "'stretch_audio': True" in text
