@@ -801,17 +801,21 @@ extern "C" int da_replace_segments(da_ctx* c, uint16_t* video, int64_t n_video, 
   if (int rc = check_nodes(c, audio_times, video_times, n_nodes, "da_replace_segments")) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
   if (!c->stretch) c->stretch = da::stretch_create();
-  const size_t vb = sizeof(uint16_t) * (size_t)n_video * channels, ab = sizeof(uint16_t) * (size_t)n_audio * channels;
-  HIP_TRY(c, c->st_video.ensure(vb)); HIP_TRY(c, c->st_audio.ensure(ab));
-  HIP_TRY(c, hipMemcpyAsync(c->st_video.p, video, vb, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->st_audio.p, audio, ab, hipMemcpyHostToDevice, c->stream));
+  const int64_t vs = da::stretch_channel_stride(n_video), as = da::stretch_channel_stride(n_audio);
+  HIP_TRY(c, c->st_video.ensure(sizeof(uint16_t) * (size_t)vs * channels));
+  HIP_TRY(c, c->st_audio.ensure(sizeof(uint16_t) * (size_t)as * channels));
+  HIP_TRY(c, hipMemcpy2DAsync(c->st_video.p, sizeof(uint16_t) * vs, video, sizeof(uint16_t) * n_video, sizeof(uint16_t) * n_video,
+                              channels, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpy2DAsync(c->st_audio.p, sizeof(uint16_t) * as, audio, sizeof(uint16_t) * n_audio, sizeof(uint16_t) * n_audio,
+                              channels, hipMemcpyHostToDevice, c->stream));
   da::StretchTimes t;
   std::string err;
   const int rc = da::stretch_replace(c->stretch, c->stream, c->st_video.as<uint16_t>(), n_video, c->st_audio.as<uint16_t>(),
                                      n_audio, channels, audio_times, video_times, n_nodes, no_pitch_correction != 0, t, err);
   if (rc) { (void)hipStreamSynchronize(c->stream); return fail(c, rc, "%s", err.c_str()); }
   stretch_stats(c, t);
-  HIP_TRY(c, hipMemcpyAsync(video, c->st_video.p, vb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpy2DAsync(video, sizeof(uint16_t) * n_video, c->st_video.p, sizeof(uint16_t) * vs, sizeof(uint16_t) * n_video,
+                              channels, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return DA_OK;
 }
@@ -829,17 +833,14 @@ extern "C" int da_stretch_resident(da_ctx* c, const double* audio_times, const d
   HIP_TRY(c, hipSetDevice(c->device));
   if (!c->stretch) c->stretch = da::stretch_create();
   const int C = sv.channels;
-  HIP_TRY(c, c->st_video.ensure(sizeof(uint16_t) * (size_t)sv.n * C));
-  HIP_TRY(c, c->st_audio.ensure(sizeof(uint16_t) * (size_t)sa.n * C));
+  HIP_TRY(c, c->st_video.ensure(sizeof(uint16_t) * (size_t)da::stretch_channel_stride(sv.n) * C));
+  HIP_TRY(c, c->st_audio.ensure(sizeof(uint16_t) * (size_t)da::stretch_channel_stride(sa.n) * C));
   HIP_TRY(c, c->st_out.ensure(sizeof(int16_t) * (size_t)sv.n * C));
   std::string err;
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-  if (da::stretch_load_pcm(c->stream, sv.pcm.as<int16_t>(), sv.n, C, sv.planar, c->st_video.as<uint16_t>()) ||
-      da::stretch_load_pcm(c->stream, sa.pcm.as<int16_t>(), sa.n, C, sa.planar, c->st_audio.as<uint16_t>()))
-    return fail(c, DA_ERR_DEVICE, "da_stretch_resident: PCM conversion launch failed");
   double f[2] = {0, 0};
-  int rc = da::stretch_match_loudness(c->stretch, c->stream, c->st_video.as<uint16_t>(), sv.n, c->st_audio.as<uint16_t>(),
-                                      sa.n, C, f, err);
+  int rc = da::stretch_prepare(c->stretch, c->stream, sv.pcm.as<int16_t>(), sv.n, sv.planar, sa.pcm.as<int16_t>(), sa.n,
+                               sa.planar, C, c->st_video.as<uint16_t>(), c->st_audio.as<uint16_t>(), f, err);
   if (rc) return fail(c, rc, "%s", err.c_str());
   HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
   if (factors) for (int k = 0; k < C; ++k) factors[k] = f[k];

@@ -23,18 +23,23 @@ struct StretchTimes {                      // device time per stage of the last 
   double finish_ms = 0;                    // peak normalisation + int16 interleave
 };
 
-// video / audio: device float16 (C, n) planar.  video is modified in place.  Returns 0 or a
+// video / audio: device float16 planar, channel stride stretch_channel_stride(n).  video is modified in place.  Returns 0 or a
 // negative da error code with the message in err.
 int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video, int64_t n_video,
                     const uint16_t* d_audio, int64_t n_audio, int channels, const double* audio_times,
                     const double* video_times, int n_nodes, bool no_pitch_correction, StretchTimes& t,
                     std::string& err);
 
-// int16 PCM (planar or interleaved) -> float16 planar
-int stretch_load_pcm(hipStream_t stream, const int16_t* d_pcm, int64_t n, int channels, int planar, uint16_t* d_out);
-// describealign.py:1135-1148; factors[channels] receives video_std / audio_std
-int stretch_match_loudness(StretchState* s, hipStream_t stream, uint16_t* d_video, int64_t n_video, uint16_t* d_audio,
-                           int64_t n_audio, int channels, double* factors, std::string& err);
+// Device float16 arrays are planar with this channel stride (elements), a multiple of 64 so that
+// every channel starts 128-byte aligned.
+int64_t stretch_channel_stride(int64_t n);
+
+// describealign.py:156 + :1135-1148 on int16 PCM (planar or interleaved): float16 conversion and
+// loudness matching in two streaming passes (moments, then convert + scale).  factors[channels]
+// receives video_std / audio_std.
+int stretch_prepare(StretchState* s, hipStream_t stream, const int16_t* d_pcm_video, int64_t n_video, int planar_video,
+                    const int16_t* d_pcm_audio, int64_t n_audio, int planar_audio, int channels, uint16_t* d_video,
+                    uint16_t* d_audio, double* factors, std::string& err);
 // describealign.py:1153 and :136: peak normalise, convert to int16, interleave
 int stretch_finish(StretchState* s, hipStream_t stream, uint16_t* d_video, int64_t n_video, int channels,
                    int16_t* d_out_interleaved, std::string& err);

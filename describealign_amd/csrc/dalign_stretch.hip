@@ -69,25 +69,61 @@ struct DBuf {
 };
 
 // ------------------------------------------------------------------------------------ bracket
+// The loudness / peak steps around replace_aligned_segments are pure streaming passes.  Every
+// thread handles 8 consecutive frames with 16-byte accesses (scalar only where a pointer is not
+// 16-byte aligned or at the ragged end); float16 device arrays are planar with a channel stride
+// that is a multiple of 64 elements so that every channel starts aligned.
 
-__global__ void k_i16_to_f16(const int16_t* __restrict__ pcm, int64_t n, int channels, int64_t stride_c,
-                             int64_t stride_n, half_t* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  for (int c = 0; c < channels; ++c) out[(int64_t)c * n + i] = (half_t)(float)pcm[c * stride_c + i * stride_n];   // (:156)
+struct Pcm { const int16_t* p; int64_t n; int planar; };
+
+template <int C>
+__device__ __forceinline__ void load_frames8(const Pcm& s, int64_t i0, int16_t (&v)[C][8]) {
+  const int64_t left = s.n - i0;
+  if (C == 2 && !s.planar) {
+    const int16_t* p = s.p + 2 * i0;
+    if (left >= 8 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+      const int4 a = reinterpret_cast<const int4*>(p)[0], b = reinterpret_cast<const int4*>(p)[1];
+      const int w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { v[0][k] = (int16_t)(w[k] & 0xffff); v[C - 1][k] = (int16_t)(w[k] >> 16); }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { v[0][k] = k < left ? p[2 * k] : (int16_t)0; v[C - 1][k] = k < left ? p[2 * k + 1] : (int16_t)0; }
+    }
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int16_t* p = s.p + (int64_t)c * s.n + i0;
+    if (left >= 8 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+      const int4 a = *reinterpret_cast<const int4*>(p);
+      const int w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[c][2 * k] = (int16_t)(w[k] & 0xffff); v[c][2 * k + 1] = (int16_t)(w[k] >> 16); }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[c][k] = k < left ? p[k] : (int16_t)0;
+    }
+  }
 }
 
-// per block: sum(x) over all channels and sum(x^2) per channel, float64 (:1137-1139)
-__global__ void __launch_bounds__(256) k_moments(const half_t* __restrict__ x, int64_t n, int channels,
-                                                 double* __restrict__ partials /* [blocks][3] */) {
-  double s = 0, q0 = 0, q1 = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double a = (double)x[i];
-    s += a; q0 += a * a;
-    if (channels == 2) { const double b = (double)x[n + i]; s += b; q1 += b * b; }
+// per block: sum(x) over all channels and sum(x^2) per channel in float64, x = float16(pcm) (:156, :1137-1139)
+template <int C>
+__global__ void __launch_bounds__(256) k_pcm_moments(const Pcm s, double* __restrict__ partials /* [blocks][3] */) {
+  double sum = 0, q0 = 0, q1 = 0;
+  const int64_t groups = (s.n + 7) / 8;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+    int16_t v[C][8];
+    load_frames8<C>(s, 8 * g, v);               // frames past the end read as 0 and add nothing
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double a = (double)(half_t)(float)v[0][k];
+      sum += a; q0 += a * a;
+      if (C == 2) { const double b = (double)(half_t)(float)v[C - 1][k]; sum += b; q1 += b * b; }
+    }
   }
   __shared__ double red[3][256];
-  red[0][threadIdx.x] = s; red[1][threadIdx.x] = q0; red[2][threadIdx.x] = q1;
+  red[0][threadIdx.x] = sum; red[1][threadIdx.x] = q0; red[2][threadIdx.x] = q1;
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
     if ((int)threadIdx.x < w)
@@ -98,19 +134,50 @@ __global__ void __launch_bounds__(256) k_moments(const half_t* __restrict__ x, i
     for (int k = 0; k < 3; ++k) partials[3 * blockIdx.x + k] = red[k][0];
 }
 
-// x = float16(float64(x) / f) or float16(float64(x) * f)  (:1144-1148: float16 array op float64 scalar)
-__global__ void k_scale(half_t* __restrict__ x, int64_t n, double f, int divide) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double a = (double)x[i];
-  x[i] = to_half(divide ? a / f : a * f);
+struct Gain { int op[2]; double f[2]; };       // per channel: 0 keep, 1 divide by f, 2 multiply by f (:1144-1148)
+
+// float16(pcm) (:156), then the float16-array-by-float64-scalar loudness gain, planar out
+template <int C>
+__global__ void __launch_bounds__(256) k_pcm_to_f16(const Pcm s, const Gain g, half_t* __restrict__ out, int64_t out_stride) {
+  const int64_t grp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i0 = 8 * grp;
+  if (i0 >= s.n) return;
+  int16_t v[C][8];
+  load_frames8<C>(s, i0, v);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    half_t h[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      h[k] = (half_t)(float)v[c][k];
+      if (g.op[c] == 1) h[k] = to_half((double)h[k] / g.f[c]);
+      else if (g.op[c] == 2) h[k] = to_half((double)h[k] * g.f[c]);
+    }
+    half_t* o = out + (int64_t)c * out_stride + i0;
+    if (s.n - i0 >= 8) *reinterpret_cast<int4*>(o) = *reinterpret_cast<const int4*>(h);
+    else for (int k = 0; k < (int)(s.n - i0); ++k) o[k] = h[k];
+  }
 }
 
-__global__ void __launch_bounds__(256) k_absmax(const half_t* __restrict__ x, int64_t n, unsigned int* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_absmax(const half_t* __restrict__ x, int64_t n, int channels, int64_t stride,
+                                                unsigned int* __restrict__ out) {
   unsigned int m = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const unsigned short b = reinterpret_cast<const unsigned short*>(x)[i] & 0x7fffu;    // |x| as ordered bits
-    m = m > b ? m : b;
+  const int64_t groups = (n + 7) / 8;
+  for (int c = 0; c < channels; ++c) {
+    const unsigned short* p = reinterpret_cast<const unsigned short*>(x) + (int64_t)c * stride;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+      if (n - 8 * g >= 8) {
+        const int4 a = *reinterpret_cast<const int4*>(p + 8 * g);
+        const unsigned int w[4] = {(unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned int lo = w[k] & 0x7fffu, hi = (w[k] >> 16) & 0x7fffu;      // |x| as ordered bits
+          m = m > lo ? m : lo; m = m > hi ? m : hi;
+        }
+      } else {
+        for (int64_t i = 8 * g; i < n; ++i) { const unsigned int b = p[i] & 0x7fffu; m = m > b ? m : b; }
+      }
+    }
   }
   __shared__ unsigned int red[256];
   red[threadIdx.x] = m; __syncthreads();
@@ -122,20 +189,38 @@ __global__ void __launch_bounds__(256) k_absmax(const half_t* __restrict__ x, in
 }
 
 // (:1153) video *= float16(32766 / max|video|) in float16 arithmetic, then (:136) int16, interleaved
-__global__ void k_finish(const half_t* __restrict__ x, int64_t n, int channels, const unsigned int* __restrict__ peak_bits,
-                         int16_t* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+template <int C>
+__global__ void __launch_bounds__(256) k_finish(const half_t* __restrict__ x, int64_t n, int64_t stride,
+                                                const unsigned int* __restrict__ peak_bits, int16_t* __restrict__ out) {
+  const int64_t i0 = 8 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+  if (i0 >= n) return;
   const unsigned short pb = (unsigned short)*peak_bits;
   const half_t peak = *reinterpret_cast<const half_t*>(&pb);
   const half_t top = (half_t)32766.0f;                                  // 32768 in float16
   const half_t gain = (half_t)((float)top / (float)peak);
-  for (int c = 0; c < channels; ++c) {
-    const half_t v = (half_t)((float)x[(int64_t)c * n + i] * (float)gain);
-    // numpy's float16 -> int16 cast goes through int32 and wraps: the reference's own peak sample
-    // (32768 after the float16 rescale) comes out as -32768; same here
-    const int32_t wide = (int32_t)(float)v;
-    out[i * channels + c] = (int16_t)(wide & 0xffff);
+  const int cnt = n - i0 >= 8 ? 8 : (int)(n - i0);
+  int16_t r[8 * C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    half_t h[8];
+    const half_t* p = x + (int64_t)c * stride + i0;
+    if (cnt == 8) *reinterpret_cast<int4*>(h) = *reinterpret_cast<const int4*>(p);
+    else for (int k = 0; k < 8; ++k) h[k] = k < cnt ? p[k] : (half_t)0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const half_t v = (half_t)((float)h[k] * (float)gain);
+      // numpy's float16 -> int16 cast goes through int32 and wraps: the reference's own peak sample
+      // (32768 after the float16 rescale) comes out as -32768; same here
+      const int32_t wide = (int32_t)(float)v;
+      r[k * C + c] = (int16_t)(wide & 0xffff);
+    }
+  }
+  int16_t* o = out + i0 * C;
+  if (cnt == 8) {
+#pragma unroll
+    for (int q = 0; q < C; ++q) reinterpret_cast<int4*>(o)[q] = reinterpret_cast<const int4*>(r)[q];
+  } else {
+    for (int k = 0; k < cnt * C; ++k) o[k] = r[k];
   }
 }
 
@@ -873,22 +958,23 @@ int ensure_hann(StretchState* s, hipStream_t stream, std::string& err) {
 
 }  // namespace
 
-int stretch_load_pcm(hipStream_t stream, const int16_t* d_pcm, int64_t n, int channels, int planar, uint16_t* d_out) {
-  if (n <= 0) return 0;
-  const int64_t sc = planar ? n : 1, sn = planar ? 1 : channels;
-  hipLaunchKernelGGL(k_i16_to_f16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_pcm, n, channels, sc, sn,
-                     reinterpret_cast<half_t*>(d_out));
-  return hipGetLastError() == hipSuccess ? 0 : DA_ERR_DEVICE;
-}
+int64_t stretch_channel_stride(int64_t n) { return (n + 63) / 64 * 64; }
 
-int stretch_match_loudness(StretchState* s, hipStream_t stream, uint16_t* d_video, int64_t n_video, uint16_t* d_audio,
-                           int64_t n_audio, int channels, double* factors, std::string& err) {
-  const int blocks = 1024;
+int stretch_prepare(StretchState* s, hipStream_t stream, const int16_t* d_pcm_video, int64_t n_video, int planar_video,
+                    const int16_t* d_pcm_audio, int64_t n_audio, int planar_audio, int channels, uint16_t* d_video,
+                    uint16_t* d_audio, double* factors, std::string& err) {
+  const int blocks = 2048;
   S_TRY(s->partials.ensure(sizeof(double) * 3 * blocks * 2));
   double* pv = s->partials.as<double>();
   double* pa = pv + 3 * blocks;
-  hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<half_t*>(d_video), n_video, channels, pv);
-  hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<half_t*>(d_audio), n_audio, channels, pa);
+  const Pcm sv{d_pcm_video, n_video, planar_video}, sa{d_pcm_audio, n_audio, planar_audio};
+  if (channels == 2) {
+    hipLaunchKernelGGL(k_pcm_moments<2>, dim3(blocks), dim3(256), 0, stream, sv, pv);
+    hipLaunchKernelGGL(k_pcm_moments<2>, dim3(blocks), dim3(256), 0, stream, sa, pa);
+  } else {
+    hipLaunchKernelGGL(k_pcm_moments<1>, dim3(blocks), dim3(256), 0, stream, sv, pv);
+    hipLaunchKernelGGL(k_pcm_moments<1>, dim3(blocks), dim3(256), 0, stream, sa, pa);
+  }
   S_TRY(hipGetLastError());
   std::vector<double> h(3 * blocks * 2);
   S_TRY(hipMemcpyAsync(h.data(), pv, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream));
@@ -900,18 +986,22 @@ int stretch_match_loudness(StretchState* s, hipStream_t stream, uint16_t* d_vide
     const double avg = sum / cnt;
     for (int c = 0; c < channels; ++c) out[c] = std::sqrt(q[c] / cnt - avg * avg);
   };
-  double sv[2], sa[2];
-  spread(h.data(), n_video, sv); spread(h.data() + 3 * blocks, n_audio, sa);
+  double dv[2], da_[2];
+  spread(h.data(), n_video, dv); spread(h.data() + 3 * blocks, n_audio, da_);
+  Gain gv{}, ga{};
   for (int c = 0; c < channels; ++c) {
-    const double f = sv[c] / sa[c];
+    const double f = dv[c] / da_[c];
     factors[c] = f;
-    if (f > 1) {                                                         // (:1144-1148)
-      hipLaunchKernelGGL(k_scale, dim3((unsigned)((n_video + 255) / 256)), dim3(256), 0, stream,
-                         reinterpret_cast<half_t*>(d_video) + (int64_t)c * n_video, n_video, f, 1);
-    } else {
-      hipLaunchKernelGGL(k_scale, dim3((unsigned)((n_audio + 255) / 256)), dim3(256), 0, stream,
-                         reinterpret_cast<half_t*>(d_audio) + (int64_t)c * n_audio, n_audio, f, 0);
-    }
+    if (f > 1) { gv.op[c] = 1; gv.f[c] = f; }                            // (:1144-1148): only the louder track is scaled
+    else { ga.op[c] = 2; ga.f[c] = f; }
+  }
+  const unsigned gvb = (unsigned)(((n_video + 7) / 8 + 255) / 256), gab = (unsigned)(((n_audio + 7) / 8 + 255) / 256);
+  if (channels == 2) {
+    hipLaunchKernelGGL(k_pcm_to_f16<2>, dim3(gvb), dim3(256), 0, stream, sv, gv, reinterpret_cast<half_t*>(d_video), stretch_channel_stride(n_video));
+    hipLaunchKernelGGL(k_pcm_to_f16<2>, dim3(gab), dim3(256), 0, stream, sa, ga, reinterpret_cast<half_t*>(d_audio), stretch_channel_stride(n_audio));
+  } else {
+    hipLaunchKernelGGL(k_pcm_to_f16<1>, dim3(gvb), dim3(256), 0, stream, sv, gv, reinterpret_cast<half_t*>(d_video), stretch_channel_stride(n_video));
+    hipLaunchKernelGGL(k_pcm_to_f16<1>, dim3(gab), dim3(256), 0, stream, sa, ga, reinterpret_cast<half_t*>(d_audio), stretch_channel_stride(n_audio));
   }
   S_TRY(hipGetLastError());
   return 0;
@@ -919,12 +1009,18 @@ int stretch_match_loudness(StretchState* s, hipStream_t stream, uint16_t* d_vide
 
 int stretch_finish(StretchState* s, hipStream_t stream, uint16_t* d_video, int64_t n_video, int channels,
                    int16_t* d_out_interleaved, std::string& err) {
+  const int64_t stride = stretch_channel_stride(n_video);
   S_TRY(s->peak.ensure(64));
   S_TRY(hipMemsetAsync(s->peak.p, 0, 4, stream));
-  hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, stream, reinterpret_cast<half_t*>(d_video), n_video * channels,
+  hipLaunchKernelGGL(k_absmax, dim3(2048), dim3(256), 0, stream, reinterpret_cast<half_t*>(d_video), n_video, channels, stride,
                      s->peak.as<unsigned int>());
-  hipLaunchKernelGGL(k_finish, dim3((unsigned)((n_video + 255) / 256)), dim3(256), 0, stream,
-                     reinterpret_cast<half_t*>(d_video), n_video, channels, s->peak.as<unsigned int>(), d_out_interleaved);
+  const unsigned gb = (unsigned)(((n_video + 7) / 8 + 255) / 256);
+  if (channels == 2)
+    hipLaunchKernelGGL(k_finish<2>, dim3(gb), dim3(256), 0, stream, reinterpret_cast<half_t*>(d_video), n_video, stride,
+                       s->peak.as<unsigned int>(), d_out_interleaved);
+  else
+    hipLaunchKernelGGL(k_finish<1>, dim3(gb), dim3(256), 0, stream, reinterpret_cast<half_t*>(d_video), n_video, stride,
+                       s->peak.as<unsigned int>(), d_out_interleaved);
   S_TRY(hipGetLastError());
   return 0;
 }
@@ -932,6 +1028,7 @@ int stretch_finish(StretchState* s, hipStream_t stream, uint16_t* d_video, int64
 int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, int64_t n_video, const uint16_t* d_audio_u,
                     int64_t n_audio, int channels, const double* audio_times, const double* video_times, int n_nodes,
                     bool no_pitch_correction, StretchTimes& tm, std::string& err) {
+  const int64_t v_stride = stretch_channel_stride(n_video), a_stride = stretch_channel_stride(n_audio);
   half_t* d_video = reinterpret_cast<half_t*>(d_video_u);
   const half_t* d_audio = reinterpret_cast<const half_t*>(d_audio_u);
   s->schedules.clear();
@@ -990,13 +1087,13 @@ int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, in
       S_TRY(hipEventRecord(s->e0, stream));
       static const SplineRows rows = spline_rows();
       hipLaunchKernelGGL(k_resample_tile, dim3(kMaxTiles, (unsigned)chunks.size(), channels), dim3(256), 0, stream,
-                         s->res_chunks.as<ResChunk>(), d_audio, n_audio, d_video, n_video, rows);
+                         s->res_chunks.as<ResChunk>(), d_audio, a_stride, d_video, v_stride, rows);
       if (any_small) {
         const int threads = (int)chunks.size() * channels;
         hipLaunchKernelGGL(k_spline_solve, dim3((threads + 63) / 64), dim3(64), 0, stream, s->res_chunks.as<ResChunk>(),
-                           (int)chunks.size(), channels, d_audio, n_audio, s->coef.as<double>());
+                           (int)chunks.size(), channels, d_audio, a_stride, s->coef.as<double>());
         hipLaunchKernelGGL(k_spline_eval, dim3((kResChunk + 255) / 256, (unsigned)chunks.size()), dim3(256), 0, stream,
-                           s->res_chunks.as<ResChunk>(), channels, s->coef.as<double>(), d_video, n_video);
+                           s->res_chunks.as<ResChunk>(), channels, s->coef.as<double>(), d_video, v_stride);
       }
       S_TRY(hipGetLastError());
       S_TRY(hipEventRecord(s->e1, stream));
@@ -1054,9 +1151,9 @@ int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, in
   S_TRY(hipEventRecord(s->e0, stream));
   hipLaunchKernelGGL(k_fill_table, dim3((unsigned)((table_total + 255) / 256)), dim3(256), 0, stream, s->where.as<int16_t>(),
                      s->loss.as<double>(), table_total);
-  hipLaunchKernelGGL(k_chunk_rms, dim3(NC), dim3(64), 0, stream, d_audio, channels, n_audio, s->segs.as<SegDesc>(),
+  hipLaunchKernelGGL(k_chunk_rms, dim3(NC), dim3(64), 0, stream, d_audio, channels, a_stride, s->segs.as<SegDesc>(),
                      s->corr_chunks.as<CorrChunk>(), s->energy.as<double>(), s->eps.as<double>());
-  hipLaunchKernelGGL(k_lag_table, dim3(NC, max_lags), dim3(64), 0, stream, d_audio, channels, n_audio,
+  hipLaunchKernelGGL(k_lag_table, dim3(NC, max_lags), dim3(64), 0, stream, d_audio, channels, a_stride,
                      s->segs.as<SegDesc>(), s->corr_chunks.as<CorrChunk>(), s->lags.as<int32_t>(), s->energy.as<double>(),
                      s->eps.as<double>(), s->where.as<int16_t>(), s->loss.as<double>());
   S_TRY(hipGetLastError());
@@ -1087,8 +1184,8 @@ int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, in
     const Interval& iv = *st[k];
     const SegDesc& d = segs[k];
     SpliceArgs sa{};
-    sa.seg = d_audio + iv.x0; sa.n_in = d.n_in; sa.in_stride = n_audio;
-    sa.out = d_video + iv.y0; sa.n_out = d.n_out; sa.out_stride = n_video; sa.channels = channels;
+    sa.seg = d_audio + iv.x0; sa.n_in = d.n_in; sa.in_stride = a_stride;
+    sa.out = d_video + iv.y0; sa.n_out = d.n_out; sa.out_stride = v_stride; sa.channels = channels;
     sa.pin = s->plan_in.as<int64_t>() + d.plan_off; sa.pout = s->plan_out.as<int64_t>() + d.plan_off;
     sa.count = s->counts.as<int32_t>() + 2 * k;
     sa.rise = s->hann.as<double>(); sa.fall = s->hann.as<double>() + kSW;

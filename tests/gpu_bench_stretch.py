@@ -14,6 +14,7 @@ from describealign_amd import _native, synth, align as A
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 1320.0
 rate = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+with_oracle = len(sys.argv) > 3 and sys.argv[3] == "oracle"
 pair = synth.make_pair(5, secs, n_jumps=10, first_gap=min(200.0, secs / 6), channels=2, rate_change=rate)
 c = _native.Context(0, _native.PREC_F32)
 c.pcm_upload(0, pair.video); c.pcm_upload(1, pair.audio)
@@ -40,5 +41,18 @@ line = dict(seconds=secs, rate_change=rate, nodes=len(x), wall_ms=round(wall * 1
             viterbi_ms=round(st["viterbi_ms"], 3), splice_ms=round(st["splice_ms"], 3), splice_points=st["splice_points"],
             finish_ms=round(st["stretch_finish_ms"], 3), schedules=[len(s) for s in c.stretch_schedules()],
             factors=[round(float(f), 4) for f in fac])
+if with_oracle:      # the CPU restatement on the same nodes: timing beside the GPU path and full-size parity
+  from oracle import stretch_oracle as SO
+  t0 = time.perf_counter()
+  v, a = pair.video.astype(np.float16), pair.audio.astype(np.float16)
+  SO.match_loudness(v, a)
+  SO.replace_aligned_segments(v, a, x, y, False)
+  SO.normalise_peak(v)
+  want = v.astype(np.int16).T
+  cpu = time.perf_counter() - t0
+  line["cpu_oracle_s"] = round(cpu, 2)
+  line["cpu_audio_hours_per_s"] = round(secs / 3600.0 / cpu, 5)
+  line["samples_differing_from_oracle"] = int((want != out).sum())
+  line["samples_total"] = int(want.size)
 print(json.dumps(line))
 c.close()
