@@ -355,17 +355,17 @@ __global__ void __launch_bounds__(256) k_spline_eval(const ResChunk* __restrict_
 // ---- fused tile kernel --------------------------------------------------------------------
 // The collocation matrix is (1/8, 3/4, 1/8) away from the first/last three rows, so the solution
 // at row i depends on the data at distance d with weight ~0.17^d.  A workgroup therefore solves a
-// TILE of 4096 coefficient rows independently of the rest of the block: every thread runs the
+// TILE of 4064 coefficient rows independently of the rest of the block: every thread runs the
 // Thomas recurrences over its own 16 rows after a 20-row warm-up (error < 1e-15 relative; at the
 // true ends of the spline the exact boundary rows are used instead), coefficients stay in LDS, and
 // the same workgroup evaluates the output points that fall on its rows.  HBM traffic is the float16
 // samples read once and the float16 result written once.
-constexpr int kTileRows = 4096;          // coefficient rows solved per workgroup
+constexpr int kTileRows = 4064;          // coefficient rows solved per workgroup (+ kApron = 256 threads x kOwn)
 constexpr int kTileStep = kTileRows - 2; // consecutive tiles overlap by two rows (a point needs c[ell-2..ell])
 constexpr int kOwn = 16;                 // rows per thread
 constexpr int kWarm = 20;                // warm-up rows
 constexpr int kApron = 32;               // forward-pass rows beyond the tile (warm-up of the backward pass)
-constexpr int kMaxTiles = 27;            // ceil((1.1e5 + 4) / 4094): the rate is within +-10 % (:33)
+constexpr int kMaxTiles = 28;            // ceil((1.1e5 + 4) / 4062): the rate is within +-10 % (:33)
 
 struct SplineRows {            // tabulated on the host with the same recurrences (n >= kFusedMinRows)
   double lo_front[kFront], w_front[kFront], cp_front[kFront];
@@ -384,6 +384,7 @@ __global__ void __launch_bounds__(256) k_resample_tile(const ResChunk* __restric
   const int32_t R0 = (int32_t)blockIdx.x * kTileStep - 2;            // first coefficient row of the tile
   if (n < kFusedMinRows || R0 + 2 >= n) return;
   const int ch = blockIdx.z;
+  const double w_mid = R.w_mid, cp_mid = R.cp_mid;
   constexpr int kRowsY = kTileRows + kApron + kWarm;                  // rows [R0 - kWarm, R0 + 4128)
   __shared__ half_t ys[kRowsY + 2 * (kRowsY / 16) + 8];
   __shared__ double cs[kTileRows + kApron + (kTileRows + kApron) / 16 + 4];
@@ -394,6 +395,7 @@ __global__ void __launch_bounds__(256) k_resample_tile(const ResChunk* __restric
     ys[pad_y(r)] = (row >= 0 && row < n) ? y[row] : (half_t)0.0f;
   }
   __syncthreads();
+#ifndef DA_DBG_RS_NOSOLVE
   // ---- forward elimination: task j owns rows [R0 + 16 j, +16)
   for (int task = threadIdx.x; task < (kTileRows + kApron) / kOwn; task += 256) {
     const int32_t lo_row = R0 + kOwn * task;
@@ -403,12 +405,31 @@ __global__ void __launch_bounds__(256) k_resample_tile(const ResChunk* __restric
     int32_t s0 = first - kWarm;
     if (s0 < kFront) s0 = 0;                                         // reach the true first rows instead of guessing
     double dp = 0.0;
-    for (int32_t i = s0; i < last; ++i) {
-      double lo, w;
-      if (i < kFront) { lo = R.lo_front[i]; w = R.w_front[i]; }
-      else if (i >= n - 3) { lo = R.lo_tail[i - (n - 3)]; w = R.w_tail[i - (n - 3)]; }
-      else { lo = 0.125; w = R.w_mid; }
-      dp = ((double)ys[pad_y(i - ybase)] - lo * dp) * w;
+    int32_t i = s0;
+    if (s0 == 0) {                                                   // the spline's true first rows (first tile only)
+      const int32_t fe = kFront < last ? kFront : last;
+      for (; i < fe; ++i) {
+        dp = ((double)ys[pad_y(i - ybase)] - R.lo_front[i] * dp) * R.w_front[i];
+        if (i >= first) cs[pad_c(i - R0)] = dp;
+      }
+    }
+    const int32_t ie = last < n - 3 ? last : n - 3;
+    for (; i + 8 <= ie; i += 8) {                                    // uniform rows: constants in registers, LDS only;
+      double yv[8];                                                  // the reads go out together ahead of the dependent chain
+#pragma unroll
+      for (int e = 0; e < 8; ++e) yv[e] = (double)ys[pad_y(i + e - ybase)];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        dp = (yv[e] - 0.125 * dp) * w_mid;
+        if (i + e >= first) cs[pad_c(i + e - R0)] = dp;
+      }
+    }
+    for (; i < ie; ++i) {
+      dp = ((double)ys[pad_y(i - ybase)] - 0.125 * dp) * w_mid;
+      if (i >= first) cs[pad_c(i - R0)] = dp;
+    }
+    for (; i < last; ++i) {                                          // the true last three rows (last tile only)
+      dp = ((double)ys[pad_y(i - ybase)] - R.lo_tail[i - (n - 3)] * dp) * R.w_tail[i - (n - 3)];
       if (i >= first) cs[pad_c(i - R0)] = dp;
     }
   }
@@ -419,18 +440,35 @@ __global__ void __launch_bounds__(256) k_resample_tile(const ResChunk* __restric
     const int task = threadIdx.x;
     const int32_t lo_row = R0 + kOwn * task;
     const int32_t first = lo_row < 0 ? 0 : lo_row;
-    const int32_t last = lo_row + kOwn < n ? lo_row + kOwn : n;
+    const int32_t last = task >= kTileRows / kOwn ? first : (lo_row + kOwn < n ? lo_row + kOwn : n);   // apron rows are not finished
     if (first < last) {
       int32_t e = last + kWarm;
       if (e > n) e = n;
       if (e > R0 + kTileRows + kApron) e = R0 + kTileRows + kApron;
       double next = 0.0;
-      auto pivot = [&](int32_t i) { return i < kFront ? R.cp_front[i] : (i >= n - 3 ? R.cp_tail[i - (n - 3)] : R.cp_mid); };
-      for (int32_t i = e - 1; i >= last; --i) next = cs[pad_c(i - R0)] - pivot(i) * next;       // warm-up
+      auto pivot = [&](int32_t i) -> double {
+        if (i >= kFront && i < n - 3) return cp_mid;                 // register constant; the tables only at the true ends
+        return i < kFront ? R.cp_front[i] : R.cp_tail[i - (n - 3)];
+      };
+      int32_t i = e - 1;
+      for (; i >= last && (i >= n - 3 || i - 3 < last); --i) next = cs[pad_c(i - R0)] - pivot(i) * next;   // true last rows / remainder
+      for (; i - 3 >= last && i - 3 >= kFront; i -= 4) {                                           // warm-up, uniform rows
+        double d4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d4[q] = cs[pad_c(i - q - R0)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) next = d4[q] - cp_mid * next;
+      }
+      for (; i >= last; --i) next = cs[pad_c(i - R0)] - pivot(i) * next;
+#pragma unroll
+      for (int k = 0; k < kOwn; ++k) {                               // this thread's own dp values, read together
+        const int32_t r = lo_row + k;
+        cown[k] = (r >= first && r < last) ? cs[pad_c(r - R0)] : 0.0;
+      }
 #pragma unroll
       for (int k = kOwn - 1; k >= 0; --k) {
-        const int32_t i = lo_row + k;
-        if (i >= first && i < last) { next = cs[pad_c(i - R0)] - pivot(i) * next; cown[k] = next; }
+        const int32_t r = lo_row + k;
+        if (r >= first && r < last) { next = cown[k] - pivot(r) * next; cown[k] = next; }
       }
     }
     __syncthreads();
@@ -441,6 +479,7 @@ __global__ void __launch_bounds__(256) k_resample_tile(const ResChunk* __restric
     }
   }
   __syncthreads();
+#endif
   // ---- evaluate the points whose knot interval ell lies in [E0, E1)
   const int32_t E0 = R0 + 2 < 2 ? 2 : R0 + 2;
   const int32_t E1 = R0 + kTileRows < n ? R0 + kTileRows : n;
@@ -455,6 +494,9 @@ __global__ void __launch_bounds__(256) k_resample_tile(const ResChunk* __restric
   const int64_t k0 = E0 <= 2 ? 0 : count_below((double)ck.b0 + (double)E0 - 1.5);
   const int64_t k1 = E1 >= n ? (int64_t)ck.count : count_below((double)ck.b0 + (double)E1 - 1.5);
   half_t* out = video + (int64_t)ch * n_video + ck.out_abs;
+#ifdef DA_DBG_RS_NOEVAL
+  if (k0 >= 0) { if (threadIdx.x == 0 && k0 < k1) out[k0] = (half_t)(float)cs[pad_c(3)]; return; }
+#endif
   for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
     const double x = x_of(k);
     double v = 0.0;
