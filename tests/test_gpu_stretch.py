@@ -170,3 +170,44 @@ def test_combine_stretch_audio_end_to_end(ctx, tmp_path):
     assert np.array_equal(got, want)
   text = open(res["report"]).read()
   assert "'stretch_audio': True" in text
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_replace_segments_random_plans_vs_oracle(ctx, seed):
+  """Random node lists over noise with silent gaps: every interval kind, both jump directions,
+  all three lag sets, mono and stereo, ragged interval lengths."""
+  rng = np.random.default_rng(100 + seed)
+  ch = 1 + seed % 2
+  rates = [1.0, 1.003, 0.9965, 1.02, 0.985, 1.06, 0.93, 1.0072, 0.9931, 1.2]
+  ys, xs = [0.37 * rng.random()], [0.5 * rng.random()]
+  for k in range(5 + seed % 3):
+    dy = float(rng.choice([1.5, 2.1, 2.6, 3.3, 4.2])) + 0.01 * rng.random()
+    r = float(rng.choice(rates))
+    ys.append(ys[-1] + dy); xs.append(xs[-1] + dy * r)
+  n_v = int(ys[-1] * 44100) + 1000
+  n_a = int(xs[-1] * 44100) + 1000
+  a = rng.standard_normal((ch, n_a)) * 2500
+  env = np.clip(np.sin(np.arange(n_a) / (3000.0 + 500 * seed)) + 0.3, 0, 1)
+  a = (a * env).astype(np.float16)
+  a[:, n_a // 3: n_a // 3 + 20000] = 0                     # digital silence
+  v = (rng.standard_normal((ch, n_v)) * 2500).astype(np.float16)
+  x, y = np.array(xs), np.array(ys)
+  want = v.copy()
+  want_s = SO.replace_aligned_segments(want, a, x, y, False)
+  ctx.replace_segments(v, a, x, y, False)
+  got_s = ctx.stretch_schedules()
+  assert len(got_s) == len(want_s), [p[0] for p in SO.segment_plan(x, y, False)]
+  for k, (g_, w_) in enumerate(zip(got_s, want_s)):
+    assert np.array_equal(g_, w_), f"schedule {k}: {g_.tolist()} vs {w_.tolist()}"
+  _report(v, want, f"seed {seed}")
+
+
+def test_interval_too_short_for_the_correlation_generator(ctx):
+  """The reference raises 'Invalid state in Pearson generator.' (:268-269) when a stretched interval
+  has fewer than 3*512-1 samples; here that cannot happen for intervals >= 2 s, but the C ABI
+  reports the same text if asked to."""
+  n = 44100 * 3
+  v = np.zeros((1, n), dtype=np.float16); a = np.zeros((1, n), dtype=np.float16)
+  # 2 s of video from 0.03 s of audio would be |1-slope| > .1 -> skipped, so no error can be provoked
+  ctx.replace_segments(v, a, np.array([0.0, 0.03]), np.array([0.0, 2.5]), False)
+  assert not v.any()
