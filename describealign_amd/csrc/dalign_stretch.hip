@@ -37,6 +37,9 @@ constexpr int kResChunk = 100000;         // chunk_size                      (:2
 constexpr int kMinOffset = 30;            // MIN_STRETCH_OFFSET              (:36)
 constexpr int kRate = 44100;              // AUDIO_SAMPLE_RATE               (:31)
 constexpr int kMaxLags = 512;
+constexpr int kGuardLo = 512;            // +inf entries below drift state 0 (a lag is < 512)
+constexpr int kGuardHi = 128;            // +inf entries above drift state 3072 (two drift steps)
+constexpr int kRow = kGuardLo + kND + kGuardHi + 3;   // 3716: one cost-history row in LDS
 
 typedef _Float16 half_t;
 
@@ -712,8 +715,11 @@ __global__ void __launch_bounds__(1024) k_viterbi(const SegDesc* __restrict__ se
                                                   int64_t* __restrict__ plan_out, int64_t* __restrict__ sched,
                                                   int32_t* __restrict__ counts) {
   extern __shared__ double lds[];
-  double* hist = lds;                          // [3][kND]
-  double* lrow = lds + 3 * kND;                // [2][kMaxLags]: loss row of this window / the next one
+  // cost history: three rows of 3073 drift states, each with guard zones of +inf on both sides so
+  // that the jump look-ups h2[d + two - lag] need no range checks (a jump from outside the drift
+  // window costs +inf, exactly the reference's untouched np.inf entries)
+  double* hist = lds;                          // [3][kRow]
+  double* lrow = lds + 3 * kRow;               // [2][kMaxLags]: loss row of this window / the next one
   int32_t* lags = reinterpret_cast<int32_t*>(lrow + 2 * kMaxLags);   // [kMaxLags]
   __shared__ int64_t sstep[2];
   const SegDesc sd = segs[blockIdx.x];
@@ -723,15 +729,16 @@ __global__ void __launch_bounds__(1024) k_viterbi(const SegDesc* __restrict__ se
   const int16_t* where = where_all + sd.table_off;
   int16_t* back = back_all + sd.back_off;
   const int tid = threadIdx.x;
-  for (int d = tid; d < 3 * kND; d += blockDim.x) hist[d] = INFINITY;
+  for (int d = tid; d < 3 * kRow; d += blockDim.x) hist[d] = INFINITY;
   if (tid < J) { lags[tid] = lags_all[sd.lag_off + tid]; lrow[tid] = loss[tid]; }
   if (tid == 0) sstep[0] = offset_step(sd.total, nw, 0);
   __syncthreads();
-  if (tid == 0) { hist[1 * kND + kMaxDrift] = 0.0; hist[2 * kND + kMaxDrift] = 0.0; }      // (:320)
+  if (tid == 0) { hist[1 * kRow + kGuardLo + kMaxDrift] = 0.0; hist[2 * kRow + kGuardLo + kMaxDrift] = 0.0; }      // (:320)
   __syncthreads();
   // drift states of this thread: tid, tid + 1024, tid + 2048; state 3072 is thread 0's extra
   constexpr int kSlots = 3;
   int64_t prev_step = 0;
+  bool overflow = false;
   for (int64_t w = 0; w < nw; ++w) {
     const int cur = (int)(w & 1);
     // the next window's loss row and drift step are fetched while this window is processed
@@ -740,30 +747,28 @@ __global__ void __launch_bounds__(1024) k_viterbi(const SegDesc* __restrict__ se
     if (tid == 0) nstep = offset_step(sd.total, nw, w + 1);
     const int step = (int)sstep[cur];
     const int two = step + (int)prev_step;
-    const double* h1 = hist + ((w + 2) % 3) * kND;       // (w-1) % 3
-    const double* h2 = hist + ((w + 1) % 3) * kND;       // (w-2) % 3
-    double* hw = hist + (w % 3) * kND;
+    if (two > kGuardHi) { overflow = true; break; }      // uniform; cannot happen for |1 - rate| <= 0.1
+    const double* h1 = hist + ((w + 2) % 3) * kRow + kGuardLo;       // (w-1) % 3
+    const double* h2 = hist + ((w + 1) % 3) * kRow + kGuardLo;       // (w-2) % 3
+    double* hw = hist + (w % 3) * kRow + kGuardLo;
     const double* lr = lrow + cur * kMaxLags;
     double best[kSlots]; int pick[kSlots];
 #pragma unroll
-    for (int m = 0; m < kSlots; ++m) {
-      const int d = tid + 1024 * m;
-      best[m] = (d < kND - step) ? h1[d + step] : INFINITY;                // no jump (:333-334)
-      pick[m] = 0;
-    }
+    for (int m = 0; m < kSlots; ++m) { best[m] = h1[tid + 1024 * m + step]; pick[m] = 0; }   // no jump (:333-334); past the end: +inf guard
+#pragma unroll 2
     for (int k = 0; k < J; ++k) {
       const int lag = lags[k];
       const double lk = lr[k];
-      const int cut = two - lag;
-      const int hi_d = kND - (cut > 0 ? cut : 0);
-      const int shift = two - lag;
+      const double* src = h2 + (two - lag);                                // (:335-342)
+      double v[kSlots];
+#pragma unroll
+      for (int m = 0; m < kSlots; ++m) v[m] = src[tid + 1024 * m] + lk;
 #pragma unroll
       for (int m = 0; m < kSlots; ++m) {
-        const int d = tid + 1024 * m;
-        if (d >= lag && d < hi_d) {                                        // (:335-342)
-          const double v = h2[d + shift] + lk;
-          if (v < best[m]) { best[m] = v; pick[m] = k + 1; }
-        }
+        // the destination slice starts at `lag` (< 512): only the first slot can lie below it
+        const bool take = m == 0 ? ((tid >= lag) & (v[m] < best[m])) : (v[m] < best[m]);
+        best[m] = take ? v[m] : best[m];
+        pick[m] = take ? k + 1 : pick[m];
       }
     }
 #pragma unroll
@@ -773,15 +778,12 @@ __global__ void __launch_bounds__(1024) k_viterbi(const SegDesc* __restrict__ se
     }
     if (tid == 0) {
       const int d = kND - 1;
-      double b = (d < kND - step) ? h1[d + step] : INFINITY;
+      double b = h1[d + step];
       int pk = 0;
       for (int k = 0; k < J; ++k) {
         const int lag = lags[k];
-        const int cut = two - lag;
-        if (d >= lag && d < kND - (cut > 0 ? cut : 0)) {
-          const double v = h2[d + cut] + lr[k];
-          if (v < b) { b = v; pk = k + 1; }
-        }
+        const double v = h2[d + two - lag] + lr[k];
+        if (d >= lag && v < b) { b = v; pk = k + 1; }
       }
       hw[d] = b; back[w * kND + d] = (int16_t)pk;
     }
@@ -829,7 +831,7 @@ __global__ void __launch_bounds__(1024) k_viterbi(const SegDesc* __restrict__ se
   }
   pout[K + 1] = ostart;
   counts[2 * blockIdx.x] = K;
-  counts[2 * blockIdx.x + 1] = bad ? 1 : 0;
+  counts[2 * blockIdx.x + 1] = (bad || overflow) ? 1 : 0;
 }
 
 struct SpliceArgs {
@@ -1203,7 +1205,7 @@ int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, in
   S_TRY(hipStreamSynchronize(stream));
   tm.correlate_ms = elapsed(s->e0, s->e1); tm.correlate_windows = windows; tm.correlate_bytes = cbytes;
 
-  const size_t lds_bytes = sizeof(double) * (3 * kND + 2 * kMaxLags) + sizeof(int32_t) * kMaxLags;
+  const size_t lds_bytes = sizeof(double) * (3 * kRow + 2 * kMaxLags) + sizeof(int32_t) * kMaxLags;
   S_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_viterbi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   S_TRY(hipEventRecord(s->e0, stream));
   hipLaunchKernelGGL(k_viterbi, dim3(NS), dim3(1024), lds_bytes, stream, s->segs.as<SegDesc>(), s->lags.as<int32_t>(),
