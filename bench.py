@@ -55,7 +55,9 @@ def cpu_baseline(sample_seconds=600.0):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=64)
+  ap.add_argument("--steps", type=int, default=256,
+                  help="pairs aligned in the timed region (it starts with an empty pipeline and ends fully drained; "
+                       "one pair's latency is ~1.2 s, so a short run mostly measures the ramp)")
   ap.add_argument("--warmup", type=int, default=8)
   ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS))
   ap.add_argument("--precision", default=None, choices=["f32", "bf16"])
