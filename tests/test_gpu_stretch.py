@@ -211,3 +211,27 @@ def test_interval_too_short_for_the_correlation_generator(ctx):
   # 2 s of video from 0.03 s of audio would be |1-slope| > .1 -> skipped, so no error can be provoked
   ctx.replace_segments(v, a, np.array([0.0, 0.03]), np.array([0.0, 2.5]), False)
   assert not v.any()
+
+
+@pytest.mark.parametrize("n_v,n_a,planar", [(3 * 44100 + 1, 3 * 44100 + 7, True), (3 * 44100 + 5, 3 * 44100 + 3, False),
+                                            (3 * 44100 + 8, 3 * 44100 + 16, True)])
+def test_stretch_resident_ragged_lengths(ctx, n_v, n_a, planar):
+  """Odd track lengths: the second planar channel is then not 16-byte aligned (scalar loads), the
+  last group of 8 frames is partial, and the float16 channel stride is padded."""
+  rng = np.random.default_rng(n_v)
+  vid = (rng.standard_normal((2, n_v)) * 6000).clip(-32768, 32767).astype(np.int16)
+  aud = (rng.standard_normal((2, n_a)) * 9000).clip(-32768, 32767).astype(np.int16)
+  aud[1] //= 3
+  x = np.array([0.01, 2.95]); y = np.array([0.0, 2.93])
+  v, a = vid.astype(np.float16), aud.astype(np.float16)
+  want_f = SO.match_loudness(v, a)
+  SO.replace_aligned_segments(v, a, x, y, False)
+  SO.normalise_peak(v)
+  want = v.astype(np.int16).T
+  if planar:
+    ctx.pcm_upload(0, vid); ctx.pcm_upload(1, aud)
+  else:
+    ctx.pcm_upload(0, np.ascontiguousarray(vid.T)); ctx.pcm_upload(1, np.ascontiguousarray(aud.T))
+  got, fac = ctx.stretch_resident(x, y, False)
+  np.testing.assert_allclose(fac, want_f, rtol=1e-12)
+  assert np.array_equal(got, want), f"{int((got != want).sum())} samples differ"
