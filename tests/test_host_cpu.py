@@ -217,3 +217,22 @@ def test_two_rank_gloo_sharding(tmp_path):
   outs = [p.communicate(timeout=180)[0] for p in procs]
   assert all(p.returncode == 0 for p in procs), outs
   assert "ok [0, 2, 4]" in outs[0] and "ok [1, 3]" in outs[1]
+
+
+def test_lp_pricing_rule_does_not_change_the_fit():
+  """align.solve_trend_lp can ask HiGHS' dual simplex for Dantzig pricing (an option; faster on an
+  idle core, slower under the pipeline's contention); the optimum is the one the reference's call
+  (steepest edge, the default here too) finds."""
+  from describealign_amd import align as A
+  rng = np.random.default_rng(5)
+  for n, rate in ((400, 0.0), (900, 0.02)):
+    x = np.sort(rng.choice(np.arange(2000, 2000 + 140 * n), n, replace=False)).astype(np.float64)
+    y = x * (1 + rate) - 42000.0
+    for j in np.sort(rng.choice(np.arange(20000, 140 * n - 20000), 4, replace=False)):
+      y[x >= j] -= rng.integers(200, 1200)
+    y += rng.integers(-1, 2, n) * 0.5 + (rng.random(n) < 0.02) * rng.integers(-40, 40, n)
+    fast = A.solve_trend_lp(x, y, pricing="dantzig")
+    ref = A.solve_trend_lp(x, y)
+    assert np.abs(fast["solution"] - ref["solution"]).max() < 1e-7
+    assert np.array_equal(np.round(fast["slopes"], 6), np.round(ref["slopes"], 6))
+    assert abs(fast["median_slope"] - ref["median_slope"]) < 1e-12
