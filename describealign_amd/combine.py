@@ -128,30 +128,18 @@ def _write_replaced_media(ffmpeg, output_filename, frames, video_file):
   return subprocess.list2cmdline(argv).replace('\\', '/')
 
 
-def process_pair(video_file, audio_desc_file, has_audio_extension, ctx, stretch_audio=False, prepend="ad_",
-                 no_pitch_correction=False, output_dir=default_output_dir, alignment_dir=default_alignment_dir):
-  """One iteration of the reference's per-pair loop (:1077-1174)."""
-  from . import _native
-  from .align import align
-  output_filename = os.path.join(output_dir, prepend + os.path.split(video_file)[1])
-  print(f" {output_filename}")
-  if (not stretch_audio) & has_audio_extension:
-    raise RuntimeError("Argument --stretch_audio is required when both inputs are audio files.")
-  if os.path.exists(output_filename) and os.path.getsize(output_filename) > 1e5:
-    print("   output file already exists, skipping...")
-    return None
-  num_channels = 2 if stretch_audio else 1
-  print("  reading video file...\r", end='')
-  video_arr = media.parse_audio_from_file(video_file, num_channels)
-  print("  computing video features... \r", end='')
-  video_features = ctx.features(video_arr, _native.SIDE_VIDEO)      # the PCM stays resident on the GPU
-  del video_arr
-  print("  reading audio file...       \r", end='')
-  audio_desc_arr = media.parse_audio_from_file(audio_desc_file, num_channels)
-  print("  computing audio features...\r", end='')
-  audio_desc_features = ctx.features(audio_desc_arr, _native.SIDE_AUDIO)
-  del audio_desc_arr
-  outputs = align(video_features, audio_desc_features, video_features[0], audio_desc_features[0], ctx=ctx)
+def _output_name(video_file, prepend, output_dir):
+  return os.path.join(output_dir, prepend + os.path.split(video_file)[1])
+
+
+def _already_done(output_filename):
+  return os.path.exists(output_filename) and os.path.getsize(output_filename) > 1e5        # (:1087-1089)
+
+
+def _finish_pair(outputs, video_file, audio_desc_file, has_audio_extension, ctx, output_filename, stretch_audio,
+                 no_pitch_correction, alignment_dir):
+  """Everything after align() for one pair (:1123-1174): warnings, the setts expression, the muxed
+  or stretched output, the plot and the text report."""
   audio_desc_times, video_times, similarity_percent, path, median_slope = outputs
   if similarity_percent < 20:
     print(f"  WARNING: similarity {similarity_percent:.1f}%, likely mismatched files")
@@ -192,12 +180,103 @@ def process_pair(video_file, audio_desc_file, has_audio_extension, ctx, stretch_
               median_slope=median_slope, setts=setts_cmd, report=stem + ".txt")
 
 
+def process_pair(video_file, audio_desc_file, has_audio_extension, ctx, stretch_audio=False, prepend="ad_",
+                 no_pitch_correction=False, output_dir=default_output_dir, alignment_dir=default_alignment_dir):
+  """One iteration of the reference's per-pair loop (:1077-1174)."""
+  from . import _native
+  from .align import align
+  output_filename = _output_name(video_file, prepend, output_dir)
+  print(f" {output_filename}")
+  if (not stretch_audio) & has_audio_extension:
+    raise RuntimeError("Argument --stretch_audio is required when both inputs are audio files.")
+  if _already_done(output_filename):
+    print("   output file already exists, skipping...")
+    return None
+  num_channels = 2 if stretch_audio else 1
+  print("  reading video file...\r", end='')
+  video_arr = media.parse_audio_from_file(video_file, num_channels)
+  print("  computing video features... \r", end='')
+  video_features = ctx.features(video_arr, _native.SIDE_VIDEO)      # the PCM stays resident on the GPU
+  del video_arr
+  print("  reading audio file...       \r", end='')
+  audio_desc_arr = media.parse_audio_from_file(audio_desc_file, num_channels)
+  print("  computing audio features...\r", end='')
+  audio_desc_features = ctx.features(audio_desc_arr, _native.SIDE_AUDIO)
+  del audio_desc_arr
+  outputs = align(video_features, audio_desc_features, video_features[0], audio_desc_features[0], ctx=ctx)
+  return _finish_pair(outputs, video_file, audio_desc_file, has_audio_extension, ctx, output_filename, stretch_audio,
+                      no_pitch_correction, alignment_dir)
+
+
+def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_dir=default_output_dir,
+                  alignment_dir=default_alignment_dir, lp_workers=None, decode_ahead=3):
+  """A directory batch on one GPU without --stretch_audio: same results and files as calling
+  process_pair for every (video, audio description) in `todo`, but pipelined -- decoding of the next
+  pairs (a small thread pool, `decode_ahead` pairs in flight), the GPU stages of pair k+1 and the
+  host-side LP / DP stages of pair k overlap (align.AlignPipeline).  Returns the per-pair results."""
+  import concurrent.futures as cf
+  import contextlib
+  import io
+  from . import _native
+  from .align import AlignPipeline, default_worker_count
+  work = []
+  for video_file, audio_desc_file, has_audio_extension in todo:
+    if has_audio_extension:
+      raise RuntimeError("Argument --stretch_audio is required when both inputs are audio files.")
+    out = _output_name(video_file, prepend, output_dir)
+    if _already_done(out):
+      print(f" {out}\n   output file already exists, skipping...")
+      continue
+    work.append((video_file, audio_desc_file, out))
+  results = []
+  if not work:
+    return results
+  decoders = cf.ThreadPoolExecutor(max_workers=2)
+  decoded = {}
+
+  def request(k):
+    if k < len(work) and k not in decoded:
+      decoded[k] = (decoders.submit(media.parse_audio_from_file, work[k][0], 1),
+                    decoders.submit(media.parse_audio_from_file, work[k][1], 1))
+
+  def make_job(k):
+    def job(c):
+      for ahead in range(k, k + 1 + decode_ahead):
+        request(ahead)
+      fv, fa = decoded.pop(k)
+      vf = c.features(fv.result(), _native.SIDE_VIDEO)
+      af = c.features(fa.result(), _native.SIDE_AUDIO)
+      return vf, af
+    return job
+
+  local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+  workers = lp_workers or min(default_worker_count(local_world), max(2, len(work)))
+  quiet = contextlib.redirect_stdout(io.StringIO())          # align()'s progress lines would interleave
+  with AlignPipeline(ctx, lp_workers=workers) as pipe:
+    if len(work) >= 8:
+      pipe.warm()
+    it = pipe.run(make_job(k) for k in range(len(work)))
+    for k in range(len(work)):
+      with quiet:
+        outputs = next(it)
+      video_file, audio_desc_file, out = work[k]
+      print(f" {out}")
+      results.append(_finish_pair(outputs, video_file, audio_desc_file, False, ctx, out, False, no_pitch_correction,
+                                  alignment_dir))
+  decoders.shutdown(wait=True)
+  return results
+
+
 def _worker(gpu, indices, pairs, kwargs, precision):
   from . import _native
   ctx = _native.Context(gpu, precision)
-  for k in indices:
-    v, a, alt = pairs[k]
-    process_pair(v, a, alt, ctx, **kwargs)
+  todo = [pairs[k] for k in indices]
+  if not kwargs.get("stretch_audio") and len(todo) >= 3:
+    process_batch(todo, ctx, prepend=kwargs["prepend"], no_pitch_correction=kwargs["no_pitch_correction"],
+                  output_dir=kwargs["output_dir"], alignment_dir=kwargs["alignment_dir"])
+  else:
+    for v, a, alt in todo:
+      process_pair(v, a, alt, ctx, **kwargs)
   ctx.close()
 
 

@@ -395,3 +395,27 @@ def test_refine_vs_oracle_on_ten_minute_pair(ctx):
   assert path.shape == want.shape
   np.testing.assert_allclose(path[:, :3], want[:, :3], atol=1e-6)
   np.testing.assert_allclose(path[:, 3:], want[:, 3:], atol=2e-3)
+
+
+def test_directory_batch_is_pipelined_and_identical_to_sequential(ctx, tmp_path):
+  """combine.process_batch (what `combine` uses for a directory on one GPU) writes the same report
+  for every pair as process_pair does one pair at a time."""
+  from describealign_amd import combine, media, synth
+  todo = []
+  for k in range(4):
+    pair = synth.make_pair(seed=60 + k, video_seconds=60.0 + 3 * k, jumps=([0.0, 25.0 + k], [4.0 + k, 1.5]))
+    v, a = str(tmp_path / f"ep{k}.wav"), str(tmp_path / f"ep{k}_ad.wav")
+    media.write_wav(v, pair.video); media.write_wav(a, pair.audio)
+    todo.append((v, a, False))
+  seq_dir, bat_dir = tmp_path / "seq", tmp_path / "bat"
+  for d in (seq_dir, bat_dir):
+    os.makedirs(d / "out"); os.makedirs(d / "plots")
+  seq = [combine.process_pair(v, a, alt, ctx, output_dir=str(seq_dir / "out"), alignment_dir=str(seq_dir / "plots"))
+         for v, a, alt in todo]
+  bat = combine.process_batch(todo, ctx, output_dir=str(bat_dir / "out"), alignment_dir=str(bat_dir / "plots"), lp_workers=2)
+  assert len(bat) == len(seq) == 4
+  for s_, b_ in zip(seq, bat):
+    assert np.array_equal(s_["audio_desc_times"], b_["audio_desc_times"]) and np.array_equal(s_["video_times"], b_["video_times"])
+    assert s_["setts"] == b_["setts"]
+    assert open(s_["report"]).read() == open(b_["report"]).read()
+    assert os.path.getsize(b_["report"][:-4] + ".png") > 10000
