@@ -15,7 +15,7 @@
 //   stage 4  one thread per output frame: 13-tap Hann smoothing of energy / zero crossings,
 //            15-tap combination of the blur sums, log10(1+x)/2, store.
 // The stage outputs are written over the PCM region once every thread is done reading it, so a
-// workgroup needs 54 KB of LDS and two fit per CU.
+// workgroup needs 27 KB of LDS and four fit per CU (register-limited).
 // The 630-tap and 90-tap Hann blurs of the reference are evaluated in their exactly equivalent
 // separable form (see FeatTables): per-group partial sums in float32, combined in float64.
 //
@@ -26,8 +26,14 @@ namespace da {
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
+#ifndef DA_FEAT_MIN_WAVES
+#define DA_FEAT_MIN_WAVES 1
+#endif
+#ifndef DA_FEAT_EXT_MONO
+#define DA_FEAT_EXT_MONO 64      /* 64-frame chunks: 27 KB of LDS, four workgroups per CU; 128-frame chunks (two per CU) were 25 % slower */
+#endif
 template <int C> struct FeatCfg {
-  static constexpr int kExt = (C == 1) ? 128 : 64;    // frames staged per workgroup (incl. halo)
+  static constexpr int kExt = (C == 1) ? DA_FEAT_EXT_MONO : 64;    // frames staged per workgroup (incl. halo)
   static constexpr int kHalo = 8;
   static constexpr int kOut = kExt - 2 * kHalo;       // frames produced per workgroup
   static constexpr int kNQ = kExt * 6;                // 35-sample groups per chunk
@@ -64,7 +70,7 @@ template <int C> struct FeatLds {
 };
 
 template <int C>
-__global__ __launch_bounds__(FeatCfg<C>::kThreads) void k_features(FeatArgs a, const FeatTables* __restrict__ tp) {
+__global__ __launch_bounds__(FeatCfg<C>::kThreads, DA_FEAT_MIN_WAVES) void k_features(FeatArgs a, const FeatTables* __restrict__ tp) {
   using Cfg = FeatCfg<C>;
   using L = FeatLds<C>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
