@@ -209,11 +209,13 @@ def process_pair(video_file, audio_desc_file, has_audio_extension, ctx, stretch_
 
 
 def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_dir=default_output_dir,
-                  alignment_dir=default_alignment_dir, lp_workers=None, decode_ahead=3):
-  """A directory batch on one GPU without --stretch_audio: same results and files as calling
-  process_pair for every (video, audio description) in `todo`, but pipelined -- decoding of the next
-  pairs (a small thread pool, `decode_ahead` pairs in flight), the GPU stages of pair k+1 and the
-  host-side LP / DP stages of pair k overlap (align.AlignPipeline).  Returns the per-pair results."""
+                  alignment_dir=default_alignment_dir, lp_workers=None, decode_ahead=3, stretch_audio=False):
+  """A directory batch on one GPU: same results and files as calling process_pair for every
+  (video, audio description) in `todo`, but pipelined -- decoding of the next pairs (a small thread
+  pool, `decode_ahead` pairs in flight), the GPU stages of pair k+1 and the host-side LP / DP stages
+  of pair k overlap (align.AlignPipeline).  With stretch_audio the decoded PCM of the pairs in flight
+  is kept on the host and uploaded again (to a second context on the same GPU) when a pair's nodes
+  arrive, so at most six pairs are in flight.  Returns the per-pair results."""
   import concurrent.futures as cf
   import contextlib
   import io
@@ -221,36 +223,44 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
   from .align import AlignPipeline, default_worker_count
   work = []
   for video_file, audio_desc_file, has_audio_extension in todo:
-    if has_audio_extension:
+    if has_audio_extension and not stretch_audio:
       raise RuntimeError("Argument --stretch_audio is required when both inputs are audio files.")
     out = _output_name(video_file, prepend, output_dir)
     if _already_done(out):
       print(f" {out}\n   output file already exists, skipping...")
       continue
-    work.append((video_file, audio_desc_file, out))
+    work.append((video_file, audio_desc_file, out, has_audio_extension))
+  num_channels = 2 if stretch_audio else 1
   results = []
   if not work:
     return results
   decoders = cf.ThreadPoolExecutor(max_workers=2)
   decoded = {}
+  kept = {}                  # stretch_audio: PCM of the pairs in flight
+  stretch_ctx = _native.Context(ctx.device, ctx.precision) if stretch_audio else None
 
   def request(k):
     if k < len(work) and k not in decoded:
-      decoded[k] = (decoders.submit(media.parse_audio_from_file, work[k][0], 1),
-                    decoders.submit(media.parse_audio_from_file, work[k][1], 1))
+      decoded[k] = (decoders.submit(media.parse_audio_from_file, work[k][0], num_channels),
+                    decoders.submit(media.parse_audio_from_file, work[k][1], num_channels))
 
   def make_job(k):
     def job(c):
       for ahead in range(k, k + 1 + decode_ahead):
         request(ahead)
       fv, fa = decoded.pop(k)
-      vf = c.features(fv.result(), _native.SIDE_VIDEO)
-      af = c.features(fa.result(), _native.SIDE_AUDIO)
+      video_arr, audio_desc_arr = fv.result(), fa.result()
+      if stretch_audio:
+        kept[k] = (video_arr, audio_desc_arr)
+      vf = c.features(video_arr, _native.SIDE_VIDEO)
+      af = c.features(audio_desc_arr, _native.SIDE_AUDIO)
       return vf, af
     return job
 
   local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
   workers = lp_workers or min(default_worker_count(local_world), max(2, len(work)))
+  if stretch_audio:
+    workers = min(workers, 4)          # pipeline depth = workers + 2 pairs of PCM held on the host
   quiet = contextlib.redirect_stdout(io.StringIO())          # align()'s progress lines would interleave
   with AlignPipeline(ctx, lp_workers=workers) as pipe:
     if len(work) >= 8:
@@ -259,11 +269,19 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
     for k in range(len(work)):
       with quiet:
         outputs = next(it)
-      video_file, audio_desc_file, out = work[k]
+      video_file, audio_desc_file, out, has_audio_extension = work[k]
       print(f" {out}")
-      results.append(_finish_pair(outputs, video_file, audio_desc_file, False, ctx, out, False, no_pitch_correction,
+      if stretch_audio:
+        video_arr, audio_desc_arr = kept.pop(k)
+        stretch_ctx.pcm_upload(_native.SIDE_VIDEO, video_arr)
+        stretch_ctx.pcm_upload(_native.SIDE_AUDIO, audio_desc_arr)
+        del video_arr, audio_desc_arr
+      results.append(_finish_pair(outputs, video_file, audio_desc_file, has_audio_extension,
+                                  stretch_ctx if stretch_audio else ctx, out, stretch_audio, no_pitch_correction,
                                   alignment_dir))
   decoders.shutdown(wait=True)
+  if stretch_ctx is not None:
+    stretch_ctx.close()
   return results
 
 
@@ -271,9 +289,10 @@ def _worker(gpu, indices, pairs, kwargs, precision):
   from . import _native
   ctx = _native.Context(gpu, precision)
   todo = [pairs[k] for k in indices]
-  if not kwargs.get("stretch_audio") and len(todo) >= 3:
+  if len(todo) >= 3:
     process_batch(todo, ctx, prepend=kwargs["prepend"], no_pitch_correction=kwargs["no_pitch_correction"],
-                  output_dir=kwargs["output_dir"], alignment_dir=kwargs["alignment_dir"])
+                  output_dir=kwargs["output_dir"], alignment_dir=kwargs["alignment_dir"],
+                  stretch_audio=bool(kwargs.get("stretch_audio")))
   else:
     for v, a, alt in todo:
       process_pair(v, a, alt, ctx, **kwargs)
@@ -336,7 +355,7 @@ def command_line_interface(argv=None):
   parser.add_argument("video", help='A video file or directory containing video files.', nargs='?', default=None)
   parser.add_argument("audio", help='An audio file or directory containing audio files.', nargs='?', default=None)
   parser.add_argument('--stretch_audio', action='store_true',
-                      help='Stretches the input audio to fit the input video (not available in this build).')
+                      help='Stretches the input audio to fit the input video (runs on the GPU).')
   parser.add_argument('--yes', action='store_true', help='Auto-skips user prompts asking to verify information.')
   parser.add_argument("--prepend", default="ad_", help='Output file name prepend text. Default is "ad_"')
   parser.add_argument('--no_pitch_correction', action='store_true',

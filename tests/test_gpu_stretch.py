@@ -235,3 +235,33 @@ def test_stretch_resident_ragged_lengths(ctx, n_v, n_a, planar):
   got, fac = ctx.stretch_resident(x, y, False)
   np.testing.assert_allclose(fac, want_f, rtol=1e-12)
   assert np.array_equal(got, want), f"{int((got != want).sum())} samples differ"
+
+
+def test_combine_directory_with_stretch_audio(ctx, tmp_path):
+  """combine() on a directory of stereo .wav pairs with --stretch_audio: the pipelined batch writes
+  the same tracks as one-pair-at-a-time processing."""
+  import wave
+  from describealign_amd import combine, media, synth
+  vdir, adir = tmp_path / "video", tmp_path / "ad"
+  os.makedirs(vdir); os.makedirs(adir)
+  for k in range(3):
+    pair = synth.make_pair(seed=60 + k, video_seconds=60.0 + 3 * k, jumps=([0.0, 25.0 + k], [4.0 + k, 1.5]), channels=2)
+    media.write_wav(str(vdir / f"ep{k}.wav"), pair.video); media.write_wav(str(adir / f"ep{k}.wav"), pair.audio)
+  if media.find_ffmpeg() is not None:
+    pytest.skip("compares the .wav tracks written when no ffmpeg binary is present")
+  outs = {}
+  for name in ("seq", "bat"):
+    os.makedirs(tmp_path / name / "out"); os.makedirs(tmp_path / name / "plots")
+  for k in range(3):
+    combine.process_pair(str(vdir / f"ep{k}.wav"), str(adir / f"ep{k}.wav"), True, ctx, stretch_audio=True,
+                         output_dir=str(tmp_path / "seq" / "out"), alignment_dir=str(tmp_path / "seq" / "plots"))
+  combine.combine(str(vdir), str(adir), stretch_audio=True, yes=True, output_dir=str(tmp_path / "bat" / "out"),
+                  alignment_dir=str(tmp_path / "bat" / "plots"))
+  for k in range(3):
+    tracks = []
+    for name in ("seq", "bat"):
+      with wave.open(str(tmp_path / name / "out" / f"ad_ep{k}.wav"), "rb") as w:
+        tracks.append(w.readframes(w.getnframes()))
+    assert tracks[0] == tracks[1] and len(tracks[0]) > 10 ** 6
+    reports = [open(tmp_path / name / "plots" / f"ep{k}.txt").read().replace(f"/{name}/out/", "/out/") for name in ("seq", "bat")]
+    assert reports[0] == reports[1]
