@@ -419,3 +419,24 @@ def test_directory_batch_is_pipelined_and_identical_to_sequential(ctx, tmp_path)
     assert s_["setts"] == b_["setts"]
     assert open(s_["report"]).read() == open(b_["report"]).read()
     assert os.path.getsize(b_["report"][:-4] + ".png") > 10000
+
+
+def test_two_hour_stereo_pair_recovers_injected_offsets(ctx_bf16):
+  """BASELINE config 3 at full size (7200 s stereo, 10 injected offset jumps, bf16 similarity
+  GEMM): every injected offset recovered within +-23 ms, in far less than 1 % of real time, and the
+  --stretch_audio track built from those nodes has the right length."""
+  import time
+  from describealign_amd import align as A, synth
+  pair = synth.make_pair(11, 7200.0, n_jumps=10, first_gap=200.0, channels=2)
+  c = ctx_bf16
+  t0 = time.perf_counter()
+  vf = c.features(pair.video, 0); af = c.features(pair.audio, 1)
+  x, y, sim, path, med = A.align(vf, af, vf[0], af[0], ctx=c)
+  elapsed = time.perf_counter() - t0
+  assert len(x) == 2 * len(pair.jump_lengths)
+  assert _max_offset_error_ms(pair, x, y) < 23.0
+  assert abs(med - 1) < 1e-3
+  assert elapsed < 72.0, f"{elapsed:.1f} s is slower than 100x real time"
+  track, fac = c.stretch_resident(x, y, False)
+  assert track.shape == (pair.video.shape[1], 2) and np.all(np.isfinite(fac))
+  assert int(np.abs(track.astype(np.int32)).max()) >= 32000            # peak-normalised
