@@ -388,6 +388,7 @@ __global__ void __launch_bounds__(256) k_resample_tile(const ResChunk* __restric
   if (n < kFusedMinRows || R0 + 2 >= n) return;
   const int ch = blockIdx.z;
   const double w_mid = R.w_mid, cp_mid = R.cp_mid;
+  const double nq_mid = -0.125 * w_mid, ncp_mid = -cp_mid;
   constexpr int kRowsY = kTileRows + kApron + kWarm;                  // rows [R0 - kWarm, R0 + 4128)
   __shared__ half_t ys[kRowsY + 2 * (kRowsY / 16) + 8];
   __shared__ double cs[kTileRows + kApron + (kTileRows + kApron) / 16 + 4];
@@ -420,15 +421,15 @@ __global__ void __launch_bounds__(256) k_resample_tile(const ResChunk* __restric
     for (; i + 8 <= ie; i += 8) {                                    // uniform rows: constants in registers, LDS only;
       double yv[8];                                                  // the reads go out together ahead of the dependent chain
 #pragma unroll
-      for (int e = 0; e < 8; ++e) yv[e] = (double)ys[pad_y(i + e - ybase)];
+      for (int e = 0; e < 8; ++e) yv[e] = (double)ys[pad_y(i + e - ybase)] * w_mid;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        dp = (yv[e] - 0.125 * dp) * w_mid;
+        dp = fma(nq_mid, dp, yv[e]);                                 // (y - dp/8) w as ONE dependent operation
         if (i + e >= first) cs[pad_c(i + e - R0)] = dp;
       }
     }
     for (; i < ie; ++i) {
-      dp = ((double)ys[pad_y(i - ybase)] - 0.125 * dp) * w_mid;
+      dp = fma(nq_mid, dp, (double)ys[pad_y(i - ybase)] * w_mid);
       if (i >= first) cs[pad_c(i - R0)] = dp;
     }
     for (; i < last; ++i) {                                          // the true last three rows (last tile only)
@@ -460,7 +461,7 @@ __global__ void __launch_bounds__(256) k_resample_tile(const ResChunk* __restric
 #pragma unroll
         for (int q = 0; q < 4; ++q) d4[q] = cs[pad_c(i - q - R0)];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) next = d4[q] - cp_mid * next;
+        for (int q = 0; q < 4; ++q) next = fma(ncp_mid, next, d4[q]);
       }
       for (; i >= last; --i) next = cs[pad_c(i - R0)] - pivot(i) * next;
 #pragma unroll
@@ -471,7 +472,7 @@ __global__ void __launch_bounds__(256) k_resample_tile(const ResChunk* __restric
 #pragma unroll
       for (int k = kOwn - 1; k >= 0; --k) {
         const int32_t r = lo_row + k;
-        if (r >= first && r < last) { next = cown[k] - pivot(r) * next; cown[k] = next; }
+        if (r >= first && r < last) { next = fma(-pivot(r), next, cown[k]); cown[k] = next; }
       }
     }
     __syncthreads();
