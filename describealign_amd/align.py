@@ -661,7 +661,9 @@ class AlignPipeline:
       done = cf.Future()
       self.gpu_threads[g].submit(self._gpu_stage, self.gpu_ctxs[g], job, tm, fname, done)
       pending.append((done, tm))
-      while len(pending) > self.depth + 2 * n_gpu:
+      # results are handed back in submission order, so pairs that finished behind a slow LP still
+      # count as pending: the window has to be wider than the worker pool or workers idle
+      while len(pending) > int(os.environ.get("DALIGN_PIPELINE_WINDOW", 2 * self.depth + 4 * n_gpu)):
         yield finish(pending.pop(0))
     for g in range(n_gpu):          # the last pair of every context still has to be copied out
       self.gpu_threads[g].submit(self._flush_deferred, self.gpu_ctxs[g])
