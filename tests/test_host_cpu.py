@@ -236,3 +236,45 @@ def test_lp_pricing_rule_does_not_change_the_fit():
     assert np.abs(fast["solution"] - ref["solution"]).max() < 1e-7
     assert np.array_equal(np.round(fast["slopes"], 6), np.round(ref["slopes"], 6))
     assert abs(fast["median_slope"] - ref["median_slope"]) < 1e-12
+
+
+def _trend_points(n, seed, rate=0.0, second_rate=None):
+  rng = np.random.default_rng(seed)
+  x = np.sort(rng.choice(np.arange(2000, 2000 + 140 * n), n, replace=False)).astype(np.float64)
+  y = x * (1 + rate) - 42000.0
+  if second_rate is not None:                      # the rate changes half-way through the file
+    h = n // 2
+    y[h:] = y[h] + (x[h:] - x[h]) * (1 + second_rate)
+  for j in np.sort(rng.choice(np.arange(20000, 140 * n - 20000), 4, replace=False)):
+    y[x >= j] -= rng.integers(200, 1200)
+  y += rng.integers(-1, 2, n) * 0.5 + (rng.random(n) < 0.02) * rng.integers(-40, 40, n)
+  return x, y
+
+
+@pytest.mark.parametrize("n,seed,rate,second", [(500, 1, 0.0, None), (800, 2, 0.02, None), (700, 3, -0.04, None),
+                                                 (600, 4, 0.0, 0.03), (900, 5, 0.01, -0.02)])
+def test_lp_without_rate_terms_is_certified_or_falls_back(n, seed, rate, second):
+  """align.solve_trend_lp first solves the LP without the rate_jump / rate_change columns and keeps
+  that optimum only when the dual certificate proves it optimal for the reference's full LP; either
+  way the fit equals the one the reference's call produces."""
+  from describealign_amd import align as A
+  x, y = _trend_points(n, seed, rate, second)
+  c, Amat, b, bounds = A.build_trend_lp(x, y)
+  reduced = A._solve_without_rate_terms(c, Amat, b, bounds, n, np.diff(x))
+  full = A.solve_trend_lp(x, y, reduce=False)
+  used = A.solve_trend_lp(x, y)
+  rate_jump = full["solution"][8 * n - 4:10 * n - 6]
+  if second is None:
+    assert reduced is not None, "a constant rate difference is absorbed by median_slope: the certificate should hold"
+    assert np.abs(rate_jump).max() < 1e-8
+  else:
+    assert reduced is None, "a rate that changes inside the file needs rate_jump: the certificate must fail"
+    assert np.abs(rate_jump).max() > 1.0
+  assert np.abs(used["solution"] - full["solution"]).max() < 1e-6
+  assert np.array_equal(np.round(used["slopes"], 6), np.round(full["slopes"], 6))
+  assert abs(used["median_slope"] - full["median_slope"]) < 1e-10
+  # the certificate is a statement about dual feasibility: check it against the full problem's own duals
+  if reduced is not None:
+    import scipy.optimize
+    ref = scipy.optimize.linprog(c, A_eq=Amat, b_eq=b, bounds=bounds, method="highs-ds")
+    assert abs(ref.fun - float(c @ reduced)) < 1e-6 * max(1.0, abs(ref.fun))
