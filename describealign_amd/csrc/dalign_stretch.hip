@@ -363,9 +363,12 @@ __global__ void __launch_bounds__(256) k_spline_eval(const ResChunk* __restrict_
 // true ends of the spline the exact boundary rows are used instead), coefficients stay in LDS, and
 // the same workgroup evaluates the output points that fall on its rows.  HBM traffic is the float16
 // samples read once and the float16 result written once.
-constexpr int kTileRows = 4064;          // coefficient rows solved per workgroup (+ kApron = 256 threads x kOwn)
+constexpr int kTileRows = 4064;          // coefficient rows solved per workgroup (+ kApron = 128 solver threads x kOwn)
+#ifndef DA_RS_OWN
+#define DA_RS_OWN 16
+#endif
 constexpr int kTileStep = kTileRows - 2; // consecutive tiles overlap by two rows (a point needs c[ell-2..ell])
-constexpr int kOwn = 16;                 // rows per thread
+constexpr int kOwn = DA_RS_OWN;          // rows per solver thread (16: all 256 threads solve; 32: half of them, 28 % fewer steps but 10 % slower)
 constexpr int kWarm = 20;                // warm-up rows
 constexpr int kApron = 32;               // forward-pass rows beyond the tile (warm-up of the backward pass)
 constexpr int kMaxTiles = 28;            // ceil((1.1e5 + 4) / 4062): the rate is within +-10 % (:33)
@@ -376,8 +379,8 @@ struct SplineRows {            // tabulated on the host with the same recurrence
   double w_mid, cp_mid;
 };
 
-__device__ __forceinline__ int pad_y(int r) { return r + 2 * (r >> 4); }       // float16 index, conflict-free per 16-row owner
-__device__ __forceinline__ int pad_c(int r) { return r + (r >> 4); }           // float64 index
+__device__ __forceinline__ int pad_y(int r) { return r + 2 * (r / kOwn); }     // float16 index, conflict-free per owner
+__device__ __forceinline__ int pad_c(int r) { return r + (r / kOwn); }         // float64 index
 
 __global__ void __launch_bounds__(256) k_resample_tile(const ResChunk* __restrict__ chunks, const half_t* __restrict__ audio,
                                                        int64_t n_audio, half_t* __restrict__ video, int64_t n_video,
