@@ -1,18 +1,21 @@
 // Audio replacement path (--stretch_audio) for gfx950: describealign.py:230-416, :1135-1153.
 //
-//   resampling   k_spline_solve  one thread per (1e5-point block, channel): Thomas solve of the
-//                                quadratic-spline collocation system (scipy make_interp_spline k=2)
-//                k_spline_eval   one thread per output sample: de Boor basis x 3 coefficients
-//   stretching   k_chunk_rms     thread per chunk of 50 windows: sliding 512-sums of the power,
-//                                epsilon = 1e-4 max(1, max), rms                     (:272-279)
-//                k_lag_table     thread per (chunk, lag): lag products, sliding 512-sums in the
-//                                reference's summation order, Pearson correlation, arg-max per
-//                                window                                              (:280-296, :321-322)
+//   resampling   k_resample_tile one workgroup per tile of 4064 spline coefficients: float16 samples
+//                                to LDS, Thomas recurrences with 20-row warm-ups (exact boundary
+//                                rows at the true ends), coefficients stay in LDS, the same workgroup
+//                                evaluates the output points on its rows (scipy make_interp_spline k=2)
+//                k_spline_solve / k_spline_eval   sequential fallback for splines shorter than 64 rows
+//   stretching   k_chunk_rms     wavefront per chunk of 50 windows: sliding 512-sums of the power in
+//                                the reference's summation order, epsilon, rms          (:272-279)
+//                k_lag_table     wavefront per (chunk, lag): lag products, sliding 512-sums (lane 0
+//                                extends the float64 running sum in order, all lanes share the
+//                                per-position work), Pearson correlation, arg-max per window
+//                                                                                   (:280-296, :321-322)
 //                k_viterbi       one workgroup per stretched interval: (window, drift) Viterbi with
-//                                the 3 x 3073 cost history in LDS, back-pointers in HBM, then the
-//                                back-track and the copy plan                       (:311-368)
+//                                the 3 x 3073 cost history (+inf guard zones) in LDS, back-pointers
+//                                in HBM, then the back-track and the copy plan      (:311-368)
 //                k_splice        one thread per output sample: run copy + Hann cross-fades (:369-385)
-//   bracket      k_moments / k_scale (:1135-1148), k_absmax / k_finish (:1153, :136)
+//   bracket      k_pcm_moments / k_pcm_to_f16 (:156, :1135-1148), k_absmax / k_finish (:1153, :136)
 //
 // All of it is HBM/latency-bound byte and fp64 work; nothing here is GEMM-shaped.
 #include "dalign_stretch.h"
