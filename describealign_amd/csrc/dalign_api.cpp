@@ -787,6 +787,9 @@ void stretch_stats(da_ctx* c, const da::StretchTimes& t) {
 
 int check_nodes(da_ctx* c, const double* at, const double* vt, int n_nodes, const char* who) {
   if (!at || !vt || n_nodes < 2) return fail(c, DA_ERR_ARG, "%s: need at least two nodes", who);
+  for (int k = 0; k < n_nodes; ++k)
+    if (!std::isfinite(at[k]) || !std::isfinite(vt[k]) || std::fabs(at[k]) > 1e9 || std::fabs(vt[k]) > 1e9)
+      return fail(c, DA_ERR_ARG, "%s: node %d is not a finite time in seconds", who, k);
   return DA_OK;
 }
 

@@ -141,6 +141,8 @@ def test_replace_segments_errors(ctx):
     ctx.replace_segments(v, a, np.array([0.0, 6.03]), np.array([0.0, 6.0]), True)     # video interval past the end
   with pytest.raises(RuntimeError, match="two nodes"):
     ctx.replace_segments(v, a, np.array([0.0]), np.array([0.0]), False)
+  with pytest.raises(RuntimeError, match="finite"):
+    ctx.replace_segments(v, a, np.array([0.0, np.nan]), np.array([0.0, 3.0]), False)
   with pytest.raises(ValueError):
     ctx.replace_segments(v.astype(np.float32), a, np.array([0.0, 3.0]), np.array([0.0, 3.0]), False)
 
