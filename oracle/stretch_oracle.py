@@ -21,6 +21,10 @@ of array functions, one per step, so each HIP kernel has a stage to be compared 
 Pinning: tests/test_oracle_golden.py checks every function here against fixtures that
 tests/golden/make_golden.py recorded by running the reference itself in the build container
 (jump schedules and full output waveforms for the cases in tests/golden/cases.py STRETCH_CASES).
+match_loudness / normalise_peak restate lines that are written inline in the reference's combine();
+they are pinned by running that combine(stretch_audio=True) itself with only its file I/O replaced
+(COMBINE_STRETCH_CASES: sha1 of the scaled tracks, of the array handed to the writer and of its
+int16 frames).
 
 Third-party arithmetic not under /root/reference: `scipy.interpolate.interp1d(kind='quadratic')`
 (scipy 1.15.3 here; `scipy~=1.10` in the reference's requirements.txt:5) -- called here exactly as

@@ -114,3 +114,13 @@ def stretch_case_f16(name: str):
     else:
       a[c] *= np.float64(0.5779034)
   return v, a, x, y
+
+
+# Whole --stretch_audio block of combine() (describealign.py:1096-1159): stereo pairs that align.
+COMBINE_STRETCH_CASES = {
+  "cs60": dict(seed=60, video_seconds=60.0, jumps=([0.0, 25.0], [4.0, 1.5]), channels=2),
+}
+
+
+def combine_stretch_case(name: str) -> synth.SynthPair:
+  return synth.make_pair(**COMBINE_STRETCH_CASES[name])

@@ -250,11 +250,65 @@ def gen_stretch(name):
   return meta
 
 
+def gen_combine_stretch(name):
+  """The reference's combine(..., stretch_audio=True) itself (describealign.py:1031-1175) on a
+  synthetic stereo pair: only its file I/O is replaced -- get_sorted_filenames,
+  parse_audio_from_file (returns the synthetic PCM as float16, what :156 produces) and
+  write_replaced_media_to_disk (records the array it is handed) -- so the loudness matching and peak
+  normalisation written inline in combine() (:1135-1153) run unmodified together with
+  get_energy/.../align/replace_aligned_segments.  Records sha1 of the float16 array handed to the
+  writer and of its int16 serialisation (:136), a sparse sample of both, and the nodes."""
+  t0 = time.time()
+  pair = cases.combine_stretch_case(name)
+  pcm = {"video.wav": pair.video, "ad.wav": pair.audio}
+  captured = {}
+  saved = {k: getattr(ref, k) for k in ("get_sorted_filenames", "parse_audio_from_file", "write_replaced_media_to_disk",
+                                        "is_ffmpeg_installed", "replace_aligned_segments")}
+  def fake_sorted(path, extensions, alt_extensions=set([])):
+    return [path], [os.path.splitext(path)[1][1:] in alt_extensions]
+  def fake_parse(media_file, num_channels=2):
+    arr = pcm[os.path.basename(media_file)]
+    assert arr.shape[0] == num_channels
+    return arr.astype(np.float16)
+  def fake_write(output_filename, media_arr, video_file=None, **kw):
+    captured["media"] = media_arr.copy(); captured["video_file"] = video_file
+    return "<ffmpeg command>"
+  def spy_replace(video_arr, audio_desc_arr, audio_desc_times, video_times, no_pitch_correction):
+    captured["x"] = np.array(audio_desc_times); captured["y"] = np.array(video_times)
+    captured["scaled_video_sha1"] = cases.sha1_of(video_arr.view(np.uint16)); captured["scaled_audio_sha1"] = cases.sha1_of(audio_desc_arr.view(np.uint16))
+    return saved["replace_aligned_segments"](video_arr, audio_desc_arr, audio_desc_times, video_times, no_pitch_correction)
+  ref.get_sorted_filenames = fake_sorted; ref.parse_audio_from_file = fake_parse
+  ref.write_replaced_media_to_disk = fake_write; ref.is_ffmpeg_installed = lambda *a, **k: True
+  ref.replace_aligned_segments = spy_replace
+  try:
+    with tempfile.TemporaryDirectory() as td:
+      ref.combine(os.path.join(td, "video.wav"), os.path.join(td, "ad.wav"), stretch_audio=True, yes=True,
+                  output_dir=os.path.join(td, "out"), alignment_dir=os.path.join(td, "plots"))
+      report = open(os.path.join(td, "plots", "video.txt")).read()
+  finally:
+    for k, v in saved.items():
+      setattr(ref, k, v)
+  print()
+  media = captured["media"]
+  s16 = media.astype(np.int16).T                        # describealign.py:136
+  out = dict(x=captured["x"], y=captured["y"], media_every_997=media[:, ::997].view(np.uint16).copy(),
+             s16_every_997=np.ascontiguousarray(s16[::997]))
+  np.savez_compressed(os.path.join(HERE, f"combine_stretch_{name}.npz"), **out)
+  meta = dict(sha1_inputs=pair.sha1(), media_shape=list(media.shape), media_dtype=str(media.dtype),
+              sha1_media_f16=cases.sha1_of(media.view(np.uint16)), sha1_s16le=cases.sha1_of(s16),
+              sha1_scaled_video=captured["scaled_video_sha1"], sha1_scaled_audio=captured["scaled_audio_sha1"],
+              peak_int16=[int(s16.min()), int(s16.max())], report_first_lines=report.split("\n")[:8],
+              seconds_reference=round(time.time() - t0, 2))
+  print(f"[combine_stretch {name}] nodes {len(captured['x'])} peak {meta['peak_int16']} ({meta['seconds_reference']} s)")
+  return meta
+
+
 def main(argv):
   idx_path = os.path.join(HERE, "index.json")
   index = json.load(open(idx_path)) if os.path.exists(idx_path) else {}
   want = argv or (["features", "a40", "e180", "e180s", "e600", "rate2", "mismatch", "e1320"] +
-                  ["stretch:" + n for n in cases.STRETCH_CASES])
+                  ["stretch:" + n for n in cases.STRETCH_CASES] +
+                  ["combine_stretch:" + n for n in cases.COMBINE_STRETCH_CASES])
   index["reference_version"] = ref.__version__
   index["numpy"] = np.__version__
   import scipy
@@ -263,6 +317,8 @@ def main(argv):
     if name == "features":
       index["features"] = gen_features()
       print("[features] done")
+    elif name.startswith("combine_stretch:"):
+      index.setdefault("combine_stretch", {})[name[16:]] = gen_combine_stretch(name[16:])
     elif name.startswith("stretch:"):
       index.setdefault("stretch", {})[name[8:]] = gen_stretch(name[8:])
     else:

@@ -267,3 +267,20 @@ def test_combine_directory_with_stretch_audio(ctx, tmp_path):
     assert tracks[0] == tracks[1] and len(tracks[0]) > 10 ** 6
     reports = [open(tmp_path / name / "plots" / f"ep{k}.txt").read().replace(f"/{name}/out/", "/out/") for name in ("seq", "bat")]
     assert reports[0] == reports[1]
+
+
+@pytest.mark.parametrize("name", list(cases.COMBINE_STRETCH_CASES))
+def test_stretch_audio_track_equals_reference_combine(ctx, name):
+  """PCM -> features -> align -> da_stretch_resident on the GPU against the fixture recorded from
+  the reference's own combine(stretch_audio=True): identical nodes and an identical s16le track."""
+  from describealign_amd import align as A
+  meta = INDEX["combine_stretch"][name]
+  g = np.load(os.path.join(GOLD, f"combine_stretch_{name}.npz"))
+  pair = cases.combine_stretch_case(name)
+  vf = ctx.features(pair.video, 0); af = ctx.features(pair.audio, 1)
+  x, y, sim, path, med = A.align(vf, af, vf[0], af[0], ctx=ctx)
+  np.testing.assert_allclose(x, g["x"], atol=1e-6); np.testing.assert_allclose(y, g["y"], atol=1e-6)
+  track, fac = ctx.stretch_resident(x, y, False)
+  assert np.array_equal(track[::997], g["s16_every_997"])
+  assert cases.sha1_of(np.ascontiguousarray(track)) == meta["sha1_s16le"]
+  assert [int(track.min()), int(track.max())] == meta["peak_int16"]

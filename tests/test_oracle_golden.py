@@ -167,3 +167,31 @@ def test_stretch_chunk_plan_covers_every_window_once():
       nxt = begin // SO.WINDOW + hi
       assert end - begin >= 3 * SO.WINDOW - 1
     assert nxt == n // SO.WINDOW, n
+
+
+@pytest.mark.parametrize("name", list(cases.COMBINE_STRETCH_CASES))
+def test_whole_stretch_audio_block_matches_reference_combine(name):
+  """The reference's combine(stretch_audio=True) was run with only its file I/O replaced
+  (make_golden.py gen_combine_stretch), so the loudness matching and peak normalisation that are
+  written inline in combine() (describealign.py:1135-1153) and the int16 serialisation (:136) are
+  pinned too: sha1 of the scaled float16 tracks, of the array handed to the writer, and of its
+  int16 frames."""
+  meta = INDEX["combine_stretch"][name]
+  g = np.load(os.path.join(GOLD, f"combine_stretch_{name}.npz"))
+  pair = cases.combine_stretch_case(name)
+  assert pair.sha1() == meta["sha1_inputs"], "synthetic generator drifted"
+  vf, af = O.features(pair.video), O.features(pair.audio)
+  x, y, sim, path, med = O.align(vf, af, vf[0], af[0])
+  np.testing.assert_allclose(x, g["x"], atol=1e-9); np.testing.assert_allclose(y, g["y"], atol=1e-9)
+  v, a = pair.video.astype(np.float16), pair.audio.astype(np.float16)
+  SO.match_loudness(v, a)
+  assert cases.sha1_of(v.view(np.uint16)) == meta["sha1_scaled_video"]
+  assert cases.sha1_of(a.view(np.uint16)) == meta["sha1_scaled_audio"]
+  SO.replace_aligned_segments(v, a, x, y, False)
+  SO.normalise_peak(v)
+  assert np.array_equal(v[:, ::997].view(np.uint16), g["media_every_997"])
+  assert cases.sha1_of(v.view(np.uint16)) == meta["sha1_media_f16"]
+  s16 = v.astype(np.int16).T
+  assert np.array_equal(s16[::997], g["s16_every_997"])
+  assert cases.sha1_of(s16) == meta["sha1_s16le"]
+  assert [int(s16.min()), int(s16.max())] == meta["peak_int16"]
