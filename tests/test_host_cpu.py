@@ -278,3 +278,35 @@ def test_lp_without_rate_terms_is_certified_or_falls_back(n, seed, rate, second)
     import scipy.optimize
     ref = scipy.optimize.linprog(c, A_eq=Amat, b_eq=b, bounds=bounds, method="highs-ds")
     assert abs(ref.fun - float(c @ reduced)) < 1e-6 * max(1.0, abs(ref.fun))
+
+
+def test_stretch_audio_command_lines_follow_the_reference_options():
+  """write_replaced_media_to_disk with a media array (describealign.py:468-487): the new stereo
+  track is piped in as s16le; with a video it is muxed in front of the original streams and tagged
+  as the described track, without one it is stored on its own."""
+  from describealign_amd import combine
+  with_video = combine._replaced_media_command("ffmpeg", "out/ad_show.mkv", "show.mkv")
+  assert with_video[:11] == ["ffmpeg", "-f", "s16le", "-acodec", "pcm_s16le", "-ac", "2", "-ar", "44100", "-i", "pipe:"]
+  joined = " ".join(with_video)
+  for needle in ("-i show.mkv", "-acodec copy", "-vcodec copy", "-scodec copy", "-max_interleave_delta 0",
+                 "-c:a:0 aac", "-disposition:a:0 default+visual_impaired+descriptions", "-metadata:s:a:0 title=AD",
+                 "-disposition:a:1 original", "-metadata:s:a:1 title=original", "out/ad_show.mkv -y"):
+    assert needle in joined, needle
+  audio_only = combine._replaced_media_command("ffmpeg", "out/ad_show.wav", None)
+  assert audio_only[-2:] == ["out/ad_show.wav", "-y"] and "-vcodec" not in audio_only
+
+
+def test_cli_accepts_the_reference_flags():
+  from describealign_amd import combine
+  import argparse
+  # parse only: no GPU is touched before combine() runs
+  real = combine.combine
+  seen = {}
+  combine.combine = lambda *a, **k: seen.update(args=a, kwargs=k)
+  try:
+    combine.command_line_interface(["v.mp4", "a.mp3", "--stretch_audio", "--yes", "--prepend", "x_",
+                                    "--no_pitch_correction", "--gpus", "2", "--precision", "bf16"])
+  finally:
+    combine.combine = real
+  flat = list(seen["args"]) + list(seen["kwargs"].values())
+  assert "v.mp4" in flat and "a.mp3" in flat and "x_" in flat and True in flat
