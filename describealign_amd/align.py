@@ -579,6 +579,23 @@ class AlignPipeline:
         os.environ.pop(k, None)
       else:
         os.environ[k] = v
+    # keep this process's own threads (GPU feeder, refine pool, the caller) off the cores the LP
+    # workers are pinned to and off their SMT siblings; threads created below inherit the mask
+    self._old_affinity = None
+    if pin and int(os.environ.get("DALIGN_PIN_MAIN", "1")) and local_world == 1:
+      try:
+        cpus = sorted(os.sched_getaffinity(0))
+        half = len(cpus) // 2
+        taken = set()
+        for k in range(self.depth):
+          w = ((local_rank * self.depth + k) * stride) % len(cpus)
+          taken.update({cpus[w], cpus[(w + half) % len(cpus)]})
+        rest = set(cpus) - taken
+        if len(rest) >= 8:
+          self._old_affinity = set(cpus)
+          os.sched_setaffinity(0, rest)
+      except Exception:
+        self._old_affinity = None
     self.gpu_threads = [cf.ThreadPoolExecutor(max_workers=1) for _ in self.gpu_ctxs]
     self.refine_pool = cf.ThreadPoolExecutor(max_workers=max(1, int(refine_threads)))
     self._local = threading.local()
@@ -614,6 +631,12 @@ class AlignPipeline:
   def __exit__(self, *exc):
     import shutil
     import sys
+    if getattr(self, "_old_affinity", None):
+      try:
+        os.sched_setaffinity(0, self._old_affinity)
+      except Exception:
+        pass
+      self._old_affinity = None
     for g in self.gpu_threads:
       g.shutdown(wait=True, cancel_futures=True)
     self.pool.shutdown(wait=True, cancel_futures=True)
