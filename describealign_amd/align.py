@@ -457,26 +457,80 @@ def _lp_worker(args):
   return lp, time.perf_counter() - t0
 
 
-def _pin_worker(slot_counter, lock, first_slot, stride):
-  """Give every worker process its own core (slots spread by `stride` logical CPUs, offset by the
-  rank's `first_slot`) so concurrent LP solves do not share SMT siblings, migrate, or -- with one
-  rank per GPU on the same host -- pile onto the same cores as another rank's workers."""
+def cpu_order(cpus=None):
+  """The CPUs this process may use, ordered so that the first K are the best K places for K
+  single-threaded solver processes: one hardware thread per physical core first (a HiGHS solve runs
+  2x slower next to a busy SMT sibling), dealt round-robin over the L3 domains (CCDs) so that
+  neighbours share as little cache as possible; the second hardware threads come last.  Read from
+  sysfs; without it, the usual Linux numbering (second half = siblings) is assumed."""
+  import os
+  cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
+  allowed = set(cpus)
+
+  def read_list(path):
+    out = []
+    for part in open(path).read().strip().split(","):
+      if "-" in part:
+        a, b = part.split("-"); out.extend(range(int(a), int(b) + 1))
+      elif part:
+        out.append(int(part))
+    return out
+
+  try:
+    primary, secondary, domain = [], [], {}
+    for c in cpus:
+      sib = [x for x in read_list(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") if x in allowed]
+      (primary if c == min(sib) else secondary).append(c)
+      try:
+        domain[c] = min(read_list(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list"))
+      except Exception:
+        domain[c] = c // 8
+  except Exception:
+    half = max(1, len(cpus) // 2)
+    primary, secondary = cpus[:half], cpus[half:]
+    domain = {c: (c % half) // 8 for c in cpus}
+
+  def deal(group):
+    buckets = {}
+    for c in group:
+      buckets.setdefault(domain[c], []).append(c)
+    keys = sorted(buckets)
+    out, k = [], 0
+    while any(buckets[d] for d in keys):
+      for d in keys:
+        if k < len(buckets[d]):
+          out.append(buckets[d][k])
+      k += 1
+      if k > len(group):
+        break
+    return out
+
+  return deal(primary) + deal(secondary)
+
+
+def _pin_worker(slot_counter, lock, first_slot, order):
+  """Give every worker process its own physical core (see cpu_order), offset by the rank's
+  `first_slot` so that ranks sharing a host do not pile onto the same cores."""
   import os
   try:
     with lock:
       k = slot_counter.value
       slot_counter.value += 1
-    cpus = sorted(os.sched_getaffinity(0))
-    os.sched_setaffinity(0, {cpus[((first_slot + k) * stride) % len(cpus)]})
+    os.sched_setaffinity(0, {order[(first_slot + k) % len(order)]})
   except Exception:
     pass
 
 
 def default_worker_count(local_world: int = 1) -> int:
-  """LP worker processes per rank: one per physical core of this rank's share of the host, at most 32."""
+  """LP worker processes per rank.  One HiGHS solve wants a whole L3 slice: on the GPU box's host
+  (2 x 64 cores, 16 CCDs) 16 pinned solves run at full speed (0.43-0.46 s each, 24 solves/s), 32-48
+  give the best aggregate (30-31 solves/s at 0.9-1.3 s each) and 128 only 26 -- so a rank on its own
+  takes 24 workers and ranks sharing a host split 48 between them."""
   import os
   ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-  return int(max(2, min(24, (ncpu // 2) // max(1, local_world))))
+  local_world = max(1, int(local_world))
+  want = 24 if local_world == 1 else max(2, 48 // local_world)
+  return int(max(2, min(want, (ncpu // 2) // local_world)))
 
 
 # ---- worker-process side of the batch pipeline ---------------------------------------------------
@@ -569,9 +623,12 @@ class AlignPipeline:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     pin = int(os.environ.get("DALIGN_PIN_WORKERS", "1")) and ncpu >= 2 * self.depth * local_world
     init, initargs = (None, ())
+    order = cpu_order() if pin else []
     if pin:
-      stride = max(1, ncpu // (self.depth * local_world))
-      init, initargs = _pin_worker, (mpc.Value("i", 0), mpc.Lock(), local_rank * self.depth, stride)
+      # rank r of a host takes slots r, r + local_world, r + 2 local_world, ... of the common order:
+      # every rank's workers are spread over all L3 domains and no two ranks share a core
+      mine = order[local_rank::local_world] if local_world > 1 else order
+      init, initargs = _pin_worker, (mpc.Value("i", 0), mpc.Lock(), 0, mine)
     self.pool = cf.ProcessPoolExecutor(max_workers=self.depth, mp_context=mpc, initializer=init, initargs=initargs)
     list(self.pool.map(int, range(self.depth)))          # spawn them now, under that environment
     for k, v in saved.items():
@@ -587,9 +644,8 @@ class AlignPipeline:
         cpus = sorted(os.sched_getaffinity(0))
         half = len(cpus) // 2
         taken = set()
-        for k in range(self.depth):
-          w = ((local_rank * self.depth + k) * stride) % len(cpus)
-          taken.update({cpus[w], cpus[(w + half) % len(cpus)]})
+        for c in order[:self.depth]:
+          taken.update({c, cpus[(cpus.index(c) + half) % len(cpus)]})
         rest = set(cpus) - taken
         if len(rest) >= 8:
           self._old_affinity = set(cpus)

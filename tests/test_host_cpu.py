@@ -310,3 +310,25 @@ def test_cli_accepts_the_reference_flags():
     combine.combine = real
   flat = list(seen["args"]) + list(seen["kwargs"].values())
   assert "v.mp4" in flat and "a.mp3" in flat and "x_" in flat and True in flat
+
+
+def test_cpu_order_is_a_permutation_with_physical_cores_first():
+  from describealign_amd import align as A
+  cpus = sorted(os.sched_getaffinity(0))
+  order = A.cpu_order()
+  assert sorted(order) == cpus
+  def siblings(c):
+    try:
+      txt = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+    except OSError:
+      return {c}
+    out = set()
+    for part in txt.split(","):
+      if "-" in part:
+        a, b = part.split("-"); out.update(range(int(a), int(b) + 1))
+      elif part:
+        out.add(int(part))
+    return out & set(cpus)
+  n_cores = len({min(siblings(c)) for c in cpus})
+  first = order[:n_cores]
+  assert len({min(siblings(c)) for c in first}) == n_cores, "the first n_cores entries must be distinct physical cores"
