@@ -20,6 +20,7 @@ ABI_VERSION = 2
 PREC_F32, PREC_BF16 = 0, 1
 SIDE_VIDEO, SIDE_AUDIO = 0, 1
 MATCH_HASHED, MATCH_DENSE = 0, 1
+MATCH_RESIDENT_ROWS = 0x100
 
 ERR_CAPACITY = -3
 ERR_MISMATCH = -4
@@ -126,6 +127,7 @@ class Context:
     self.device = device
     self._n = {}
     self._channels = {}
+    self._rows = {}
 
   def close(self):
     if getattr(self, "_h", None) is not None and self._h:
@@ -168,6 +170,7 @@ class Context:
     self._check(self._lib.da_pcm_upload(self._h, side, _ptr(pcm), n, channels, planar))
     self._n[side] = n
     self._channels[side] = channels
+    self._rows.pop(side, None)
     return n, channels
 
   def features_resident(self, side: int, download: bool = True):
@@ -181,6 +184,7 @@ class Context:
     out = np.empty((5, max(le, 1)), dtype=np.float32)
     self._check(self._lib.da_features_resident(self._h, side, _ptr(out), out.shape[1], lengths))
     le, lo = lengths[0], lengths[1]
+    self._rows[side] = (out, le, lo)           # match_begin recognises these rows and skips their upload
     return [out[0, :le]] + [out[k, :lo] for k in range(1, 5)]      # row views of one buffer
 
   def features(self, pcm: np.ndarray, side: int = SIDE_VIDEO):
@@ -199,10 +203,30 @@ class Context:
       rows[k, :len(f)] = f
     return rows, (C.c_int64 * 2)(le, lo)
 
+  def _resident_rows(self, side, feats):
+    """(row buffer, lengths) if `feats` are the untouched row views features_resident() returned
+    last for `side` on this context, else None."""
+    held = self._rows.get(side)
+    if held is None or len(feats) != 5:
+      return None
+    out, le, lo = held
+    for k, f in enumerate(feats):
+      if not isinstance(f, np.ndarray) or f.base is not out or f.dtype != np.float32 or len(f) != (le if k == 0 else lo) \
+         or f.ctypes.data != out[k].ctypes.data:
+        return None
+    return out, (C.c_int64 * 2)(le, lo)
+
   def match_begin(self, video_features, audio_features, mode: int = MATCH_HASHED, rows=None):
     """Enqueue preparation + the similarity GEMM for one pair and return without waiting."""
-    vrows, vlen = self._pack_rows(video_features)
-    arows, alen = self._pack_rows(audio_features)
+    res = self._resident_rows(SIDE_VIDEO, video_features), self._resident_rows(SIDE_AUDIO, audio_features)
+    if res[0] is not None and res[1] is not None:
+      # the rows are the ones features_resident() just produced on this context: they are still on
+      # the device, so neither re-packed nor uploaded
+      (vrows, vlen), (arows, alen) = res
+      mode |= MATCH_RESIDENT_ROWS
+    else:
+      vrows, vlen = self._pack_rows(video_features)
+      arows, alen = self._pack_rows(audio_features)
     rb, re = (0, -1) if rows is None else rows
     self._pending_rows = (vrows, arows, vlen, alen)          # must outlive the asynchronous work
     self._check(self._lib.da_match_begin(self._h, _ptr(vrows), vrows.shape[1], vlen, _ptr(arows), arows.shape[1], alen,

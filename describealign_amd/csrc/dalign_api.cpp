@@ -264,22 +264,31 @@ int da_features(da_ctx* c, const int16_t* pcm, int64_t n, int channels, int plan
 // ------------------------------------------------------------------------------------- matching
 namespace {
 
-int upload_and_prep(da_ctx* c, Side& s, const float* feat, int64_t stride, const int64_t lengths[2], int is_video) {
+int upload_and_prep(da_ctx* c, Side& s, const float* feat, int64_t stride, const int64_t lengths[2], int is_video,
+                    bool resident) {
   const int64_t le = lengths[0], lo = lengths[1];
   const int64_t lmax = std::max(le, lo);
   s.lmax = lmax;
   s.mlen[0] = le; for (int j = 1; j < 5; ++j) s.mlen[j] = lo;
-  const int64_t dstride = lmax + kPad;
-  HIP_TRY(c, s.mfeat.ensure(sizeof(float) * 5 * (size_t)dstride));
-  HIP_TRY(c, hipMemsetAsync(s.mfeat.p, 0, sizeof(float) * 5 * (size_t)dstride, c->stream));
-  for (int j = 0; j < 5; ++j) {
-    const int64_t L = s.mlen[j];
-    if (L > 0)
-      HIP_TRY(c, hipMemcpyAsync(s.mfeat.as<float>() + (size_t)j * dstride, feat + (size_t)j * stride, sizeof(float) * L,
-                                hipMemcpyHostToDevice, c->stream));
-  }
+  int64_t dstride = lmax + kPad;
   PrepArgs p{};
-  p.feat = s.mfeat.as<float>(); p.row_stride = dstride; p.lmax = lmax; p.is_video = is_video;
+  if (resident && s.feat.p && s.len[0] == le && s.len[1] == lo && s.feat_stride >= lmax + kPad) {
+    // DA_MATCH_RESIDENT_ROWS: the rows da_features_resident left on the device (zero padded) are used
+    // in place; nothing is uploaded
+    dstride = s.feat_stride;
+    p.feat = s.feat.as<float>();
+  } else {
+    HIP_TRY(c, s.mfeat.ensure(sizeof(float) * 5 * (size_t)dstride));
+    HIP_TRY(c, hipMemsetAsync(s.mfeat.p, 0, sizeof(float) * 5 * (size_t)dstride, c->stream));
+    for (int j = 0; j < 5; ++j) {
+      const int64_t L = s.mlen[j];
+      if (L > 0)
+        HIP_TRY(c, hipMemcpyAsync(s.mfeat.as<float>() + (size_t)j * dstride, feat + (size_t)j * stride, sizeof(float) * L,
+                                  hipMemcpyHostToDevice, c->stream));
+    }
+    p.feat = s.mfeat.as<float>();
+  }
+  p.row_stride = dstride; p.lmax = lmax; p.is_video = is_video;
   const size_t n = (size_t)dstride;
   for (int j = 0; j < 5; ++j) {
     p.len[j] = s.mlen[j];
@@ -321,6 +330,8 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
                               const float* afeat, int64_t a_stride, const int64_t a_lengths[2], int mode,
                               int64_t row_begin, int64_t row_end) {
   if (!c) return DA_ERR_ARG;
+  const bool resident_rows = (mode & DA_MATCH_RESIDENT_ROWS) != 0;
+  mode &= ~DA_MATCH_RESIDENT_ROWS;
   if (!vfeat || !afeat || !v_lengths || !a_lengths || (mode != 0 && mode != 1))
     return fail(c, DA_ERR_ARG, "da_match: bad argument");
   if (v_lengths[0] > v_stride || a_lengths[0] > a_stride || v_lengths[1] > v_lengths[0] || a_lengths[1] > a_lengths[0])
@@ -329,8 +340,8 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
   c->match_ready = false; c->match_pending = false;       // fetch_ready is untouched: the previous results stay fetchable
   Side& V = c->side[0]; Side& A = c->side[1];
   HIP_TRY(c, hipEventRecord(c->prep_e0, c->stream));
-  int rc = upload_and_prep(c, V, vfeat, v_stride, v_lengths, 1); if (rc) return rc;
-  rc = upload_and_prep(c, A, afeat, a_stride, a_lengths, 0); if (rc) return rc;
+  int rc = upload_and_prep(c, V, vfeat, v_stride, v_lengths, 1, resident_rows); if (rc) return rc;
+  rc = upload_and_prep(c, A, afeat, a_stride, a_lengths, 0, resident_rows); if (rc) return rc;
   HIP_TRY(c, hipEventRecord(c->prep_e1, c->stream));
 
   // row lists from the energy rows (describealign.py:629-630, :657-658)

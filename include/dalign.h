@@ -32,7 +32,11 @@ enum {
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };       /* similarity-GEMM input precision */
 enum { DA_SIDE_VIDEO = 0, DA_SIDE_AUDIO = 1 };
 enum { DA_MATCH_HASHED = 0,  /* reference candidate vote (:649-660) applied to GEMM survivors */
-       DA_MATCH_DENSE = 1 }; /* every pair under the correlation threshold (no hash vote) */
+       DA_MATCH_DENSE = 1,   /* every pair under the correlation threshold (no hash vote) */
+       DA_MATCH_RESIDENT_ROWS = 0x100 }; /* OR-ed into `mode`: the rows passed are exactly those the last
+                                da_features_resident calls produced for both sides; their device copies
+                                are used in place and nothing is uploaded (the host rows are still read
+                                for the non-quiet frame lists) */
 
 int  da_create(int device_id, int precision, da_ctx** out);
 void da_destroy(da_ctx* ctx);

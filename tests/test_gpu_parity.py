@@ -440,3 +440,21 @@ def test_two_hour_stereo_pair_recovers_injected_offsets(ctx_bf16):
   track, fac = c.stretch_resident(x, y, False)
   assert track.shape == (pair.video.shape[1], 2) and np.all(np.isfinite(fac))
   assert int(np.abs(track.astype(np.int32)).max()) >= 32000            # peak-normalised
+
+
+def test_resident_rows_fast_path_equals_uploaded_rows(ctx, native):
+  """Rows that features_resident() just produced are matched from their device copies (no re-pack,
+  no upload); copies of the same rows take the upload path: identical matches either way."""
+  pair = cases.align_case("a40")
+  vf = ctx.features(pair.video, 0); af = ctx.features(pair.audio, 1)
+  assert ctx._resident_rows(0, vf) is not None and ctx._resident_rows(1, af) is not None
+  fast = ctx.match(vf, af)
+  vf2, af2 = [f.copy() for f in vf], [f.copy() for f in af]
+  assert ctx._resident_rows(0, vf2) is None
+  slow = ctx.match(vf2, af2)
+  for a_, b_ in zip(fast, slow):
+    assert np.array_equal(a_, b_)
+  assert len(fast[0]) > 1000
+  # a second upload for one side invalidates its resident rows
+  ctx.pcm_upload(0, pair.video)
+  assert ctx._resident_rows(0, vf) is None
