@@ -226,7 +226,11 @@ __device__ __forceinline__ void threshold_rows2(const f32x16 (&acc)[3], float th
   const f32x2 x0 = {acc[0][g_hi - 1], acc[0][g_hi]};
   const f32x2 x1 = {acc[1][g_hi - 1], acc[1][g_hi]};
   const f32x2 x2 = {acc[2][g_hi - 1], acc[2][g_hi]};
-  const f32x2 pr = x0 * x1 * x2;
+  // two packed multiplies for the two rows (the compiler scalarises the vector expression: the
+  // operands come out of AGPRs, so pairing them costs nothing when asked for explicitly)
+  f32x2 pr;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(pr) : "v"(x0), "v"(x1));
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(pr) : "v"(pr), "v"(x2));
   asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[1]), "v"(thr) : "vcc");
   asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[0]), "v"(thr) : "vcc");
 }
