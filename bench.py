@@ -72,9 +72,13 @@ def main():
 
   import torch
   from describealign_amd import _native, synth, distrib
-  grp = distrib.Group("nccl")
+  # DALIGN_DIST_BACKEND=gloo and DALIGN_BENCH_DEVICE=<id> exist so that the multi-rank launch path
+  # can be exercised on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device)
+  grp = distrib.Group(os.environ.get("DALIGN_DIST_BACKEND", "nccl"))
   rank, local_rank, world = grp.rank, grp.local_rank, grp.world
   device = local_rank if world > 1 else 0
+  if os.environ.get("DALIGN_BENCH_DEVICE"):
+    device = int(os.environ["DALIGN_BENCH_DEVICE"])
   from describealign_amd import align as A
 
   if args.pipeline < 0:

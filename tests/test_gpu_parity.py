@@ -458,3 +458,25 @@ def test_resident_rows_fast_path_equals_uploaded_rows(ctx, native):
   # a second upload for one side invalidates its resident rows
   ctx.pcm_upload(0, pair.video)
   assert ctx._resident_rows(0, vf) is None
+
+
+def test_bench_launch_contract_two_ranks(tmp_path):
+  """The driver launches bench.py under torch.distributed.run, one rank per GPU.  With only one
+  GPU here both ranks share it (gloo instead of RCCL, which refuses two ranks on one device): rank 0
+  must print exactly one JSON line with the contract's keys."""
+  import subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, DALIGN_DIST_BACKEND="gloo", DALIGN_BENCH_DEVICE="0")
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+         "--pipeline", "2", "--no-cpu-baseline"]
+  res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+  assert res.returncode == 0, res.stderr[-2000:]
+  lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, res.stdout[-2000:]
+  d = json.loads(lines[0])
+  for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+    assert key in d, key
+  assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+  assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
