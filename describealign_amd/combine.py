@@ -285,8 +285,13 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
   return results
 
 
-def _worker(gpu, indices, pairs, kwargs, precision):
+def _worker(gpu, indices, pairs, kwargs, precision, n_workers=1):
   from . import _native
+  if n_workers > 1:
+    # one process per GPU on one host: tell the batch pipeline, so that the LP worker pools of the
+    # processes split the host's cores between them instead of all pinning to the same ones
+    os.environ["LOCAL_WORLD_SIZE"] = str(n_workers)
+    os.environ["LOCAL_RANK"] = str(gpu)
   ctx = _native.Context(gpu, precision)
   todo = [pairs[k] for k in indices]
   if len(todo) >= 3:
@@ -337,7 +342,7 @@ def combine(video, audio, stretch_audio=False, yes=False, prepend="ad_", no_pitc
   else:
     import multiprocessing as mp
     mpctx = mp.get_context("spawn")
-    procs = [mpctx.Process(target=_worker, args=(g, idx, pairs, kwargs, prec))
+    procs = [mpctx.Process(target=_worker, args=(g, idx, pairs, kwargs, prec, gpus))
              for g, idx in enumerate(shard_pairs(len(pairs), gpus)) if idx]
     for p in procs:
       p.start()
