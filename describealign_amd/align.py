@@ -212,17 +212,17 @@ def solve_trend_lp(x, y, pricing=None, reduce=None):
   """The reference's scipy.optimize.linprog call (:841-858): HiGHS dual simplex, IPM retry on
   status 4.
 
-  reduce: for short inputs the optimum of this LP has every rate_jump and rate_change variable at
-  zero -- a rate difference between the files is absorbed by median_slope; they only come into play
-  when the rate changes inside the file, or when the running sum of the slope-row duals reaches the
-  rate_change cost of 40 000, which long files do (the 22-minute golden pair does after 273 of its
-  3 122 fit points, with rate jumps of 7e-3 frames in the optimum).  So for n <= 2000 fit points
-  (DALIGN_LP_REDUCE=0 never, =1 always) the LP is first solved without those 4n-6 columns and the
-  n-2 rows they alone appear in (same solver, same call), and a dual certificate
-  (_rate_terms_certificate) decides whether that optimum, padded with zeros, is optimal for the full
-  LP.  If it is, it is the solution the reference's call returns (the optimum is unique: every cost
-  is positive; agreement <= 1e-8 frames on all recorded and synthetic cases), about 3x sooner (10-minute
-  golden pair: 0.46 -> 0.16 s).  If it is not, the full LP is solved exactly as the reference does.
+  reduce (opt-in: reduce=True or DALIGN_LP_REDUCE=1; off by default, so the default IS the
+  reference's call): for short inputs the optimum of this LP usually has every rate_jump and
+  rate_change variable at zero -- a rate difference between the files is absorbed by median_slope;
+  they only come into play when the rate changes inside the file, or when the running sum of the
+  slope-row duals reaches the rate_change cost of 40 000, which long files do.  The LP is then first
+  solved without those 4n-6 columns and the n-2 rows they alone appear in (same solver, same call),
+  and a dual certificate (_rate_terms_certificate) decides whether that optimum, padded with zeros,
+  is optimal for the full LP; if not, the full LP is solved exactly as the reference does.  The
+  certificate proves OPTIMALITY, not that HiGHS would return the same vertex when the optimum is
+  not unique (median_slope has zero cost; L1 fits can tie on exactly colinear data), which is why
+  this shortcut is not the default (10-minute golden pair: 0.46 -> 0.16 s, solution equal to 1e-11).
 
   pricing="reference" (the default) keeps HiGHS' default steepest-edge pricing; "dantzig" / "devex"
   (or DALIGN_LP_PRICING) select another rule for the full solve: same optimum, 1.3-2x faster on an
@@ -231,7 +231,7 @@ def solve_trend_lp(x, y, pricing=None, reduce=None):
   n = len(x)
   if reduce is None:
     env = os.environ.get("DALIGN_LP_REDUCE", "")
-    reduce = (n <= 2000) if env == "" else (env != "0")
+    reduce = (env == "1")
   s = _solve_without_rate_terms(c, A, b, bounds, n, np.diff(x)) if (reduce and n >= 4) else None
   if s is None:
     s = _solve_full_lp(c, A, b, bounds, pricing)
@@ -778,11 +778,17 @@ class AlignPipeline:
       self._free.append((state["fname"], state["fsize"]))
     return out
 
-  def run(self, jobs, timings=None):
+  def run(self, jobs, timings=None, window=None):
+    """Yields the results in submission order.  `window` = pairs admitted before the oldest result
+    is waited for (default 2 x workers + 4 per GPU, or DALIGN_PIPELINE_WINDOW): callers that hold
+    per-pair host memory until a pair's result arrives (combine --stretch_audio) narrow it."""
     import concurrent.futures as cf
     import os
     pending = []          # (future of the pair's result, tm) in submission order
     n_gpu = len(self.gpu_ctxs)
+    if window is None:
+      window = int(os.environ.get("DALIGN_PIPELINE_WINDOW", 2 * self.depth + 4 * n_gpu))
+    window = max(1, int(window))
 
     def finish(entry):
       done, tm = entry
@@ -801,7 +807,7 @@ class AlignPipeline:
       pending.append((done, tm))
       # results are handed back in submission order, so pairs that finished behind a slow LP still
       # count as pending: the window has to be wider than the worker pool or workers idle
-      while len(pending) > int(os.environ.get("DALIGN_PIPELINE_WINDOW", 2 * self.depth + 4 * n_gpu)):
+      while len(pending) >= window:
         yield finish(pending.pop(0))
     for g in range(n_gpu):          # the last pair of every context still has to be copied out
       self.gpu_threads[g].submit(self._flush_deferred, self.gpu_ctxs[g])

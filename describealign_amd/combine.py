@@ -10,8 +10,9 @@ worker process per GPU (`--gpus`).
 
 --stretch_audio (replace_aligned_segments, :230-416, and the loudness / peak handling around it,
 :1135-1153) runs on the GPU as well: the PCM uploaded for the feature kernels stays resident and
-only the finished int16 track is copied back.  Out of scope: the GUI, the ffprobe-based
-"is the first track already AD" check (:460-462; the original track is always titled "original").
+only the finished int16 track is copied back.  The key-frame probe of the default mux (:443-458) goes
+through the ffprobe binary next to ffmpeg.  Out of scope: the GUI, the ffprobe-based "is the first
+track already AD" check (:460-462; the original track is always titled "original").
 """
 from __future__ import annotations
 
@@ -44,38 +45,88 @@ def ensure_folders_exist(dirs):
       os.makedirs(d)
 
 
+def _candidate_files(path):
+  """The files an input path stands for: the entries of a list, the children of a directory,
+  or the file itself.  Missing inputs raise the reference's messages (:97-110)."""
+  if isinstance(path, list):
+    listed = [os.path.abspath(p) for p in path]
+    missing = next((p for p in listed if not os.path.isfile(p)), None)
+    if missing is not None:
+      raise RuntimeError(f"No file found at input path:\n  {missing}")
+    return listed, path
+  where = os.path.abspath(path)
+  if os.path.isfile(where):
+    return [where], where
+  if not os.path.isdir(where):
+    raise RuntimeError(f"No file or directory found at input path:\n  {where}")
+  children = glob.glob(os.path.join(glob.escape(where), "*"))
+  if not children:
+    raise RuntimeError(f"Empty input directory:\n  {where}")
+  return children, where
+
+
 def get_sorted_filenames(path, extensions, alt_extensions=set([])):
-  """A file, a directory or a list of files -> naturally sorted matching files and a flag per
-  file telling whether it only matched the alternative extensions (:94-121)."""
-  if type(path) is list:
-    files = [os.path.abspath(f) for f in path]
-    for f in files:
-      if not os.path.isfile(f):
-        raise RuntimeError(f"No file found at input path:\n  {f}")
-  else:
-    path = os.path.abspath(path)
-    if os.path.isdir(path):
-      files = glob.glob(glob.escape(path) + "/*")
-      if len(files) == 0:
-        raise RuntimeError(f"Empty input directory:\n  {path}")
-    else:
-      if not os.path.isfile(path):
-        raise RuntimeError(f"No file or directory found at input path:\n  {path}")
-      files = [path]
-  ext_of = lambda f: os.path.splitext(f)[1][1:]
-  files = [f for f in files if ext_of(f) in extensions | alt_extensions]
-  if len(files) == 0:
-    raise RuntimeError("\n".join([
-        f"No files with valid extensions found at input path:\n  {path}",
-        "Did you accidentally put the audio filepath before the video filepath?",
-        "The video path should be the first positional input, audio second.",
-        "Or maybe you need to add a new extension to this script's regex?",
-        f"valid extensions for this input are:\n  {extensions}"]))
-  files = sorted(files, key=_natural_key)
-  return files, [0 if ext_of(f) in extensions else 1 for f in files]
+  """describealign.get_sorted_filenames (:94-121): the media files behind `path` in natural
+  order, plus per file 0 when its extension is one of `extensions` and 1 when it only matched
+  `alt_extensions`."""
+  candidates, shown = _candidate_files(path)
+  kind = {}
+  for name in candidates:
+    ext = os.path.splitext(name)[1][1:]
+    if ext in extensions:
+      kind[name] = 0
+    elif ext in alt_extensions:
+      kind[name] = 1
+  if not kind:
+    raise RuntimeError(f"No files with valid extensions found at input path:\n  {shown}\n"
+                       "Did you accidentally put the audio filepath before the video filepath?\n"
+                       "The video path should be the first positional input, audio second.\n"
+                       "Or maybe you need to add a new extension to this script's regex?\n"
+                       f"valid extensions for this input are:\n  {extensions}")
+  ordered = sorted(kind, key=_natural_key)
+  return ordered, [kind[name] for name in ordered]
 
 
 from .distrib import shard_pairs  # noqa: E402  (round-robin pair -> GPU assignment)
+
+
+def parse_key_frame_times(ffprobe_json, entry="pts_time"):
+  """Key-frame timestamps out of `ffprobe -show_frames -skip_frame nokey -of json` output
+  (what ffmpeg.probe hands get_key_frame_data, :443-449): frames lacking the entry are skipped."""
+  import json
+  frames = json.loads(ffprobe_json).get("frames", [])
+  return np.array([float(f[entry]) for f in frames if entry in f], dtype=np.float64)
+
+
+def get_key_frame_data(video_file, time=None, entry="pts_time", ffprobe=None):
+  """describealign.get_key_frame_data (:443-449) through the ffprobe binary directly."""
+  ffprobe = ffprobe or media.find_ffprobe()
+  if ffprobe is None:
+    raise RuntimeError("no ffprobe binary on PATH")
+  interval = f"%+{max(60, time + 40)}" if time is not None else "%"
+  argv = [ffprobe, "-show_format", "-show_streams", "-of", "json", "-select_streams", "V", "-show_frames",
+          "-skip_frame", "nokey", "-read_intervals", interval, "-show_entries", "frame=" + entry, video_file]
+  res = subprocess.run(argv, capture_output=True)
+  if res.returncode != 0:
+    raise RuntimeError("ffprobe error: " + res.stderr.decode("utf-8", "replace"))
+  return parse_key_frame_times(res.stdout.decode("utf-8", "replace"), entry)
+
+
+def closest_key_frame_time(key_frame_times, time):
+  """Midpoint between the key frames on either side of `time` (:451-458): ffmpeg's -ss then cuts
+  at the last key frame before the described audio starts."""
+  key_frame_times = np.asarray(key_frame_times, dtype=np.float64)
+  if len(key_frame_times) == 0:
+    key_frame_times = np.array([0.0])
+  later = key_frame_times[key_frame_times > time]
+  earlier = key_frame_times[key_frame_times <= time]
+  nxt = np.min(later) if len(later) > 0 else time
+  prv = np.max(earlier) if len(earlier) > 0 else nxt
+  return (prv + nxt) / 2.
+
+
+def get_closest_key_frame_time(video_file, time, ffprobe=None):
+  return closest_key_frame_time(get_key_frame_data(video_file, time, ffprobe=ffprobe), time)
 
 
 def _mux_command(ffmpeg, video_file, audio_desc_file, output_filename, setts_cmd, video_offset,
@@ -162,9 +213,10 @@ def _finish_pair(outputs, video_file, audio_desc_file, has_audio_extension, ctx,
                                            None if has_audio_extension else video_file)
   elif ffmpeg is not None and not has_audio_extension:
     print("  processing output file...                   \r", end='')
-    # without ffprobe's key-frame table the cut point is the offset itself
+    # to make ffmpeg cut at the last key frame before the audio starts, use a timestamp after it (:1162-1164)
+    after_start_key_frame = get_closest_key_frame_time(video_file, video_offset)
     argv = _mux_command(ffmpeg, video_file, audio_desc_file, output_filename, setts_cmd, video_offset,
-                        max(0.0, video_offset), median_slope)
+                        after_start_key_frame, median_slope)
     res = subprocess.run(argv, capture_output=True)
     if res.returncode != 0:
       print("  ERROR: ffmpeg failed to write output file: " + output_filename)
@@ -215,10 +267,13 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
   pool, `decode_ahead` pairs in flight), the GPU stages of pair k+1 and the host-side LP / DP stages
   of pair k overlap (align.AlignPipeline).  With stretch_audio the decoded PCM of the pairs in flight
   is kept on the host and uploaded again (to a second context on the same GPU) when a pair's nodes
-  arrive, so at most six pairs are in flight.  Returns the per-pair results."""
+  arrive; a semaphore admits at most `workers + 2` (<= 6) such pairs between decode and the finished
+  track (2 h stereo = 2.5 GB of PCM per pair), and the pipeline window is narrowed to match.
+  Returns the per-pair results."""
   import concurrent.futures as cf
   import contextlib
   import io
+  import threading
   from . import _native
   from .align import AlignPipeline, default_worker_count
   work = []
@@ -236,8 +291,14 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
     return results
   decoders = cf.ThreadPoolExecutor(max_workers=2)
   decoded = {}
-  kept = {}                  # stretch_audio: PCM of the pairs in flight
+  kept = {}                  # stretch_audio: PCM of the pairs in flight (bounded by `held`)
   stretch_ctx = _native.Context(ctx.device, ctx.precision) if stretch_audio else None
+  local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+  workers = lp_workers or min(default_worker_count(local_world), max(2, len(work)))
+  if stretch_audio:
+    workers = min(workers, 4)
+  max_held = workers + 2
+  held = threading.BoundedSemaphore(max_held)
 
   def request(k):
     if k < len(work) and k not in decoded:
@@ -248,6 +309,8 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
     def job(c):
       for ahead in range(k, k + 1 + decode_ahead):
         request(ahead)
+      if stretch_audio:
+        held.acquire()         # released when pair k's track has been written (below)
       fv, fa = decoded.pop(k)
       video_arr, audio_desc_arr = fv.result(), fa.result()
       if stretch_audio:
@@ -257,15 +320,11 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
       return vf, af
     return job
 
-  local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
-  workers = lp_workers or min(default_worker_count(local_world), max(2, len(work)))
-  if stretch_audio:
-    workers = min(workers, 4)          # pipeline depth = workers + 2 pairs of PCM held on the host
   quiet = contextlib.redirect_stdout(io.StringIO())          # align()'s progress lines would interleave
   with AlignPipeline(ctx, lp_workers=workers) as pipe:
     if len(work) >= 8:
       pipe.warm()
-    it = pipe.run(make_job(k) for k in range(len(work)))
+    it = pipe.run((make_job(k) for k in range(len(work))), window=(max_held if stretch_audio else None))
     for k in range(len(work)):
       with quiet:
         outputs = next(it)
@@ -276,9 +335,13 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
         stretch_ctx.pcm_upload(_native.SIDE_VIDEO, video_arr)
         stretch_ctx.pcm_upload(_native.SIDE_AUDIO, audio_desc_arr)
         del video_arr, audio_desc_arr
-      results.append(_finish_pair(outputs, video_file, audio_desc_file, has_audio_extension,
-                                  stretch_ctx if stretch_audio else ctx, out, stretch_audio, no_pitch_correction,
-                                  alignment_dir))
+      try:
+        results.append(_finish_pair(outputs, video_file, audio_desc_file, has_audio_extension,
+                                    stretch_ctx if stretch_audio else ctx, out, stretch_audio, no_pitch_correction,
+                                    alignment_dir))
+      finally:
+        if stretch_audio:
+          held.release()
   decoders.shutdown(wait=True)
   if stretch_ctx is not None:
     stretch_ctx.close()

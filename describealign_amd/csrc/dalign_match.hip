@@ -601,11 +601,8 @@ void launch_match_f32(const MatchArgs& a, hipStream_t s) {
 void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   if (a.n_v <= 0 || a.n_a <= 0) return;
   const int smem = kBfBuffers * kBfBufBytes + kBfConsumers * kBfSurv * 8 + kBfBuffers * kBfGroup * 32 * (4 + 4);
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    once = true;
-  }
+  // per launch: the attribute is per device and contexts on several devices / threads share this code
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   const int64_t rows_per_block = 32 * kBfConsumers;
   const int64_t bx = (a.n_v + rows_per_block - 1) / rows_per_block;
   const int64_t atiles = (a.n_a + 31) / 32;

@@ -21,10 +21,11 @@ def as_pcm_int16(arr) -> np.ndarray:
   if arr.dtype == np.int16:
     return arr
   if arr.dtype == np.float16:
-    # float16 holds every value the reference's cast produced exactly; samples above 2048 were
-    # already rounded by that cast and survive the round trip (the kernel's own int16 ->
-    # float16 rounding is then the identity on them).
-    return arr.astype(np.int16)
+    # The reference's int16 -> float16 cast (:156) rounds samples above 2048 to the float16 grid;
+    # 32760..32767 round UP to 32768.0, which int16 cannot hold (a plain astype would wrap to
+    # -32768 and flip the sample's sign).  Clamping to 32767 is lossless for the kernel: its own
+    # int16 -> float16 rounding sends 32767 back to 32768.0, every other value is a fixed point.
+    return np.clip(arr.astype(np.float32), -32768.0, 32767.0).astype(np.int16)
   raise TypeError(f"PCM must be int16 or the reference's float16 array, not {arr.dtype}")
 
 

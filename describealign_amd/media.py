@@ -22,30 +22,73 @@ def find_ffmpeg():
   return shutil.which("ffmpeg")
 
 
-def _downmix(pcm: np.ndarray, num_channels: int) -> np.ndarray:
+def find_ffprobe():
+  exe = shutil.which("ffprobe")
+  if exe is None and find_ffmpeg() is not None:          # static builds ship the two side by side
+    cand = os.path.join(os.path.dirname(find_ffmpeg()), "ffprobe")
+    exe = cand if os.path.isfile(cand) else None
+  return exe
+
+
+def _read_native(media_file, ext, num_channels):
+  """44.1 kHz 16-bit PCM WAV / raw s16le without ffmpeg.  Returns None when the file is not
+  exactly what ffmpeg would hand back untouched (other rate / width / channel count, extensible
+  or float WAV headers, ragged raw files): those go through ffmpeg, whose resampler and downmix
+  the reference's results depend on (:149-157)."""
+  try:
+    if ext == ".wav":
+      with wave.open(media_file, "rb") as w:
+        if w.getframerate() != AUDIO_SAMPLE_RATE or w.getsampwidth() != 2 or w.getnchannels() != num_channels:
+          return None
+        raw = w.readframes(w.getnframes())
+      return np.ascontiguousarray(np.frombuffer(raw, dtype="<i2").reshape(-1, num_channels).T)
+    pcm = np.fromfile(media_file, dtype="<i2")        # raw files carry no header: taken as num_channels s16le
+    if len(pcm) % num_channels:
+      return None
+    return np.ascontiguousarray(pcm.reshape(-1, num_channels).T)
+  except (wave.Error, EOFError, OSError, ValueError):
+    return None
+
+
+def _downmix_like_swresample(pcm: np.ndarray, num_channels: int) -> np.ndarray:
+  """Channel-count change for natively read PCM when no ffmpeg binary exists (test media only;
+  with ffmpeg on PATH the file is decoded by ffmpeg itself).  Stereo -> mono is the average with
+  the half rounded up, (L + R + 1) >> 1, which is what swresample's int16 path produces for its
+  0.5 / 0.5 mix matrix; mono -> stereo duplicates the channel."""
   c = pcm.shape[0]
   if c == num_channels:
     return pcm
-  if num_channels == 1:
-    return np.clip(np.round(pcm.astype(np.float32).mean(axis=0)), -32768, 32767).astype(np.int16)[None, :]
-  if c == 1:
+  if num_channels == 1 and c == 2:
+    return ((pcm[0].astype(np.int32) + pcm[1].astype(np.int32) + 1) >> 1).astype(np.int16)[None, :]
+  if num_channels == 2 and c == 1:
     return np.repeat(pcm, 2, axis=0)
-  return pcm[:num_channels]
+  return None
+
+
+def _read_wav_any_channels(media_file):
+  try:
+    with wave.open(media_file, "rb") as w:
+      if w.getframerate() != AUDIO_SAMPLE_RATE or w.getsampwidth() != 2:
+        return None
+      raw = w.readframes(w.getnframes())
+      return np.ascontiguousarray(np.frombuffer(raw, dtype="<i2").reshape(-1, w.getnchannels()).T)
+  except (wave.Error, EOFError, OSError, ValueError):
+    return None
 
 
 def parse_audio_from_file(media_file, num_channels=2) -> np.ndarray:
   ext = os.path.splitext(media_file)[1].lower()
-  if ext == ".wav":
-    with wave.open(media_file, "rb") as w:
-      if w.getframerate() == AUDIO_SAMPLE_RATE and w.getsampwidth() == 2:
-        raw = w.readframes(w.getnframes())
-        pcm = np.frombuffer(raw, dtype="<i2").reshape(-1, w.getnchannels()).T
-        return np.ascontiguousarray(_downmix(pcm, num_channels))
-  if ext in (".raw", ".s16le", ".pcm"):
-    pcm = np.fromfile(media_file, dtype="<i2")
-    return np.ascontiguousarray(pcm.reshape(1, -1) if num_channels == 1 else pcm.reshape(-1, 2).T)
+  if ext in (".wav", ".raw", ".s16le", ".pcm"):
+    pcm = _read_native(media_file, ext, num_channels)
+    if pcm is not None:
+      return pcm
   exe = find_ffmpeg()
   if exe is None:
+    if ext == ".wav":              # no decoder at all: 1 <-> 2 channel WAVs are still usable
+      pcm = _read_wav_any_channels(media_file)
+      pcm = None if pcm is None else _downmix_like_swresample(pcm, num_channels)
+      if pcm is not None:
+        return np.ascontiguousarray(pcm)
     raise RuntimeError(f"cannot decode {media_file}: no ffmpeg binary on PATH "
                        "(only 44.1 kHz 16-bit .wav and raw s16le are read natively)")
   cmd = [exe, "-i", media_file, "-f", "s16le", "-acodec", "pcm_s16le", "-af", "aresample=async=1:first_pts=0",

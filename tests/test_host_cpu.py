@@ -148,6 +148,83 @@ def test_file_pairing_and_sharding(tmp_path):
   assert shard_pairs(3, 8)[3:] == [[]] * 5
 
 
+def test_file_pairing_errors_and_alt_extensions(tmp_path):
+  """The remaining branches of get_sorted_filenames (:94-121): list input, missing list entry,
+  empty directory, no valid extension (the reference's five-line message), audio files accepted
+  through the alternative extensions and flagged 1."""
+  from describealign_amd import combine as Cb
+  d = tmp_path / "in"; d.mkdir()
+  with pytest.raises(RuntimeError, match="Empty input directory"):
+    Cb.get_sorted_filenames(str(d), Cb.VIDEO_EXTENSIONS)
+  for n in ("b2.mkv", "b10.mkv", "a.flac", "x.txt"):
+    (d / n).write_bytes(b"x")
+  files, alt = Cb.get_sorted_filenames(str(d), Cb.VIDEO_EXTENSIONS, Cb.AUDIO_EXTENSIONS)
+  assert [os.path.basename(f) for f in files] == ["a.flac", "b2.mkv", "b10.mkv"] and alt == [1, 0, 0]
+  files, alt = Cb.get_sorted_filenames([str(d / "b10.mkv"), str(d / "b2.mkv")], Cb.VIDEO_EXTENSIONS)
+  assert [os.path.basename(f) for f in files] == ["b2.mkv", "b10.mkv"] and alt == [0, 0]
+  with pytest.raises(RuntimeError, match="No file found at input path"):
+    Cb.get_sorted_filenames([str(d / "nope.mkv")], Cb.VIDEO_EXTENSIONS)
+  with pytest.raises(RuntimeError) as e:
+    Cb.get_sorted_filenames(str(d / "x.txt"), Cb.VIDEO_EXTENSIONS)
+  msg = str(e.value).split("\n")
+  assert msg[0] == "No files with valid extensions found at input path:" and msg[1].strip().endswith("x.txt")
+  assert msg[2] == "Did you accidentally put the audio filepath before the video filepath?"
+  assert msg[5] == "valid extensions for this input are:" and len(msg) == 7
+
+
+def test_key_frame_time_follows_the_reference():
+  """get_closest_key_frame_time (:451-458): expectations recorded from the reference's function fed
+  the same key-frame tables; the parser reads what `ffprobe -of json -show_frames` prints."""
+  from describealign_amd import combine as Cb
+  for kf, t, want in (([0.0, 2.5, 5.0, 7.5, 10.0], 6.1, 6.25), ([0.0, 2.5], 9.0, 5.75), ([], 3.0, 1.5),
+                      ([4.0, 8.0], 1.0, 4.0), ([0.0, 5.0], 5.0, 5.0)):
+    assert Cb.closest_key_frame_time(kf, t) == want
+  canned = json.dumps({"frames": [{"pts_time": "0.000000"}, {"pts_time": "2.502500", "side_data_list": [{}]},
+                                  {"pkt_pos": "1"}, {"pts_time": "5.005000"}],
+                       "streams": [], "format": {}})
+  got = Cb.parse_key_frame_times(canned)
+  assert got.tolist() == [0.0, 2.5025, 5.005]
+  assert Cb.closest_key_frame_time(got, 3.0) == (2.5025 + 5.005) / 2
+  if Cb.media.find_ffprobe() is None:
+    with pytest.raises(RuntimeError, match="no ffprobe binary"):
+      Cb.get_key_frame_data("video.mp4", 3.0)
+
+
+def test_media_native_reader_only_takes_what_ffmpeg_would_return_untouched(tmp_path):
+  """float / extensible WAV headers, other channel counts and ragged raw files must not
+  crash or be silently mis-decoded by the native reader."""
+  import wave
+  from describealign_amd import media
+  st = np.stack([np.arange(-5, 5, dtype=np.int16), np.arange(10, 0, -1, dtype=np.int16) * 3])
+  media.write_wav(str(tmp_path / "st.wav"), st)
+  assert np.array_equal(media.parse_audio_from_file(str(tmp_path / "st.wav"), 2), st)
+  mono = media.parse_audio_from_file(str(tmp_path / "st.wav"), 1)      # no ffmpeg here: (L + R + 1) >> 1
+  if media.find_ffmpeg() is None:
+    assert np.array_equal(mono[0], (st[0].astype(np.int32) + st[1] + 1) >> 1)
+  (tmp_path / "bad.wav").write_bytes(b"RIFF\x00\x00\x00\x00WAVEjunk")
+  (tmp_path / "odd.raw").write_bytes(b"\x01\x00\x02\x00\x03\x00")
+  if media.find_ffmpeg() is None:
+    for name, ch in (("bad.wav", 1), ("odd.raw", 2)):
+      with pytest.raises(RuntimeError, match="cannot decode"):
+        media.parse_audio_from_file(str(tmp_path / name), ch)
+  assert media.parse_audio_from_file(str(tmp_path / "odd.raw"), 1).tolist() == [[1, 2, 3]]
+  with wave.open(str(tmp_path / "r48.wav"), "wb") as w:
+    w.setnchannels(1); w.setsampwidth(2); w.setframerate(48000); w.writeframes(b"\x00\x00" * 8)
+  assert media._read_native(str(tmp_path / "r48.wav"), ".wav", 1) is None
+
+
+def test_float16_pcm_full_scale_does_not_wrap():
+  """the reference's float16 array holds 32768.0 for samples 32760..32767; converting it
+  back for the int16 kernel input must clamp, not wrap to -32768."""
+  from describealign_amd import features
+  pcm = np.array([[32767, 32760, 32759, -32768, 0, 2049, -2051]], dtype=np.int16)
+  f16 = pcm.astype(np.float16)
+  back = features.as_pcm_int16(f16)
+  assert back.dtype == np.int16 and back[0, 0] == 32767 and back[0, 1] == 32767 and back[0, 2] == 32752 and back[0, 3] == -32768
+  # the kernel's own int16 -> float16 rounding then reproduces the reference's array exactly
+  assert np.array_equal(back.astype(np.float16), f16)
+
+
 def test_wav_round_trip(tmp_path):
   from describealign_amd import media, synth
   pcm = synth.programme(9, 44100).astype(np.int16)[None, :]
