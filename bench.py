@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the alignment hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg1|cfg2|cfg3-short] [--precision f32|bf16]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg-small] [--precision f32|bf16]
 
 One step = one pass of the hot path over one (video, AD) pair whose PCM is already resident in
-HBM: feature kernel (both sides) -> similarity GEMM + verification -> chain DP -> host LP ->
-banded extension + second DP -> nodes.  metric = aligned audio-hours/s (video-side duration of
-the pairs processed / wall time), whole job over all ranks.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank aligns its own pair: a directory batch
-shards with no data-path collective (weak scaling).
+HBM: feature kernel (both sides) -> similarity GEMM + verification -> chain DP (device) -> host
+LP -> banded extension + second DP -> nodes.  metric = aligned audio-hours/s (video-side duration
+of the pairs processed / wall time), whole job over all ranks.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank aligns its own pair: a directory batch shards
+with no data-path collective (weak scaling).
 
 Workloads (BASELINE.json configs):
-  cfg1  configs[1] stand-in: 1320 s video / ~1558 s AD, 10 jumps + 200 s intro, mono, fp32 GEMM  (default)
-  cfg2  configs[2]: 7200 s stereo pair, 10 jumps, bf16 MFMA GEMM
+  cfg2  configs[2]: 7200 s stereo pair, 10 jumps, bf16 MFMA GEMM -- the largest single-GPU
+        configuration and the north_star target                                      (default)
+  cfg1  configs[1] stand-in: 1320 s video / ~1558 s AD, 10 jumps + 200 s intro, mono, fp32 GEMM
+        (reported as the `secondary` object of the same JSON line at N = 1)
+
+Timed region (steady state of a directory batch).  The pairs go through ONE primed pipeline:
+W warm-up pairs, K timed pairs and a tail that keeps the pipeline full are submitted as one
+stream; results come back in order; the clock runs from the arrival of result W (the last
+warm-up result; the start of the run when W = 0) to the arrival of result W + K.  A barrier and a
+device synchronisation bracket the run of the stream (before the first job is submitted, after the
+last result); inside it the K timed results are complete on the host when the clock stops, so no
+work of the timed steps is left out -- what is NOT waited for at that instant is the in-flight
+work of the tail pairs, which is not part of the K steps.  elapsed = max over ranks.
 """
 import argparse
 import json
@@ -28,7 +39,7 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
   "cfg1": dict(desc="configs[1] stand-in: synthetic 1320 s video / ~1558 s AD, 10 jumps + 200 s intro, mono",
                seconds=1320.0, n_jumps=10, first_gap=200.0, channels=1, precision="f32"),
-  "cfg2": dict(desc="configs[2]: synthetic 7200 s stereo pair, 10 jumps + 200 s intro",
+  "cfg2": dict(desc="configs[2]: synthetic 7200 s (2 h) stereo pair, 10 injected offset jumps + 200 s intro",
                seconds=7200.0, n_jumps=10, first_gap=200.0, channels=2, precision="bf16"),
   "cfg-small": dict(desc="600 s mono pair, 5 jumps (CI-sized)",
                     seconds=600.0, n_jumps=5, first_gap=60.0, channels=1, precision="f32"),
@@ -37,222 +48,281 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # dense MFMA peaks, MI355X_MICR
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(sample_seconds=600.0):
-  """The oracle (numpy port of the reference algorithm) on one host core, bounded sample."""
+def cpu_baseline(channels, workload_seconds, sample_seconds=None):
+  """The oracle (numpy restatement of the reference algorithm) on ONE host core, on a bounded sample
+  of the workload's shape (same generator, same channel count, same jump density).  Stage 2 of the
+  reference is quadratic in the duration, so the sample's audio-hours/s is an
+  UPPER bound for the CPU path at the workload's duration; the quadratic extrapolation is printed
+  beside it."""
   from describealign_amd import synth
   from oracle import dalign_oracle as O
-  pair = synth.make_pair(3, sample_seconds, n_jumps=5, first_gap=60.0)
+  if sample_seconds is None:
+    sample_seconds = 900.0 if channels == 2 else 600.0
+  n_jumps = max(2, int(round(10 * sample_seconds / 1320.0)))
+  pair = synth.make_pair(3, sample_seconds, n_jumps=n_jumps, first_gap=60.0, channels=channels)
   t0 = time.perf_counter()
   vf, af = O.features(pair.video), O.features(pair.audio)
+  t1 = time.perf_counter()
   x, y, sim, path, med = O.align(vf, af, vf[0], af[0])
-  dt = time.perf_counter() - t0
-  return pair, (x, y), dict(value=(sample_seconds / 3600.0) / dt, unit="audio-hours/s", cores=1, kind="port",
-                            sample=f"{sample_seconds:.0f} s video / {pair.audio_seconds:.0f} s AD synthetic mono pair, "
-                                   f"5 jumps; features + align through oracle/dalign_oracle.py, {dt:.1f} s on one core",
-                            seconds=round(dt, 2))
+  t2 = time.perf_counter()
+  dt = t2 - t0
+  ratio = workload_seconds / sample_seconds
+  est = (t1 - t0) * ratio + (t2 - t1) * ratio * ratio
+  try:
+    model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+  except Exception:
+    model = "unknown"
+  return pair, (x, y), dict(
+      value=(sample_seconds / 3600.0) / dt, unit="audio-hours/s", cores=1, kind="port",
+      sample=f"{sample_seconds:.0f} s video / {pair.audio_seconds:.0f} s AD synthetic {'stereo' if channels == 2 else 'mono'} pair, "
+             f"{n_jumps} jumps; features {t1 - t0:.1f} s + align {t2 - t1:.1f} s through oracle/dalign_oracle.py on one core",
+      seconds=round(dt, 2), host_cpu=model, host_cores=os.cpu_count(),
+      extrapolated_to_workload=dict(
+          seconds=round(est, 1), value=(workload_seconds / 3600.0) / est,
+          how=f"features x{ratio:.1f} (linear) + align x{ratio * ratio:.0f} (stage 2 is quadratic in the duration)"))
+
+
+class Bench:
+  def __init__(self, args, grp, device):
+    self.args, self.grp, self.device = args, grp, device
+
+  def sync(self):
+    import torch
+    torch.cuda.synchronize()
+    self.grp.barrier()
+    torch.cuda.synchronize()
+
+  def run(self, workload, steps, warmup, with_cpu_baseline, with_stretch):
+    import contextlib, io, threading
+    from describealign_amd import _native, synth
+    from describealign_amd import align as A
+    args, grp = self.args, self.grp
+    rank, world = grp.rank, grp.world
+    wl = WORKLOADS[workload]
+    prec_name = args.precision or wl["precision"]
+    prec = _native.PREC_F32 if prec_name == "f32" else _native.PREC_BF16
+    workers = args.pipeline
+    if workers < 0:
+      workers = A.default_worker_count(int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    ctx = _native.Context(self.device, prec)
+    # every rank aligns its own pair (seed differs per rank): a sharded directory batch
+    pair = synth.make_pair(5 + rank, wl["seconds"], n_jumps=wl["n_jumps"], first_gap=wl["first_gap"], channels=wl["channels"])
+    gpu_ctxs = [ctx] + [_native.Context(self.device, prec) for _ in range(max(1, args.gpu_streams) - 1 if workers > 0 else 0)]
+    for c in gpu_ctxs:                       # the PCM is resident in HBM before anything is timed
+      c.pcm_upload(_native.SIDE_VIDEO, pair.video)
+      c.pcm_upload(_native.SIDE_AUDIO, pair.audio)
+    h2d_ms = ctx.stats()["h2d_ms"]
+    feat = {}
+    lock = threading.Lock()
+
+    def make_job(idx):
+      def job(c):
+        if args.include_h2d:
+          c.pcm_upload(_native.SIDE_VIDEO, pair.video)
+          c.pcm_upload(_native.SIDE_AUDIO, pair.audio)
+        vf = c.features_resident(_native.SIDE_VIDEO)
+        s_v = c.stats()
+        af = c.features_resident(_native.SIDE_AUDIO)
+        s_a = c.stats()
+        with lock:
+          feat[idx] = (s_v["features_ms"] + s_a["features_ms"], s_v["features_bytes"] + s_a["features_bytes"])
+        return vf, af
+      return job
+
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    tms, outs = [], []
+    # tail: pairs submitted behind the timed ones so that the stages are still all busy when the
+    # clock stops; once fewer than `workers` pairs are left the LP stage starts to drain
+    tail = 0 if workers <= 0 else (args.tail if args.tail >= 0 else min(workers, 8 if wl["seconds"] > 3000 else workers))
+    total = warmup + steps + tail
+    pipe = None
+    if workers > 0:
+      pipe = A.AlignPipeline(gpu_ctxs, lp_workers=workers)
+      pipe.warm()
+    self.sync()
+    t_start = time.perf_counter()
+    t0 = t_start if warmup == 0 else None
+    t1 = None
+    with quiet:
+      if pipe is not None:
+        it = pipe.run((make_job(k) for k in range(total)), timings=tms)
+        for k in range(total):
+          o = next(it)
+          outs.append(o if k == warmup + steps - 1 else None)          # a 2 h pair's path is ~60 MB
+          now = time.perf_counter()
+          if k == warmup - 1:
+            t0 = now
+          if k == warmup + steps - 1:
+            t1 = now
+      else:
+        for k in range(total):
+          vf, af = make_job(k)(ctx)
+          tm = {}
+          o = A.align(vf, af, vf[0], af[0], ctx=ctx, timings=tm)
+          outs.append(o if k == warmup + steps - 1 else None)
+          tms.append(tm)
+          now = time.perf_counter()
+          if k == warmup - 1:
+            t0 = now
+          if k == warmup + steps - 1:
+            t1 = now
+    self.sync()
+    t_end = time.perf_counter()
+    elapsed = grp.max_over_ranks(t1 - t0)
+    out = outs[warmup + steps - 1]
+    sel = tms[warmup:warmup + steps]
+    acc = {}
+
+    def add(k, v):
+      acc[k] = acc.get(k, 0.0) + v
+
+    for tm in sel:
+      d = tm["device"]
+      for k in ("gemm_ms", "gemm_flops", "gemm_pairs", "verify_ms", "prep_ms", "chain_ms", "refine_kernel_ms",
+                "refine_dp_ms", "survivors", "matches"):
+        add(k, d[k])
+      add("lp_s", tm["lp_s"]); add("match_s", tm["match_s"]); add("chain_s", tm["chain_s"])
+      add("n_path1", tm["n_path1"]); add("n_fit_points", tm["n_fit_points"])
+      add("align_s", tm["match_s"] + tm["chain_s"] + tm["pass1_host_s"] + tm["lp_s"] + tm["cluster_s"] + tm["refine_s"] + tm["nodes_s"])
+    for idx in range(warmup, warmup + steps):
+      add("feat_ms", feat[idx][0]); add("feat_bytes", feat[idx][1])
+
+    # accuracy of the recovered piecewise offsets against the injected truth (this rank's pair)
+    x, y = out[0], out[1]
+    inj_err_ms = 0.0
+    for k in range(0, len(x) - 1, 2):
+      mid = 0.5 * (y[k] + y[k + 1])
+      inj_err_ms = max(inj_err_ms, abs((x[k] - y[k]) - pair.true_offset_at(mid)) * 1e3,
+                       abs((x[k + 1] - y[k + 1]) - pair.true_offset_at(mid)) * 1e3)
+
+    res = None
+    if rank == 0:
+      k = float(steps)
+      hours = wl["seconds"] / 3600.0
+      value = hours * world * steps / elapsed
+      gemm_tf = acc["gemm_flops"] / (acc["gemm_ms"] * 1e-3) / 1e12 if acc.get("gemm_ms") else 0.0
+      peak = PEAK_TFLOPS[prec_name]
+      res = {
+        "metric": "aligned audio-hours/sec", "value": value, "unit": "audio-hours/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if prec_name == "f32" else "bf16", "data": "synthetic",
+        "config": {"workload": wl["desc"] + f", {prec_name} similarity GEMM", "pairs_per_rank_per_step": 1,
+                   "video_seconds": wl["seconds"], "audio_seconds": round(pair.audio_seconds, 1),
+                   "channels": wl["channels"], "parallelism": f"pairs sharded over {world} GPU(s), no collectives"},
+        "realtime_factor": wl["seconds"] * world * steps / elapsed,
+        "timed_region": {"kind": "steady state of one primed pipeline" if pipe is not None else "sequential align() calls",
+                         "pairs_streamed": total, "tail_pairs": tail,
+                         "whole_stream_s": round(t_end - t_start, 2), "timed_s": round(elapsed, 3)},
+        "single_pair_latency_s": round(acc["align_s"] / k, 3),
+        "single_pair_realtime_factor": round(wl["seconds"] / (acc["align_s"] / k), 1),
+        "roofline": {"bound": "mfma", "kernel": "k_match_" + prec_name, "achieved": gemm_tf, "peak": peak, "unit": "TFLOP/s",
+                     "frac": gemm_tf / peak, "traffic": None,
+                     "avg_launch_ms": acc["gemm_ms"] / k, "flops_per_launch": acc["gemm_flops"] / k,
+                     "algorithmic": "246 flop x (non-quiet audio frames) x (every 4th non-quiet video frame)"},
+        "feature_stage": {"bound": "hbm", "achieved": acc["feat_bytes"] / (acc["feat_ms"] * 1e-3) / 1e9 if acc.get("feat_ms") else 0.0,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_step": acc["feat_bytes"] / k,
+                          "ms_per_step": acc["feat_ms"] / k},
+        "stage_ms_per_step": {n: round(acc[n] / k, 3) for n in ("feat_ms", "prep_ms", "gemm_ms", "verify_ms", "chain_ms",
+                                                                "refine_kernel_ms", "refine_dp_ms")},
+        "host_s_per_step": {"lp": round(acc["lp_s"] / k, 4), "align_latency_per_pair": round(acc["align_s"] / k, 4),
+                            "gpu_match_stage_wall": round(acc["match_s"] / k, 4),
+                            "chain_enqueue_to_collected": round(acc["chain_s"] / k, 4)},
+        "pipeline": {"lp_worker_processes": workers, "gpu_streams": len(gpu_ctxs), "host_cores": os.cpu_count(),
+                     "note": "GPU stages of pair k+1 and the device chain DPs of earlier pairs overlap the host LP of pair k; "
+                             "results identical to sequential align()"},
+        "counts": {"gemm_pairs": acc["gemm_pairs"] / k, "survivors": acc["survivors"] / k, "matches": acc["matches"] / k,
+                   "path_points": acc["n_path1"] / k, "lp_fit_points": acc["n_fit_points"] / k},
+        "max_offset_err_vs_injected_ms": round(inj_err_ms, 3),
+        "pcm_resident_in_hbm": not args.include_h2d,
+        "pcm_h2d_ms_audio_side": round(h2d_ms, 2),
+      }
+      # HBM traffic of the dominant kernel from the committed PMC profile of this workload (PMC
+      # collection needs its own rocprofv3 passes; bench.py itself only times with HIP events)
+      for prof_name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+          prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
+          key = workload + "_" + prec_name
+          if key in prof:
+            res["roofline"]["traffic"] = prof[key]["k_match_" + prec_name]["traffic_bytes_per_launch"]
+            res["roofline"]["traffic_source"] = f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            break
+        except Exception:
+          pass
+      if with_stretch:
+        # outside the timed region: the --stretch_audio stage (SURVEY section 8 row f3) once on this
+        # rank's resident pair with the nodes just found
+        try:
+          t_s = time.perf_counter()
+          track, _ = ctx.stretch_resident(out[0], out[1], False)
+          wall_s = time.perf_counter() - t_s
+          ss = ctx.stats()
+          res["stretch_audio_stage"] = {
+            "wall_ms_incl_copy_out": round(1e3 * wall_s, 2), "frames": int(track.shape[0]), "channels": int(track.shape[1]),
+            "prepare_ms": round(ss["stretch_prepare_ms"], 3), "resample_ms": round(ss["resample_ms"], 3),
+            "resample_GBs": round(ss["resample_bytes"] / max(ss["resample_ms"], 1e-9) / 1e6, 1) if ss["resample_ms"] else None,
+            "correlate_ms": round(ss["correlate_ms"], 3), "viterbi_ms": round(ss["viterbi_ms"], 3),
+            "splice_ms": round(ss["splice_ms"], 3), "finish_ms": round(ss["stretch_finish_ms"], 3),
+            "bound": "hbm", "peak_GBs": HBM_PEAK_GBS}
+          del track
+        except Exception as e:            # never let the auxiliary measurement cost the headline line
+          res["stretch_audio_stage"] = {"error": str(e)}
+      if with_cpu_baseline:
+        spair, (ox, oy), cb = cpu_baseline(wl["channels"], wl["seconds"], args.cpu_sample_seconds)
+        # same sample through the GPU path: max |node time| difference vs the CPU reference port
+        with quiet:
+          vf = ctx.features(spair.video, _native.SIDE_VIDEO); af = ctx.features(spair.audio, _native.SIDE_AUDIO)
+          gx, gy, *_ = A.align(vf, af, vf[0], af[0], ctx=ctx)
+        err = float("nan")
+        if len(gx) == len(ox):
+          err = 1e3 * max(np.max(np.abs(gx - ox)), np.max(np.abs(gy - oy)))
+        cb["max_offset_err_vs_cpu_ms"] = round(err, 4)
+        res["cpu_baseline"] = cb
+    if pipe is not None:
+      pipe.__exit__()
+    for c in gpu_ctxs[1:]:
+      c.close()
+    ctx.close()
+    return res
 
 
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=256,
-                  help="pairs aligned in the timed region (it starts with an empty pipeline and ends fully drained; "
-                       "one pair's latency is ~1.2 s, so a short run mostly measures the ramp)")
-  ap.add_argument("--warmup", type=int, default=8)
-  ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS))
+  ap.add_argument("--steps", type=int, default=24, help="pairs in the timed region")
+  ap.add_argument("--warmup", type=int, default=6, help="pairs streamed through the pipeline before the clock starts")
+  ap.add_argument("--tail", type=int, default=-1, help="pairs submitted behind the timed ones (-1: enough to keep the host stage full)")
+  ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
   ap.add_argument("--precision", default=None, choices=["f32", "bf16"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--cpu-sample-seconds", type=float, default=None)
+  ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] measurement reported as `secondary`")
   ap.add_argument("--include-h2d", action="store_true",
                   help="diagnostic: re-upload the PCM over PCIe inside every step (the PCIe-inclusive rate; never the headline value)")
   ap.add_argument("--gpu-streams", type=int, default=1,
                   help="contexts (HIP streams + host threads) feeding the GPU matching stage; pipelined mode only")
   ap.add_argument("--pipeline", type=int, default=-1,
-                  help="host worker processes (chain DP, pass 1, LP); -1 = one per physical core of this rank's share of the host, max 32; 0 = strictly sequential align()")
+                  help="host worker processes (pass 1, LP); -1 = sized for this rank's share of the host; 0 = strictly sequential align()")
   args = ap.parse_args()
 
-  import torch
-  from describealign_amd import _native, synth, distrib
+  from describealign_amd import distrib
   # DALIGN_DIST_BACKEND=gloo and DALIGN_BENCH_DEVICE=<id> exist so that the multi-rank launch path
   # can be exercised on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device)
   grp = distrib.Group(os.environ.get("DALIGN_DIST_BACKEND", "nccl"))
-  rank, local_rank, world = grp.rank, grp.local_rank, grp.world
-  device = local_rank if world > 1 else 0
+  device = grp.local_rank if grp.world > 1 else 0
   if os.environ.get("DALIGN_BENCH_DEVICE"):
     device = int(os.environ["DALIGN_BENCH_DEVICE"])
-  from describealign_amd import align as A
-
-  if args.pipeline < 0:
-    args.pipeline = A.default_worker_count(int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-  wl = WORKLOADS[args.workload]
-  prec_name = args.precision or wl["precision"]
-  prec = _native.PREC_F32 if prec_name == "f32" else _native.PREC_BF16
-  ctx = _native.Context(device, prec)
-  # every rank aligns its own pair (seed differs per rank): a sharded directory batch
-  pair = synth.make_pair(5 + rank, wl["seconds"], n_jumps=wl["n_jumps"], first_gap=wl["first_gap"],
-                         channels=wl["channels"])
-  gpu_ctxs = [ctx] + [_native.Context(device, prec) for _ in range(max(1, args.gpu_streams) - 1 if args.pipeline > 0 else 0)]
-  for c in gpu_ctxs:                       # the PCM is resident in HBM before anything is timed
-    c.pcm_upload(_native.SIDE_VIDEO, pair.video)
-    c.pcm_upload(_native.SIDE_AUDIO, pair.audio)
-  h2d_ms = ctx.stats()["h2d_ms"]
-
-  acc = {}
-  tms = []
-
-  def add(k, v):
-    acc[k] = acc.get(k, 0.0) + v
-
-  import threading
-  acc_lock = threading.Lock()
-
-  def make_job(record):
-    def job(c):
-      if args.include_h2d:
-        c.pcm_upload(_native.SIDE_VIDEO, pair.video)
-        c.pcm_upload(_native.SIDE_AUDIO, pair.audio)
-      vf = c.features_resident(_native.SIDE_VIDEO)
-      s_v = c.stats()
-      af = c.features_resident(_native.SIDE_AUDIO)
-      s_a = c.stats()
-      if record:
-        with acc_lock:
-          add("feat_ms", s_v["features_ms"] + s_a["features_ms"])
-          add("feat_bytes", s_v["features_bytes"] + s_a["features_bytes"])
-      return vf, af
-    return job
-
-  def jobs(n, record):
-    for _ in range(n):
-      yield make_job(record)
-
-  def sync():
-    torch.cuda.synchronize()
-    grp.barrier()
-    torch.cuda.synchronize()
-
-  import contextlib, io
-  quiet = contextlib.redirect_stdout(io.StringIO())
-  pipe = None
-  if args.pipeline > 0:
-    pipe = A.AlignPipeline(gpu_ctxs, lp_workers=args.pipeline)
-    pipe.warm()
-
-  def run(n, record):
-    outs = []
-    if pipe is not None:
-      outs = list(pipe.run(jobs(n, record), timings=tms if record else None))
-    else:
-      for job in jobs(n, record):
-        vf, af = job(ctx)
-        tm = {}
-        outs.append(A.align(vf, af, vf[0], af[0], ctx=ctx, timings=tm))
-        if record:
-          tms.append(tm)
-    return outs
-
-  with quiet:
-    run(args.warmup, False)
-  sync()
-  t0 = time.perf_counter()
-  with quiet:
-    outs = run(args.steps, True)
-  sync()
-  elapsed = time.perf_counter() - t0
-  elapsed = grp.max_over_ranks(elapsed)
-  out = outs[-1]
-  for tm in tms:
-    d = tm["device"]
-    for k in ("gemm_ms", "gemm_flops", "gemm_pairs", "verify_ms", "prep_ms", "chain_ms", "refine_kernel_ms",
-              "refine_dp_ms", "survivors", "matches"):
-      add(k, d[k])
-    add("lp_s", tm["lp_s"]); add("match_s", tm["match_s"])
-    add("align_s", tm["match_s"] + tm["chain_s"] + tm["pass1_host_s"] + tm["lp_s"] + tm["cluster_s"] + tm["refine_s"] + tm["nodes_s"])
-
-  # accuracy of the recovered piecewise offsets against the injected truth (this rank's pair)
-  x, y = out[0], out[1]
-  inj_err_ms = 0.0
-  for k in range(0, len(x) - 1, 2):
-    mid = 0.5 * (y[k] + y[k + 1])
-    inj_err_ms = max(inj_err_ms, abs((x[k] - y[k]) - pair.true_offset_at(mid)) * 1e3,
-                     abs((x[k + 1] - y[k + 1]) - pair.true_offset_at(mid)) * 1e3)
-
-  if rank == 0:
-    k = float(args.steps)
-    hours = wl["seconds"] / 3600.0
-    value = hours * world * args.steps / elapsed
-    gemm_tf = acc["gemm_flops"] / (acc["gemm_ms"] * 1e-3) / 1e12 if acc.get("gemm_ms") else 0.0
-    peak = PEAK_TFLOPS[prec_name]
-    res = {
-      "metric": "aligned audio-hours/sec", "value": value, "unit": "audio-hours/s", "n_gpus": world,
-      "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-      "dtype": "f32" if prec_name == "f32" else "bf16", "data": "synthetic",
-      "config": {"workload": wl["desc"] + f", {prec_name} similarity GEMM", "pairs_per_rank_per_step": 1,
-                 "video_seconds": wl["seconds"], "audio_seconds": round(pair.audio_seconds, 1),
-                 "channels": wl["channels"], "parallelism": f"pairs sharded over {world} GPU(s), no collectives"},
-      "realtime_factor": wl["seconds"] * world * args.steps / elapsed,
-      "roofline": {"bound": "mfma", "kernel": "k_match_" + prec_name, "achieved": gemm_tf, "peak": peak, "unit": "TFLOP/s",
-                   "frac": gemm_tf / peak, "traffic": None,
-                   "avg_launch_ms": acc["gemm_ms"] / k, "flops_per_launch": acc["gemm_flops"] / k,
-                   "algorithmic": "246 flop x (non-quiet audio frames) x (every 4th non-quiet video frame)"},
-      "feature_stage": {"bound": "hbm", "achieved": acc["feat_bytes"] / (acc["feat_ms"] * 1e-3) / 1e9 if acc.get("feat_ms") else 0.0,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_step": acc["feat_bytes"] / k,
-                        "ms_per_step": acc["feat_ms"] / k},
-      "stage_ms_per_step": {n: round(acc[n] / k, 3) for n in ("feat_ms", "prep_ms", "gemm_ms", "verify_ms", "chain_ms",
-                                                              "refine_kernel_ms", "refine_dp_ms")},
-      "host_s_per_step": {"lp": round(acc["lp_s"] / k, 4), "align_latency_per_pair": round(acc["align_s"] / k, 4),
-                          "gpu_match_stage_wall": round(acc["match_s"] / k, 4)},
-      "pipeline": {"lp_worker_processes": args.pipeline, "gpu_streams": len(gpu_ctxs), "host_cores": os.cpu_count(),
-                   "note": "GPU + DP stages of pair k+1 overlap the host LP of pair k; results identical to sequential align()"},
-      "counts": {"gemm_pairs": acc["gemm_pairs"] / k, "survivors": acc["survivors"] / k, "matches": acc["matches"] / k},
-      "max_offset_err_vs_injected_ms": round(inj_err_ms, 3),
-      "pcm_resident_in_hbm": not args.include_h2d,
-      "pcm_h2d_ms_audio_side": round(h2d_ms, 2),
-    }
-    # HBM traffic of the dominant kernel from the committed PMC profile of this workload (PMC
-    # collection needs its own rocprofv3 passes; bench.py itself only times with HIP events)
-    try:
-      prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-      key = {"cfg1": "cfg1_" + prec_name}.get(args.workload)
-      if key in prof:
-        res["roofline"]["traffic"] = prof[key]["k_match_" + prec_name]["traffic_bytes_per_launch"]
-        res["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-    except Exception:
-      pass
-    # outside the timed region: the --stretch_audio stage (SURVEY section 8 row f3) once on this
-    # rank's resident pair with the nodes just found -- loudness matching, replace_aligned_segments,
-    # peak normalisation, int16 interleave, copy-out
-    try:
-      t_s = time.perf_counter()
-      track, _ = ctx.stretch_resident(out[0], out[1], False)
-      wall_s = time.perf_counter() - t_s
-      ss = ctx.stats()
-      res["stretch_audio_stage"] = {
-        "wall_ms_incl_copy_out": round(1e3 * wall_s, 2), "frames": int(track.shape[0]), "channels": int(track.shape[1]),
-        "prepare_ms": round(ss["stretch_prepare_ms"], 3), "resample_ms": round(ss["resample_ms"], 3),
-        "resample_GBs": round(ss["resample_bytes"] / max(ss["resample_ms"], 1e-9) / 1e6, 1) if ss["resample_ms"] else None,
-        "correlate_ms": round(ss["correlate_ms"], 3), "viterbi_ms": round(ss["viterbi_ms"], 3),
-        "splice_ms": round(ss["splice_ms"], 3), "finish_ms": round(ss["stretch_finish_ms"], 3),
-        "bound": "hbm", "peak_GBs": HBM_PEAK_GBS}
-    except Exception as e:            # never let the auxiliary measurement cost the headline line
-      res["stretch_audio_stage"] = {"error": str(e)}
-    if world == 1 and not args.no_cpu_baseline:
-      spair, (ox, oy), cb = cpu_baseline()
-      # same sample through the GPU path: max |node time| difference vs the CPU reference port
-      with quiet:
-        vf = ctx.features(spair.video, _native.SIDE_VIDEO); af = ctx.features(spair.audio, _native.SIDE_AUDIO)
-        gx, gy, *_ = A.align(vf, af, vf[0], af[0], ctx=ctx)
-      err = float("nan")
-      if len(gx) == len(ox):
-        err = 1e3 * max(np.max(np.abs(gx - ox)), np.max(np.abs(gy - oy)))
-      cb["max_offset_err_vs_cpu_ms"] = round(err, 4)
-      res["cpu_baseline"] = cb
+  b = Bench(args, grp, device)
+  single = grp.world == 1
+  res = b.run(args.workload, args.steps, args.warmup, with_cpu_baseline=single and not args.no_cpu_baseline, with_stretch=True)
+  if single and args.workload == "cfg2" and not args.no_secondary and args.precision is None:
+    sec = b.run("cfg1", max(args.steps, 64), max(args.warmup, 8), with_cpu_baseline=False, with_stretch=False)
+    if res is not None and sec is not None:
+      res["secondary"] = {k: sec[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "realtime_factor",
+                                              "roofline", "feature_stage", "stage_ms_per_step", "host_s_per_step", "counts",
+                                              "single_pair_latency_s", "max_offset_err_vs_injected_ms")}
+  if grp.rank == 0:
     print(json.dumps(res))
-  if pipe is not None:
-    pipe.__exit__()
-  for c in gpu_ctxs[1:]:
-    c.close()
-  ctx.close()
   grp.close()
 
 

@@ -15,7 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdalign.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 PREC_F32, PREC_BF16 = 0, 1
 SIDE_VIDEO, SIDE_AUDIO = 0, 1
@@ -27,7 +27,7 @@ ERR_MISMATCH = -4
 
 EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm_upload",
            "da_features_resident", "da_features", "da_match", "da_match_begin", "da_match_finish", "da_match_fetch",
-           "da_match_corr", "da_chain",
+           "da_match_corr", "da_chain", "da_chain_begin", "da_chain_finish", "da_chain_resident", "da_chain_poll",
            "da_refine", "da_stats", "da_replace_segments", "da_stretch_resident", "da_stretch_schedule"]
 
 
@@ -66,6 +66,12 @@ def load():
     if not os.path.exists(LIB_PATH):
       raise ImportError(f"{LIB_PATH} is missing: the HIP extension has not been built "
                         "(run __graft_entry__.build()); describealign_amd has no CPU fallback")
+    # Every da_ctx owns a compute stream, a copy stream and one stream per chain DP in flight (a
+    # persistent one-workgroup kernel that runs for ~1 s beside the GEMMs of later pairs).  The HIP
+    # runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that
+    # share a queue execute in order, which would park a GEMM behind a chain DP.  Read at HIP
+    # initialisation, so it has to be in the environment before the library is loaded.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     lib = C.CDLL(LIB_PATH)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     P = C.POINTER
@@ -82,6 +88,10 @@ def load():
     lib.da_match_fetch.argtypes = [vp, vp, vp, vp, i64]
     lib.da_match_corr.argtypes = [vp, vp, vp, i64, vp]
     lib.da_chain.argtypes = [vp, vp, vp, vp, i64, C.c_double, vp, vp, P(i64)]
+    lib.da_chain_begin.argtypes = [vp, P(C.c_uint64)]
+    lib.da_chain_finish.argtypes = [vp, C.c_uint64, C.c_double, vp, vp, P(i64)]
+    lib.da_chain_resident.argtypes = [vp, C.c_double, vp, vp, P(i64)]
+    lib.da_chain_poll.argtypes = [vp, C.c_uint64]
     lib.da_refine.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, vp, i32, C.c_double, vp, P(i64), P(i64)]
     lib.da_stats.argtypes = [vp, P(Stats)]
     lib.da_replace_segments.argtypes = [vp, vp, i64, vp, i64, i32, vp, vp, i32, i32]
@@ -269,6 +279,40 @@ class Context:
     m = C.c_int64(n)
     self._check(self._lib.da_chain(self._h, _ptr(i), _ptr(v), _ptr(q), n, float(min_len), _ptr(pi), _ptr(pv), C.byref(m)))
     return pi[:m.value].copy(), pv[:m.value].copy()
+
+  def chain_begin(self) -> int:
+    """Hand the resident matches of the last match()/match_finish() to the device chain DP and
+    enqueue it on its own stream; returns a ticket for chain_finish.  The context is free for the
+    next match_begin at once."""
+    t = C.c_uint64(0)
+    self._check(self._lib.da_chain_begin(self._h, C.byref(t)))
+    return t.value
+
+  def chain_finish(self, ticket: int, min_len: float = 0.0):
+    """Wait for that DP; returns (path_i, path_v).  Raises the reference's mismatch error when
+    the path is shorter than min_len (:698)."""
+    m = C.c_int64(0)
+    rc = self._lib.da_chain_finish(self._h, C.c_uint64(ticket), float(min_len), None, None, C.byref(m))
+    if rc == 0:
+      return np.empty(0, dtype=np.int32), np.empty(0, dtype=np.int32)
+    if rc != ERR_CAPACITY:
+      if rc == ERR_MISMATCH:
+        raise RuntimeError("Alignment failed, are the input files mismatched?")
+      self._check(rc)
+    pi = np.empty(m.value, dtype=np.int32); pv = np.empty(m.value, dtype=np.int32)
+    self._check(self._lib.da_chain_finish(self._h, C.c_uint64(ticket), float(min_len), _ptr(pi), _ptr(pv), C.byref(m)))
+    return pi[:m.value], pv[:m.value]
+
+  def chain_done(self, ticket: int) -> bool:
+    """True once chain_finish(ticket) will not block."""
+    rc = self._lib.da_chain_poll(self._h, C.c_uint64(ticket))
+    if rc < 0:
+      self._check(rc)
+    return rc == 1
+
+  def chain_resident(self, min_len: float = 0.0):
+    """Stage-2 chain DP on the matches still resident from the last match (describealign.py:654-698)."""
+    return self.chain_finish(self.chain_begin(), min_len)
 
   def refine(self, a_scaled, v_scaled, cl_x0, cl_x1, cl_offset, cl_slope, min_len: float = 0.0):
     """Banded line extension + second DP -- describealign.py:895-993.  Returns (path[M,5], n_points)."""

@@ -7,7 +7,7 @@ is the seam `combine()` calls (reference describealign.py:1121-1122).  The quadr
 data-parallel stages run in HIP behind the C ABI (include/dalign.h):
 
   stage 1+2  mean-sub / norms / hash digits, similarity GEMM on MFMA, exact verification  da_match
-  stage 2    heaviest-chain DP over the verified matches                                    da_chain
+  stage 2    heaviest-chain DP over the verified matches (device-resident)                  da_chain_begin/finish
   stage 4    banded line extension + second DP                                              da_refine
 
 and this module does what the reference keeps on the host: the pass-1 continuity filter,
@@ -347,40 +347,39 @@ def default_context(device: int = 0, precision: int = _native.PREC_F32) -> "_nat
   return _default_ctx
 
 
-def _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm, alloc=None):
-  """Stages 1+2 on the GPU: prep, similarity GEMM, exact verification, sort."""
+def _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm, rows=None):
+  """Stages 1+2 on the GPU: prep, similarity GEMM, exact verification, sort.  The verified
+  matches stay on the device; returns their number."""
   t0 = time.perf_counter()
-  mi, mv, mq = ctx.match(video_features, audio_desc_features, mode=mode, alloc=alloc)
+  ctx.match_begin(video_features, audio_desc_features, mode, rows)
+  n = ctx.match_finish()
   tm["device"] = ctx.stats()
   tm["match_s"] = time.perf_counter() - t0
-  tm["n_matches"] = len(mi)
-  return mi, mv, mq
+  tm["n_matches"] = n
+  return n
 
 
-def _stage_chain_pass1(ctx, matches, video_features, audio_desc_features, n_ve, n_ae, tm):
-  """Chain DP (host C++) + pass-1 host work: continuity filter, scaling, compression."""
-  mi, mv, mq = matches
-  t1 = time.perf_counter()
-  if ctx is None:                                # CPU worker process: host-only DP, no device
-    px, py = _native.chain_host(mi, mv, mq, min_len=min_path_length(n_ve, n_ae))
-    tm.setdefault("device", {})["chain_ms"] = 1e3 * (time.perf_counter() - t1)
-  else:
-    px, py = ctx.chain(mi, mv, mq, min_len=min_path_length(n_ve, n_ae))    # raises the mismatch error
-    tm.setdefault("device", {})["chain_ms"] = ctx.stats()["chain_ms"]
+def _stage_pass1(px, py, video_features, audio_desc_features, tm):
+  """Pass-1 host work on the stage-2 path (:701-767): continuity filter, per-feature scaling,
+  path compression.  px = audio frames, py = video frames of the chain."""
   t2 = time.perf_counter()
-  x = px.astype(np.int64); y = py.astype(np.int64)
+  x = np.asarray(px).astype(np.int64); y = np.asarray(py).astype(np.int64)
   keep = continuity_error(x, y) < 3
   x, y = x[keep], y[keep]
   a_scaled, v_scaled = scale_feature_stacks(video_features, audio_desc_features, x, y)
   fx, fy = compress_path(x, y)
-  t3 = time.perf_counter()
-  tm.update(chain_s=t2 - t1, pass1_host_s=t3 - t2, n_path1=len(px), n_fit_points=len(fx))
+  tm.update(pass1_host_s=time.perf_counter() - t2, n_path1=len(px), n_fit_points=len(fx))
   return fx, fy, a_scaled, v_scaled
 
 
 def _stage_match(ctx, video_features, audio_desc_features, n_ve, n_ae, mode, tm):
-  matches = _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm)
-  return _stage_chain_pass1(ctx, matches, video_features, audio_desc_features, n_ve, n_ae, tm)
+  """Matching + chain DP, both on the device; only the path comes back."""
+  _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm)
+  t1 = time.perf_counter()
+  px, py = ctx.chain_resident(min_len=min_path_length(n_ve, n_ae))          # raises the mismatch error (:698)
+  tm["device"]["chain_ms"] = ctx.stats()["chain_ms"]
+  tm["chain_s"] = time.perf_counter() - t1
+  return _stage_pass1(px, py, video_features, audio_desc_features, tm)
 
 
 def _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm, clusters=None):
@@ -440,7 +439,10 @@ def align_tiled(video_features, audio_desc_features, video_energy, audio_desc_en
   mi, mv, mq = group.all_gather_matches(mi, mv, mq)
   t2 = time.perf_counter()
   tm.update(match_s=t1 - t0, gather_s=t2 - t1, n_matches=len(mi), rows=(rb, re))
-  fx, fy, a_scaled, v_scaled = _stage_chain_pass1(ctx, (mi, mv, mq), video_features, audio_desc_features, n_ve, n_ae, tm)
+  px, py = ctx.chain(mi, mv, mq, min_len=min_path_length(n_ve, n_ae))
+  tm["device"]["chain_ms"] = ctx.stats()["chain_ms"]
+  tm["chain_s"] = time.perf_counter() - t2
+  fx, fy, a_scaled, v_scaled = _stage_pass1(px, py, video_features, audio_desc_features, tm)
   t3 = time.perf_counter()
   lp = solve_trend_lp(fx, fy)
   tm["lp_s"] = time.perf_counter() - t3
@@ -536,13 +538,13 @@ def default_worker_count(local_world: int = 1) -> int:
 # ---- worker-process side of the batch pipeline ---------------------------------------------------
 # Worker processes never touch the GPU (a second process with a device context makes the GPU
 # time-slice between processes, which costs far more than it gains): they run the host-only
-# stages -- chain DP (C++), pass-1 numpy, the HiGHS LP, clustering -- each under its own GIL.
+# stages -- pass-1 numpy, the HiGHS LP, clustering -- each under its own GIL.
 
 def _block_layout(n, le_v, lo_v, le_a, lo_a):
-  """Byte offsets of one pair's shared block: match lists, feature rows, scaled stacks."""
+  """Byte offsets of one pair's shared block: the stage-2 path (n points), feature rows, scaled stacks."""
   off, lay = 0, {}
   la, lv = min(le_a, lo_a), min(le_v, lo_v)
-  for name, count, size in (("mq", n, 8), ("a_scaled", 3 * la, 8), ("v_scaled", 3 * lv, 8), ("mi", n, 4), ("mv", n, 4),
+  for name, count, size in (("a_scaled", 3 * la, 8), ("v_scaled", 3 * lv, 8), ("px", n, 4), ("py", n, 4),
                             ("vf0", le_v, 4), ("vf", 4 * lo_v, 4), ("af0", le_a, 4), ("af", 4 * lo_a, 4)):
     lay[name] = (off, count)
     off += ((count * size + 63) // 64) * 64
@@ -556,17 +558,17 @@ def _block_views(buf, lay, le_v, lo_v, le_a, lo_a):
     return a if shape is None else a.reshape(shape)
   vf = [arr("vf0", np.float32)] + list(arr("vf", np.float32, (4, lo_v)))
   af = [arr("af0", np.float32)] + list(arr("af", np.float32, (4, lo_a)))
-  return (arr("mi", np.int32), arr("mv", np.int32), arr("mq", np.float64), vf, af,
+  return (arr("px", np.int32), arr("py", np.int32), vf, af,
           arr("a_scaled", np.float64, (-1, 3)), arr("v_scaled", np.float64, (-1, 3)))
 
 
 def _proc_mid(fname, fsize, n, le_v, lo_v, le_a, lo_a):
-  """Host-only middle of the pipeline for one pair: chain DP, pass 1, LP, clustering."""
+  """Host-only middle of the pipeline for one pair: pass 1, LP, clustering."""
   lay, size = _block_layout(n, le_v, lo_v, le_a, lo_a)
   mm = np.memmap(fname, dtype=np.uint8, mode="r+", shape=(fsize,))
-  mi, mv, mq, vf, af, a_out, v_out = _block_views(mm, lay, le_v, lo_v, le_a, lo_a)
+  px, py, vf, af, a_out, v_out = _block_views(mm, lay, le_v, lo_v, le_a, lo_a)
   tm = {}
-  fx, fy, a_s, v_s = _stage_chain_pass1(None, (mi, mv, mq), vf, af, le_v, le_a, tm)
+  fx, fy, a_s, v_s = _stage_pass1(px, py, vf, af, tm)
   t0 = time.perf_counter()
   lp = solve_trend_lp(fx, fy)
   tm["lp_s"] = time.perf_counter() - t0
@@ -582,13 +584,15 @@ def _proc_mid(fname, fsize, n, le_v, lo_v, le_a, lo_a):
 
 class AlignPipeline:
   """Directory-batch throughput.  One pair's latency is dominated by host work (the
-  single-threaded HiGHS LP, the two sequential DPs), so pairs are pipelined:
+  single-threaded HiGHS LP), so pairs are pipelined:
 
     GPU threads       (one da_ctx / HIP stream each) features + matching of successive pairs:
-                      prep, similarity GEMM, verification, sort; the verified match lists are
-                      copied from the device straight into a /dev/shm block
-    worker processes  (own GIL, no device) per pair: chain DP -> pass-1 host -> LP (HiGHS) ->
-                      clustering; they map the pair's /dev/shm block, nothing big is pickled
+                      prep, similarity GEMM, verification, sort; then the pair's chain DP is
+                      enqueued on a stream of its own (da_chain_begin: one persistent workgroup,
+                      several pairs' DPs run beside the GEMMs of later pairs) and collected when it
+                      has finished -- the match list never leaves the device, only the path does
+    worker processes  (own GIL, no device) per pair: pass-1 host -> LP (HiGHS) -> clustering; they
+                      map the pair's /dev/shm block (path + feature rows), nothing big is pickled
     refine threads    (one da_ctx each, this process) banded extension kernels + second DP + nodes
 
   A job is either a tuple (video_features, audio_features) or a callable job(ctx) returning that
@@ -661,7 +665,9 @@ class AlignPipeline:
     self._dir = tempfile.mkdtemp(prefix=f"dalign_{os.getpid()}_", dir=shm)
     self._seq = 0
     self._free = []        # reusable (file name, bytes) blocks: fresh tmpfs pages cost ~0.2 ms per MB
-    self._deferred = {}    # per GPU context: the pair whose matches are finished but not yet copied out
+    self._queued = {}      # per GPU context: pairs submitted to its thread that have not started yet
+    self._chains = {}      # per GPU context: pairs whose chain DP is enqueued (ticket, ...), oldest first
+    self.max_chains = int(os.environ.get("DALIGN_MAX_CHAINS", "12"))      # DPs in flight per context (the library allows 16)
     import sys
     self._old_switch = sys.getswitchinterval()
     sys.setswitchinterval(2e-4)
@@ -704,30 +710,51 @@ class AlignPipeline:
     sys.setswitchinterval(self._old_switch)
 
   def _gpu_stage(self, ctx, job, tm, fname, done):
-    """Features + matching of one pair on this GPU thread.  The copy-out and hand-off of the
-    PREVIOUS pair of this context run between match_begin and match_finish, i.e. under the GEMM."""
+    """Features + matching of one pair on this GPU thread, then its chain DP is enqueued on its own
+    stream.  Finished DPs of earlier pairs are collected and handed to the worker processes between
+    match_begin and match_finish, i.e. under the GEMM."""
     try:
+      with self._lock:
+        self._queued[id(ctx)] = self._queued.get(id(ctx), 0) - 1
       t0 = time.perf_counter()
       vf, af = job(ctx) if callable(job) else job
       tm["features_s"] = time.perf_counter() - t0
       t1 = time.perf_counter()
       ctx.match_begin(vf, af, self.mode)
-      self._flush_deferred(ctx)
+      self._collect_chains(ctx, block_above=self.max_chains - 1)
       n = ctx.match_finish()
       tm["device"] = ctx.stats()
       tm["match_s"] = time.perf_counter() - t1
       tm["n_matches"] = n
-      self._deferred[id(ctx)] = (vf, af, tm, fname, done, n)
+      ticket = ctx.chain_begin()
+      self._chains.setdefault(id(ctx), []).append((ticket, vf, af, tm, fname, done, time.perf_counter()))
     except BaseException as e:
       done.set_exception(e)
 
-  def _flush_deferred(self, ctx):
-    d = self._deferred.pop(id(ctx), None)
-    if d is None:
-      return
-    vf, af, tm, fname, done, n = d
+  def _collect_chains(self, ctx, block_above=None):
+    """Hand every pair whose chain DP has finished to the worker processes, in order.  With
+    block_above = k, wait for the oldest ones until at most k DPs are outstanding (k = 0: drain)."""
+    queue = self._chains.get(id(ctx), [])
+    while queue:
+      must = block_above is not None and len(queue) > block_above
+      if not must and not ctx.chain_done(queue[0][0]):
+        break
+      self._hand_off(ctx, *queue.pop(0))
+
+  def _collect_idle(self, ctx):
+    """Runs on the GPU thread after every pair: while no further pair is waiting for this context,
+    wait for its outstanding chain DPs one at a time (otherwise they are collected under the next
+    pair's GEMM) -- so a caller that stops submitting until results arrive cannot starve them."""
+    while self._chains.get(id(ctx)) and self._queued.get(id(ctx), 0) <= 0:
+      self._collect_chains(ctx, block_above=len(self._chains[id(ctx)]) - 1)
+
+  def _hand_off(self, ctx, ticket, vf, af, tm, fname, done, t_begin):
     try:
       dims = (len(vf[0]), len(vf[1]), len(af[0]), len(af[1]))
+      px, py = ctx.chain_finish(ticket, min_len=min_path_length(dims[0], dims[2]))      # raises the mismatch error (:698)
+      tm["device"]["chain_ms"] = ctx.stats()["chain_ms"]
+      tm["chain_s"] = time.perf_counter() - t_begin          # enqueue -> collected (includes waiting in the queue)
+      n = len(px)
       state = {}
       lay, size = _block_layout(n, *dims)
       with self._lock:
@@ -742,12 +769,12 @@ class AlignPipeline:
         state["fname"] = fname
         mm = np.memmap(fname, dtype=np.uint8, mode="w+", shape=(fsize,))
       state.update(mm=mm, lay=lay, n=n, fsize=fsize)
-      mi, mv, mq, bvf, baf, _, _ = _block_views(mm, lay, *dims)
+      bx, by, bvf, baf, _, _ = _block_views(mm, lay, *dims)
+      bx[:] = px; by[:] = py
       for dst, src in zip(bvf, vf):
         dst[:] = src
       for dst, src in zip(baf, af):
         dst[:] = src
-      ctx.match_fetch(n, alloc=lambda k: (mi, mv, mq))
       mm.flush()
       mid = self.pool.submit(_proc_mid, state["fname"], fsize, n, *dims)
 
@@ -769,7 +796,7 @@ class AlignPipeline:
     dev.update(wtm.pop("device", {}))
     tm.update(wtm); tm["device"] = dev
     ctx = self._thread_ctx()
-    _, _, _, _, _, a_s, v_s = _block_views(state["mm"], state["lay"], *dims)
+    _, _, _, _, a_s, v_s = _block_views(state["mm"], state["lay"], *dims)
     out = _stage_refine(ctx, dict(median_slope=med), a_s, v_s, dims[0], dims[2], tm, clusters=clusters)
     del a_s, v_s
     mm = state.pop("mm")
@@ -803,13 +830,16 @@ class AlignPipeline:
       fname = os.path.join(self._dir, f"pair{self._seq}.bin")
       self._seq += 1
       done = cf.Future()
+      with self._lock:
+        self._queued[id(self.gpu_ctxs[g])] = self._queued.get(id(self.gpu_ctxs[g]), 0) + 1
       self.gpu_threads[g].submit(self._gpu_stage, self.gpu_ctxs[g], job, tm, fname, done)
+      self.gpu_threads[g].submit(self._collect_idle, self.gpu_ctxs[g])
       pending.append((done, tm))
       # results are handed back in submission order, so pairs that finished behind a slow LP still
       # count as pending: the window has to be wider than the worker pool or workers idle
       while len(pending) >= window:
         yield finish(pending.pop(0))
-    for g in range(n_gpu):          # the last pair of every context still has to be copied out
-      self.gpu_threads[g].submit(self._flush_deferred, self.gpu_ctxs[g])
+    for g in range(n_gpu):          # the chain DPs still in flight have to be collected
+      self.gpu_threads[g].submit(self._collect_chains, self.gpu_ctxs[g], 0)
     while pending:
       yield finish(pending.pop(0))

@@ -46,6 +46,28 @@ struct Side {
   int64_t mlen[5] = {0, 0, 0, 0, 0}; int64_t lmax = 0;
 };
 
+// One set of buffers for a stage-2 chain DP in flight (or for the results of the last match):
+// the sorted matches, the DP's working arrays and its own stream, so that the DP of pair k runs
+// beside the similarity GEMM of pair k+1 and its buffers are not reused until it has been collected.
+struct ChainSlot {
+  DevBuf keys, q;                 // matches sorted by (i, v): packed keys and qualities
+  DevBuf rank, flags, rows, pred, tree, ids, out_iv, small, temp;
+  hipStream_t stream = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr, ready = nullptr;
+  int64_t n = 0, n_ranks = 0;
+  int state = 0;                  // 0 free, 1 holds the last finished match, 2 chain DP enqueued
+  unsigned long long ticket = 0;
+  long long* h_small = nullptr;   // pinned copy of `small`: [0] rows | err << 32, [1] best id, [2] path length
+  void release() {
+    for (DevBuf* b : {&keys, &q, &rank, &flags, &rows, &pred, &tree, &ids, &out_iv, &small, &temp}) b->release();
+    if (stream) (void)hipStreamDestroy(stream);
+    for (hipEvent_t e : {e0, e1, ready}) if (e) (void)hipEventDestroy(e);
+    if (h_small) (void)hipHostFree(h_small);
+    stream = nullptr; e0 = e1 = ready = nullptr; h_small = nullptr;
+  }
+};
+constexpr int kMaxChainSlots = 16;
+
 double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -61,14 +83,18 @@ struct da_ctx {
   std::string err;
   Side side[2];
   DevBuf tables, hann41;
-  DevBuf vlist, alist, surv, counters, keys0, keys1, q0, q1, sort_tmp;
+  DevBuf vlist, alist, surv, counters, keys0, q0, sort_tmp, rankmap;
+  std::vector<ChainSlot*> slots;  // sorted match lists live in slots (see ChainSlot)
+  int res_slot = -1;              // slot holding the results of the last finished match
+  unsigned long long next_ticket = 1;
+  int64_t res_lv = 0;             // video frames of the last match (rank map size)
   DevBuf pair_i, pair_v, pair_c;
   DevBuf ascaled, vscaled, band_y, band_q, band_part;
   bool match_ready = false;
   unsigned long long n_match_resident = 0;
   // state carried from da_match_begin to da_match_finish
   bool match_pending = false;
-  bool fetch_ready = false;       // results of the last finished match are resident (keys0 / q1)
+  bool fetch_ready = false;       // results of the last finished match are resident (keys0 / the result slot)
   int pend_mode = 0; int64_t pend_nv = 0; size_t pend_cap = 0;
   hipEvent_t gemm_e0 = nullptr, gemm_e1 = nullptr, prep_e0 = nullptr, prep_e1 = nullptr;
   hipStream_t copy_stream = nullptr;
@@ -95,6 +121,22 @@ int fail(da_ctx* c, int code, const char* fmt, ...) {
     if (e_ != hipSuccess)                                                                       \
       return fail((c), DA_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
+
+// a free chain slot (creating one if needed); -1 when all kMaxChainSlots are in flight
+int acquire_slot(da_ctx* c) {
+  for (size_t k = 0; k < c->slots.size(); ++k)
+    if (c->slots[k]->state == 0) return (int)k;
+  if ((int)c->slots.size() >= kMaxChainSlots) return -1;
+  ChainSlot* sl = new ChainSlot();
+  if (hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&sl->e0) != hipSuccess || hipEventCreate(&sl->e1) != hipSuccess ||
+      hipEventCreateWithFlags(&sl->ready, hipEventDisableTiming) != hipSuccess ||
+      hipHostMalloc((void**)&sl->h_small, 64, hipHostMallocDefault) != hipSuccess) {
+    sl->release(); delete sl; return -1;
+  }
+  c->slots.push_back(sl);
+  return (int)c->slots.size() - 1;
+}
 
 void hann_inner(int m, std::vector<double>& w) {       // scipy.signal.windows.hann(m+2)[1:-1]
   w.resize(m);
@@ -135,7 +177,7 @@ void build_tables(FeatTables& T) {
 
 extern "C" {
 
-int da_abi_version(void) { return 2; }
+int da_abi_version(void) { return 3; }
 
 const char* da_last_error(const da_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -180,10 +222,12 @@ void da_destroy(da_ctx* c) {
     for (int j = 0; j < 3; ++j) { s.ms32[j].release(); s.inv32[j].release(); s.nrm32[j].release(); s.nrmpk[j].release(); s.bfe[j].release(); s.bfo[j].release(); }
     s.prod32.release();
   }
-  DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->counters, &c->keys0, &c->keys1,
-                   &c->q0, &c->q1, &c->sort_tmp, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
+  DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->counters, &c->keys0,
+                   &c->q0, &c->sort_tmp, &c->rankmap, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
                    &c->band_y, &c->band_q, &c->band_part};
   for (DevBuf* b : all) b->release();
+  for (ChainSlot* sl : c->slots) { if (sl->stream) (void)hipStreamSynchronize(sl->stream); sl->release(); delete sl; }
+  c->slots.clear();
   c->st_video.release(); c->st_audio.release(); c->st_out.release();
   da::stretch_destroy(c->stretch); c->stretch = nullptr;
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -338,6 +382,7 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
     return fail(c, DA_ERR_ARG, "da_match: inconsistent lengths");
   HIP_TRY(c, hipSetDevice(c->device));
   c->match_ready = false; c->match_pending = false;       // fetch_ready is untouched: the previous results stay fetchable
+  c->res_lv = v_lengths[0];
   Side& V = c->side[0]; Side& A = c->side[1];
   HIP_TRY(c, hipEventRecord(c->prep_e0, c->stream));
   int rc = upload_and_prep(c, V, vfeat, v_stride, v_lengths, 1, resident_rows); if (rc) return rc;
@@ -407,6 +452,8 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
   HIP_TRY(c, hipSetDevice(c->device));
   c->match_pending = false;
   c->fetch_ready = false;                                   // verification is about to overwrite the result buffers
+  if (c->res_slot >= 0 && c->slots[c->res_slot]->state == 1) c->slots[c->res_slot]->state = 0;   // never handed to the chain DP
+  c->res_slot = -1;
   Side& V = c->side[0]; Side& A = c->side[1];
   unsigned long long* d_cnt = c->counters.as<unsigned long long>();
   const int mode = c->pend_mode; const int64_t n_v = c->pend_nv;
@@ -449,8 +496,8 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
     v.n_out = d_cnt + 1;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     for (int attempt = 0; attempt < 2; ++attempt) {
-      HIP_TRY(c, c->keys0.ensure(sizeof(unsigned long long) * mcap)); HIP_TRY(c, c->keys1.ensure(sizeof(unsigned long long) * mcap));
-      HIP_TRY(c, c->q0.ensure(sizeof(double) * mcap)); HIP_TRY(c, c->q1.ensure(sizeof(double) * mcap));
+      HIP_TRY(c, c->keys0.ensure(sizeof(unsigned long long) * mcap));
+      HIP_TRY(c, c->q0.ensure(sizeof(double) * mcap));
       v.keys = c->keys0.as<unsigned long long>(); v.quals = c->q0.as<double>(); v.out_capacity = mcap;
       HIP_TRY(c, hipMemsetAsync(d_cnt + 1, 0, 2 * sizeof(unsigned long long), c->stream));
       launch_verify(v, n_surv, c->stream);
@@ -461,16 +508,23 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
       if (attempt == 1) return fail(c, DA_ERR_DEVICE, "da_match: match list kept overflowing");
       mcap = (size_t)n_match + 1024;
     }
+    const int si = acquire_slot(c);
+    if (si < 0) return fail(c, DA_ERR_STATE, "da_match: all %d chain slots are in flight; collect them with da_chain_finish", kMaxChainSlots);
+    ChainSlot& sl = *c->slots[si];
+    HIP_TRY(c, sl.keys.ensure(sizeof(unsigned long long) * std::max<size_t>(1, n_match)));
+    HIP_TRY(c, sl.q.ensure(sizeof(double) * std::max<size_t>(1, n_match)));
+    sl.n = (int64_t)n_match; sl.n_ranks = n_v; sl.state = 1;
+    c->res_slot = si;
     if (n_match > 0) {
       size_t tmp_bytes = 0;
       if (sort_pairs(nullptr, nullptr, nullptr, nullptr, (int64_t)n_match, nullptr, &tmp_bytes, c->stream) != 0)
         return fail(c, DA_ERR_DEVICE, "da_match: sort sizing failed");
       HIP_TRY(c, c->sort_tmp.ensure(tmp_bytes + 256));
-      if (sort_pairs(c->keys0.as<unsigned long long>(), c->keys1.as<unsigned long long>(), c->q0.as<double>(),
-                     c->q1.as<double>(), (int64_t)n_match, c->sort_tmp.p, &tmp_bytes, c->stream) != 0)
+      if (sort_pairs(c->keys0.as<unsigned long long>(), sl.keys.as<unsigned long long>(), c->q0.as<double>(),
+                     sl.q.as<double>(), (int64_t)n_match, c->sort_tmp.p, &tmp_bytes, c->stream) != 0)
         return fail(c, DA_ERR_DEVICE, "da_match: device sort failed");
       // keys0 is free again after the sort: unpack the sorted keys into two int32 arrays there
-      launch_unpack_keys(c->keys1.as<unsigned long long>(), (int64_t)n_match, c->keys0.as<int32_t>(),
+      launch_unpack_keys(sl.keys.as<unsigned long long>(), (int64_t)n_match, c->keys0.as<int32_t>(),
                          c->keys0.as<int32_t>() + n_match, c->stream);
       HIP_TRY(c, hipGetLastError());
     }
@@ -514,7 +568,8 @@ extern "C" int da_match_fetch(da_ctx* c, int32_t* out_i, int32_t* out_v, double*
   // while the next pair's da_match_begin work occupies the compute stream
   HIP_TRY(c, hipMemcpyAsync(out_i, d_i, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->copy_stream));
   HIP_TRY(c, hipMemcpyAsync(out_v, d_i + c->n_match_resident, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->copy_stream));
-  HIP_TRY(c, hipMemcpyAsync(out_q, c->q1.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->copy_stream));
+  if (c->res_slot < 0) return fail(c, DA_ERR_STATE, "da_match_fetch: no finished match is resident");
+  HIP_TRY(c, hipMemcpyAsync(out_q, c->slots[c->res_slot]->q.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->copy_stream));
   HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
   return DA_OK;
 }
@@ -538,22 +593,30 @@ extern "C" int da_match_corr(da_ctx* c, const int32_t* pi, const int32_t* pv, in
 }
 
 // ------------------------------------------------------------------------------------- chain DP
-// Heaviest chain non-decreasing in both coordinates (describealign.py:654-656, :674-697) as a
-// prefix-max Fenwick tree over the rank of v.  Equal cumulative weights resolve to the point
-// added later, which is what the reference's staircase frontier does (a new entry evicts
-// entries to its right whose weight is not larger, :679-680).
-extern "C" int da_chain(da_ctx* c, const int32_t* pi, const int32_t* pv, const double* pq, int64_t n, double min_len,
-                        int32_t* path_i, int32_t* path_v, int64_t* n_path) {
-  // c may be NULL: the chain DP is host-only, so CPU worker processes can call it without a device
-  if (n < 0 || !n_path || (n > 0 && (!pi || !pv || !pq))) return fail(c, DA_ERR_ARG, "da_chain: bad argument");
-  const double t0 = now_ms();
-  int32_t vmax = -1;
+// Heaviest chain non-decreasing in both coordinates (describealign.py:654-656, :674-697).  With a
+// context it runs on the device (dalign_chain.hip); with a NULL context the host utility below is
+// used (CPU-only callers: tests, tools) -- same recurrence, prefix-max Fenwick tree over the rank of v.
+// Equal cumulative weights resolve to the point added later, which is what the reference's
+// staircase frontier does (a new entry evicts entries to its right whose weight is not larger,
+// :679-680).
+namespace {
+
+int check_sorted(da_ctx* c, const int32_t* pi, const int32_t* pv, int64_t n, int32_t& vmax) {
+  vmax = -1;
   for (int64_t k = 0; k < n; ++k) {
-    if (pv[k] < 0) return fail(c, DA_ERR_ARG, "da_chain: negative video index");
+    if (pv[k] < 0 || pi[k] < 0) return fail(c, DA_ERR_ARG, "da_chain: negative frame index");
     vmax = std::max(vmax, pv[k]);
-    if (k > 0 && (pi[k] < pi[k - 1] || (pi[k] == pi[k - 1] && pv[k] < pv[k - 1])))
+    if (k > 0 && (pi[k] < pi[k - 1] || (pi[k] == pi[k - 1] && pv[k] <= pv[k - 1])))
       return fail(c, DA_ERR_ARG, "da_chain: input not sorted by (i, v)");
   }
+  return DA_OK;
+}
+
+int chain_host(da_ctx* c, const int32_t* pi, const int32_t* pv, const double* pq, int64_t n, double min_len,
+               int32_t* path_i, int32_t* path_v, int64_t* n_path) {
+  const double t0 = now_ms();
+  int32_t vmax = -1;
+  if (int rc = check_sorted(c, pi, pv, n, vmax)) return rc;
   std::vector<int32_t> rank((size_t)vmax + 2, 0);
   for (int64_t k = 0; k < n; ++k) rank[pv[k]] = 1;
   int32_t nr = 0;
@@ -587,6 +650,168 @@ extern "C" int da_chain(da_ctx* c, const int32_t* pi, const int32_t* pv, const d
   if ((int64_t)chain.size() > capacity) return fail(c, DA_ERR_CAPACITY, "da_chain: path of %zu exceeds capacity", chain.size());
   for (size_t k = 0; k < chain.size(); ++k) { path_i[k] = pi[chain[k]]; path_v[k] = pv[chain[k]]; }
   return DA_OK;
+}
+
+// enqueue the device DP of slot `sl` (sorted keys / q resident).  The per-match ranks come either
+// from the video row list of the match (rank_from_vlist) or have been uploaded into sl.rank.
+int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
+  const int64_t n = sl.n;
+  const size_t nn = (size_t)std::max<int64_t>(1, n);
+  HIP_TRY(c, sl.rank.ensure(sizeof(int32_t) * nn)); HIP_TRY(c, sl.flags.ensure(nn));
+  HIP_TRY(c, sl.rows.ensure(sizeof(int32_t) * (nn + 1))); HIP_TRY(c, sl.pred.ensure(sizeof(int32_t) * nn));
+  HIP_TRY(c, sl.ids.ensure(sizeof(int32_t) * nn)); HIP_TRY(c, sl.out_iv.ensure(sizeof(int32_t) * 2 * nn));
+  HIP_TRY(c, sl.tree.ensure(16 * ((size_t)sl.n_ranks + 2)));
+  HIP_TRY(c, sl.small.ensure(64));
+  const size_t tb = da::chain_rows_temp_bytes(n);
+  HIP_TRY(c, sl.temp.ensure(tb + 256));
+  hipStream_t st = sl.stream;
+  // `small`: int32 [0] rows, [1] err; int64 [1] best id, [2] path length
+  ChainLaunch L{};
+  L.keys = sl.keys.as<unsigned long long>(); L.q = sl.q.as<double>(); L.n = n;
+  L.n_ranks = sl.n_ranks; L.rank = sl.rank.as<int32_t>(); L.flags = sl.flags.as<uint8_t>();
+  L.row_start = sl.rows.as<int32_t>(); L.d_nrows = sl.small.as<int32_t>(); L.err = sl.small.as<int32_t>() + 1;
+  L.temp = sl.temp.p; L.temp_bytes = tb;
+  L.tree_lo = sl.tree.p; L.pred = sl.pred.as<int32_t>(); L.path_ids = sl.ids.as<int32_t>();
+  L.meta = sl.small.as<int64_t>() + 1; L.out_i = sl.out_iv.as<int32_t>(); L.out_v = sl.out_iv.as<int32_t>() + nn;
+  if (rank_from_vlist) {
+    // the rank map is built from this match's video row list on the MAIN stream (the next
+    // da_match_begin overwrites that list); the slot's stream waits for it
+    HIP_TRY(c, c->rankmap.ensure(sizeof(int32_t) * (size_t)std::max<int64_t>(1, c->res_lv)));
+    HIP_TRY(c, hipMemsetAsync(c->rankmap.p, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(1, c->res_lv), c->stream));
+    da::launch_rankmap(c->vlist.as<int32_t>(), sl.n_ranks, c->rankmap.as<int32_t>(), c->stream);
+    L.rankmap = c->rankmap.as<int32_t>(); L.rankmap_len = c->res_lv;
+  }
+  HIP_TRY(c, hipMemsetAsync(sl.small.p, 0, 64, c->stream));
+  HIP_TRY(c, hipMemsetAsync(sl.tree.p, 0, 16 * ((size_t)sl.n_ranks + 2), c->stream));
+  if (da::launch_chain_prep(L, c->stream) != 0) return fail(c, DA_ERR_ARG, "da_chain: %lld matches / %lld video rows exceed the kernel's range", (long long)n, (long long)sl.n_ranks);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(sl.ready, c->stream));
+  HIP_TRY(c, hipStreamWaitEvent(st, sl.ready, 0));
+  HIP_TRY(c, hipEventRecord(sl.e0, st));
+  if (da::launch_chain_dp(L, st) != 0) return fail(c, DA_ERR_DEVICE, "da_chain: launch failed");
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(sl.e1, st));
+  HIP_TRY(c, hipMemcpyAsync(sl.h_small, sl.small.p, 32, hipMemcpyDeviceToHost, st));
+  sl.state = 2;
+  sl.ticket = c->next_ticket++;
+  return DA_OK;
+}
+
+// wait for a slot's DP and hand the path out; frees the slot unless the caller's buffers were too small
+int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
+  HIP_TRY(c, hipStreamSynchronize(sl.stream));
+  float ms = 0.f; (void)hipEventElapsedTime(&ms, sl.e0, sl.e1); c->st.chain_ms = ms;
+  const int err = (int)((unsigned long long)sl.h_small[0] >> 32);
+  const int64_t L = sl.n > 0 ? (int64_t)sl.h_small[2] : 0;
+  if (err) {
+    sl.state = 0;
+    return fail(c, DA_ERR_ARG, err & 1 ? "da_chain: qualities must be finite and positive (describealign.py:672 yields (0, 50])"
+                                       : (err & 2 ? "da_chain: input not sorted by (i, v)" : "da_chain: a match names a video frame outside the matched rows"));
+  }
+  const int64_t capacity = *n_path;
+  *n_path = L;
+  if ((double)L < min_len) { sl.state = 0; return fail(c, DA_ERR_MISMATCH, "Alignment failed, are the input files mismatched?"); }
+  if (L > capacity) return fail(c, DA_ERR_CAPACITY, "da_chain: path of %lld exceeds capacity %lld", (long long)L, (long long)capacity);
+  if (L > 0) {
+    if (!path_i || !path_v) return fail(c, DA_ERR_ARG, "da_chain: null output");
+    const size_t nn = (size_t)std::max<int64_t>(1, sl.n);
+    HIP_TRY(c, hipMemcpyAsync(path_i, sl.out_iv.as<int32_t>(), sizeof(int32_t) * L, hipMemcpyDeviceToHost, sl.stream));
+    HIP_TRY(c, hipMemcpyAsync(path_v, sl.out_iv.as<int32_t>() + nn, sizeof(int32_t) * L, hipMemcpyDeviceToHost, sl.stream));
+    HIP_TRY(c, hipStreamSynchronize(sl.stream));
+  }
+  sl.state = 0;
+  return DA_OK;
+}
+
+}  // namespace
+
+extern "C" int da_chain(da_ctx* c, const int32_t* pi, const int32_t* pv, const double* pq, int64_t n, double min_len,
+                        int32_t* path_i, int32_t* path_v, int64_t* n_path) {
+  if (n < 0 || !n_path || (n > 0 && (!pi || !pv || !pq))) return fail(c, DA_ERR_ARG, "da_chain: bad argument");
+  if (!c) return chain_host(nullptr, pi, pv, pq, n, min_len, path_i, path_v, n_path);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int32_t vmax = -1;
+  if (int rc = check_sorted(c, pi, pv, n, vmax)) return rc;
+  const int si = acquire_slot(c);
+  if (si < 0) return fail(c, DA_ERR_STATE, "da_chain: all chain slots are in flight");
+  ChainSlot& sl = *c->slots[si];
+  // dense 1-based ranks of the video frames that occur
+  std::vector<int32_t> rk((size_t)vmax + 2, 0);
+  for (int64_t k = 0; k < n; ++k) rk[pv[k]] = 1;
+  int32_t nr = 0;
+  for (size_t x = 0; x < rk.size(); ++x) if (rk[x]) rk[x] = ++nr;
+  std::vector<unsigned long long> keys((size_t)n);
+  std::vector<int32_t> ranks((size_t)n);
+  for (int64_t k = 0; k < n; ++k) { keys[k] = ((unsigned long long)(uint32_t)pi[k] << 32) | (uint32_t)pv[k]; ranks[k] = rk[pv[k]]; }
+  const size_t nn = (size_t)std::max<int64_t>(1, n);
+  HIP_TRY(c, sl.keys.ensure(sizeof(unsigned long long) * nn)); HIP_TRY(c, sl.q.ensure(sizeof(double) * nn));
+  HIP_TRY(c, sl.rank.ensure(sizeof(int32_t) * nn));
+  if (n > 0) {
+    HIP_TRY(c, hipMemcpyAsync(sl.keys.p, keys.data(), sizeof(unsigned long long) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(sl.q.p, pq, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(sl.rank.p, ranks.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+  }
+  sl.n = n; sl.n_ranks = nr;
+  int rc = chain_enqueue(c, sl, false);
+  if (rc) { (void)hipStreamSynchronize(c->stream); sl.state = 0; return rc; }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));          // the host staging vectors go out of scope
+  rc = chain_collect(c, sl, min_len, path_i, path_v, n_path);
+  if (rc == DA_ERR_CAPACITY) sl.state = 0;              // one-shot call: nothing stays resident
+  return rc;
+}
+
+extern "C" int da_chain_begin(da_ctx* c, uint64_t* ticket) {
+  if (!c) return DA_ERR_ARG;
+  if (!ticket) return fail(c, DA_ERR_ARG, "da_chain_begin: null ticket");
+  if (!c->fetch_ready) return fail(c, DA_ERR_STATE, "da_chain_begin: no finished match is resident");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int si = c->res_slot;
+  if (si < 0) {                                         // the match produced nothing: an empty DP
+    si = acquire_slot(c);
+    if (si < 0) return fail(c, DA_ERR_STATE, "da_chain_begin: all chain slots are in flight");
+    c->slots[si]->n = 0; c->slots[si]->n_ranks = 0;
+  }
+  ChainSlot& sl = *c->slots[si];
+  if (sl.state == 2) return fail(c, DA_ERR_STATE, "da_chain_begin: the chain DP of this match is already in flight");
+  const int rc = chain_enqueue(c, sl, true);
+  if (rc) return rc;
+  c->res_slot = si;                                     // still the resident match (da_match_fetch keeps working)
+  *ticket = sl.ticket;
+  return DA_OK;
+}
+
+extern "C" int da_chain_finish(da_ctx* c, uint64_t ticket, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
+  if (!c) return DA_ERR_ARG;
+  if (!n_path) return fail(c, DA_ERR_ARG, "da_chain_finish: bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (size_t k = 0; k < c->slots.size(); ++k) {
+    ChainSlot& sl = *c->slots[k];
+    if (sl.state == 2 && sl.ticket == ticket) {
+      const int rc = chain_collect(c, sl, min_len, path_i, path_v, n_path);
+      if (sl.state == 0 && c->res_slot == (int)k) { c->res_slot = -1; c->fetch_ready = false; }
+      return rc;
+    }
+  }
+  return fail(c, DA_ERR_STATE, "da_chain_finish: unknown ticket %llu", (unsigned long long)ticket);
+}
+
+extern "C" int da_chain_poll(da_ctx* c, uint64_t ticket) {
+  if (!c) return DA_ERR_ARG;
+  for (ChainSlot* sl : c->slots)
+    if (sl->state == 2 && sl->ticket == ticket) {
+      const hipError_t e = hipStreamQuery(sl->stream);
+      if (e == hipSuccess) return 1;
+      if (e == hipErrorNotReady) return 0;
+      return fail(c, DA_ERR_DEVICE, "da_chain_poll: %s", hipGetErrorString(e));
+    }
+  return fail(c, DA_ERR_STATE, "da_chain_poll: unknown ticket %llu", (unsigned long long)ticket);
+}
+
+extern "C" int da_chain_resident(da_ctx* c, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
+  uint64_t t = 0;
+  int rc = da_chain_begin(c, &t);
+  if (rc) return rc;
+  return da_chain_finish(c, t, min_len, path_i, path_v, n_path);
 }
 
 // ------------------------------------------------------------------------------------- refine

@@ -119,4 +119,30 @@ void launch_band_refine(const BandArgs& a, double* d_partials, int n_blocks, hip
 void launch_band_quality(const BandArgs& a, double* d_y, double* d_q, hipStream_t s);
 void launch_colmax(const double* d, int64_t n, int stride, double* d_out, hipStream_t s);
 
+// ---- stage-2 chain DP on the device (dalign_chain.hip) ---------------------------------------
+struct ChainArgs {                         // k_chain_forward
+  const double* q; const int32_t* rank;    // per match, sorted by (i, v); rank = 1-based video rank
+  const int32_t* row_start; const int32_t* d_nrows;   // first match of every audio row; row count (device)
+  int64_t n; int64_t n_ranks; int S;       // S lowest tree levels in global memory, the rest in LDS
+  uint4* tree_lo;                          // [n_ranks + 1] 16-byte (sum, id + 1) nodes, zeroed
+  int32_t* pred;                           // [n] predecessor ids (-1 = none)
+  int64_t* meta;                           // [0] id of the heaviest point (-1 = none), [1] path length
+};
+struct ChainLaunch {
+  const unsigned long long* keys; const double* q; int64_t n;   // sorted (i << 32 | v), qualities
+  const int32_t* rankmap; int64_t rankmap_len;                  // video frame -> 1-based rank, or NULL when `rank` is filled in
+  int64_t n_ranks;
+  int32_t* rank; uint8_t* flags; int32_t* row_start; int32_t* d_nrows; int32_t* err;
+  void* temp; size_t temp_bytes;                                // hipCUB select scratch (chain_rows_temp_bytes)
+  void* tree_lo; int32_t* pred; int32_t* path_ids; int64_t* meta;
+  int32_t* out_i; int32_t* out_v;                               // the path, ascending
+};
+int chain_tree_shift(int64_t n_ranks);
+size_t chain_rows_temp_bytes(int64_t n);
+// prep = per-match ranks / row-head flags / validation; dp = row starts, forward DP, back-track, gather.
+// Both return -1 when the input is out of the kernels' range.
+int launch_chain_prep(const ChainLaunch& c, hipStream_t s);
+int launch_chain_dp(const ChainLaunch& c, hipStream_t s);
+void launch_rankmap(const int32_t* vlist, int64_t n_v, int32_t* rankmap, hipStream_t s);
+
 }  // namespace da

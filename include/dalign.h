@@ -103,9 +103,28 @@ int da_match_corr(da_ctx* ctx, const int32_t* i, const int32_t* v, int64_t n, fl
  * describealign.py:654-656, :674-698: heaviest chain non-decreasing in both coordinates over
  * matches sorted by (i, v).  *n_path in: capacity, out: length.  min_len = the reference's
  * failure bound max(min(Lv,La)/500, 1050) (:698); shorter -> DA_ERR_MISMATCH.
- * Host-only: ctx may be NULL (no device needed; then only the return code reports errors). */
+ * With a context the DP runs on the device (one persistent wavefront walking the audio rows:
+ * Fenwick prefix maxima in LDS / L2, exact in-order double sums; qualities must be > 0 as the
+ * reference's are, :672).  ctx may be NULL: a host-only utility with the same result for CPU
+ * tools and tests (then only the return code reports errors). */
 int da_chain(da_ctx* ctx, const int32_t* i, const int32_t* v, const double* q, int64_t n,
              double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path);
+
+/* The same DP on the matches of the most recent da_match / da_match_finish, which are still
+ * resident on the device: nothing but the path travels to the host (a 2 h pair has ~5e7 matches,
+ * its path ~1.5e6 points).  da_chain_begin hands the resident match list to the DP and ENQUEUES it on
+ * a stream of its own -- one persistent workgroup per pair, so the DPs of several pairs run beside
+ * the similarity GEMMs of later pairs -- and returns a ticket; the context is immediately free for
+ * the next da_match_begin.  da_chain_finish(ticket) waits for that DP and returns its path
+ * (*n_path in: capacity, out: length; DA_ERR_CAPACITY keeps the result collectable).  At most 16
+ * tickets may be outstanding per context.  da_chain_resident == begin + finish. */
+int da_chain_begin(da_ctx* ctx, uint64_t* ticket);
+int da_chain_finish(da_ctx* ctx, uint64_t ticket, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path);
+int da_chain_resident(da_ctx* ctx, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path);
+/* 1 when the DP behind `ticket` has completed (da_chain_finish will not block), 0 while it runs,
+ * negative on error.  Lets the thread that feeds the context collect finished DPs between its own
+ * calls; a context is still used by one thread at a time. */
+int da_chain_poll(da_ctx* ctx, uint64_t ticket);
 
 /* ---- stage 4: banded line extension + second DP ---------------------------------------------
  * describealign.py:895-993.  a_scaled [La][3], v_scaled [Lv][3] (the scaled feature stacks of
@@ -155,7 +174,7 @@ typedef struct da_stats_t {
   double verify_ms;          /* exact re-verification + compaction + sort */
   double survivors;          /* pairs the GEMM passed to verification */
   double matches;            /* verified matches returned */
-  double chain_ms;           /* host DP */
+  double chain_ms;           /* stage-2 chain DP: device time of the last collected DP (host time with a NULL-ctx call) */
   double refine_kernel_ms;   /* banded evaluation kernels */
   double refine_dp_ms;       /* host second DP */
   double refine_points;

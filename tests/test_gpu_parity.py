@@ -164,6 +164,55 @@ def test_chain_equals_reference_path(ctx, a40):
   assert np.array_equal(pi, i[idx]) and np.array_equal(pv, v[idx])
 
 
+def _random_chain_instance(rng, n, rows, cols, step=4, quals=(50.0, 50.0, 12.5, 3.25, 0.75)):
+  i = np.sort(rng.integers(0, rows, n)); v = rng.integers(0, cols, n) * step
+  keys = np.unique(i.astype(np.int64) * (1 << 32) + v)
+  i, v = (keys >> 32).astype(np.int32), (keys & 0xffffffff).astype(np.int32)
+  return i, v, rng.choice(quals, len(i))
+
+
+@pytest.mark.parametrize("shape", ["wide_rows", "many_ranks", "sparse"])
+def test_chain_kernel_equals_host_utility(ctx, native, shape):
+  """The device DP (da_chain with a context) against the host utility (NULL context) on instances
+  that exercise what the goldens do not: rows with more than 64 points (several wavefront steps per
+  row, carried sums), more than 2^19 distinct video ranks (another LDS / L2 split of the tree) and
+  rows of one or two points.  Qualities are drawn from a few values, so equal sums abound."""
+  rng = np.random.default_rng({"wide_rows": 1, "many_ranks": 2, "sparse": 3}[shape])
+  if shape == "wide_rows":
+    i, v, q = _random_chain_instance(rng, 60000, 300, 5000)              # ~200 points per row
+  elif shape == "many_ranks":
+    i, v, q = _random_chain_instance(rng, 1500000, 40000, 1200000, step=1)
+  else:
+    i, v, q = _random_chain_instance(rng, 20000, 15000, 30000)
+  want_i, want_v = native.chain_host(i, v, q)
+  got_i, got_v = ctx.chain(i, v, q)
+  assert len(got_i) == len(want_i) and np.array_equal(got_i, want_i) and np.array_equal(got_v, want_v)
+  assert ctx.stats()["chain_ms"] > 0
+
+
+def test_chain_resident_equals_chain_of_fetched_matches(ctx, native):
+  """da_chain_resident works on the match list left on the device by da_match; the same list copied
+  out and run through the host utility gives the same path.  Two DPs may be in flight at once."""
+  pairs = [cases.align_case("e180"), cases.align_case("a40")]
+  want, tickets = [], []
+  for p in pairs:
+    vf = ctx.features(p.video, 0); af = ctx.features(p.audio, 1)
+    mi, mv, mq = ctx.match(vf, af)
+    want.append(native.chain_host(mi, mv, mq))
+    tickets.append(ctx.chain_begin())                 # the next match starts while this DP runs
+  for t, (wi, wv) in zip(tickets, want):
+    gi, gv = ctx.chain_finish(t)
+    assert np.array_equal(gi, wi) and np.array_equal(gv, wv) and len(gi) > 1000
+  with pytest.raises(RuntimeError, match="unknown ticket"):
+    ctx.chain_finish(tickets[0])
+
+
+def test_chain_rejects_nonpositive_quality(ctx):
+  i = np.arange(10, dtype=np.int32); v = np.arange(10, dtype=np.int32); q = np.ones(10); q[4] = 0.0
+  with pytest.raises(RuntimeError, match="positive"):
+    ctx.chain(i, v, q)
+
+
 def test_chain_mismatch_error(ctx):
   i = np.arange(10, dtype=np.int32); v = np.arange(10, dtype=np.int32); q = np.ones(10)
   with pytest.raises(RuntimeError, match="Alignment failed, are the input files mismatched"):
@@ -469,7 +518,7 @@ def test_bench_launch_contract_two_ranks(tmp_path):
   env = dict(os.environ, DALIGN_DIST_BACKEND="gloo", DALIGN_BENCH_DEVICE="0")
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
          "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-         "--pipeline", "2", "--no-cpu-baseline"]
+         "--pipeline", "2", "--no-cpu-baseline", "--workload", "cfg-small"]
   res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
   assert res.returncode == 0, res.stderr[-2000:]
   lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
