@@ -14,7 +14,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdalign.so")
+LIB_PATH = os.environ.get("DALIGN_LIB") or os.path.join(_HERE, "libdalign.so")   # DALIGN_LIB: diagnostic builds
 ABI_VERSION = 3
 
 PREC_F32, PREC_BF16 = 0, 1

@@ -660,8 +660,8 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
   HIP_TRY(c, sl.rank.ensure(sizeof(int32_t) * nn)); HIP_TRY(c, sl.flags.ensure(nn));
   HIP_TRY(c, sl.rows.ensure(sizeof(int32_t) * (nn + 1))); HIP_TRY(c, sl.pred.ensure(sizeof(int32_t) * nn));
   HIP_TRY(c, sl.ids.ensure(sizeof(int32_t) * nn)); HIP_TRY(c, sl.out_iv.ensure(sizeof(int32_t) * 2 * nn));
-  HIP_TRY(c, sl.tree.ensure(16 * ((size_t)sl.n_ranks + 2)));
-  HIP_TRY(c, sl.small.ensure(64));
+  HIP_TRY(c, sl.tree.ensure(16 * ((size_t)sl.n_ranks + 2 + 64)));        // + one scrap record per lane
+  HIP_TRY(c, sl.small.ensure(128));
   const size_t tb = da::chain_rows_temp_bytes(n);
   HIP_TRY(c, sl.temp.ensure(tb + 256));
   hipStream_t st = sl.stream;
@@ -681,7 +681,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     da::launch_rankmap(c->vlist.as<int32_t>(), sl.n_ranks, c->rankmap.as<int32_t>(), c->stream);
     L.rankmap = c->rankmap.as<int32_t>(); L.rankmap_len = c->res_lv;
   }
-  HIP_TRY(c, hipMemsetAsync(sl.small.p, 0, 64, c->stream));
+  HIP_TRY(c, hipMemsetAsync(sl.small.p, 0, 128, c->stream));
   HIP_TRY(c, hipMemsetAsync(sl.tree.p, 0, 16 * ((size_t)sl.n_ranks + 2), c->stream));
   if (da::launch_chain_prep(L, c->stream) != 0) return fail(c, DA_ERR_ARG, "da_chain: %lld matches / %lld video rows exceed the kernel's range", (long long)n, (long long)sl.n_ranks);
   HIP_TRY(c, hipGetLastError());
@@ -701,6 +701,14 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
 int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
   HIP_TRY(c, hipStreamSynchronize(sl.stream));
   float ms = 0.f; (void)hipEventElapsedTime(&ms, sl.e0, sl.e1); c->st.chain_ms = ms;
+  if (std::getenv("DALIGN_DEBUG_STAMPS")) {               // diagnostic builds (-DDA_CHAIN_STAMPS) only
+    long long st[6];
+    if (hipMemcpy(st, sl.small.as<int64_t>() + 3, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
+      double tot = 0; for (long long v : st) tot += (double)v;
+      if (tot > 0) std::fprintf(stderr, "chain stamps: setup %.1f%% issue-loads %.1f%% wait+reduce %.1f%% jacobi %.1f%% update %.1f%% (total %.0f ticks, %.2f ms)\n",
+                                100 * st[0] / tot, 100 * st[1] / tot, 100 * st[2] / tot, 100 * st[3] / tot, 100 * st[4] / tot, tot, ms);
+    }
+  }
   const int err = (int)((unsigned long long)sl.h_small[0] >> 32);
   const int64_t L = sl.n > 0 ? (int64_t)sl.h_small[2] : 0;
   if (err) {

@@ -33,8 +33,8 @@ namespace da {
 
 namespace {
 
-constexpr int kLowMax = 8;        // S <= 8 lowest tree levels in global memory
-constexpr int kHighMax = 16;      // up to 16 levels in LDS: ranks < 2^24
+constexpr int kScrap = 64;         // scrap records behind either part of the tree, one per lane
+constexpr int kLowMax = 8;        // S <= 8 lowest tree levels in global memory; up to 16 levels in LDS: ranks < 2^24
 
 __device__ __forceinline__ bool beats(double ac, uint32_t ai, double bc, uint32_t bi) {
   return ac > bc || (ac == bc && ai > bi);
@@ -43,17 +43,15 @@ __device__ __forceinline__ double node_cum(const uint4& n) { return __hiloint2do
 __device__ __forceinline__ uint4 make_node(double c, uint32_t id1) {
   return uint4{(uint32_t)__double2loint(c), (uint32_t)__double2hiint(c), id1, 0u};
 }
-// value of the lane to the left (lane 0: `edge`), whole-wave shift by one lane
-__device__ __forceinline__ double left_neighbour(double x, double edge) {
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(x), 0x138, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(x), 0x138, 0xf, 0xf, false);
+// value of the lane to the left (lane 0 reads 0.0), whole-wave shift by one lane
+__device__ __forceinline__ double left_neighbour(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double max_f64(double a, double b) {     // plain v_max_f64 (no NaNs here)
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+// one v_max_f64: this file is compiled with -ffinite-math-only (no NaN canonicalisation, and no
+// hazard padding as around inline assembly); nothing here is ever NaN or infinite
+__device__ __forceinline__ double max_f64(double a, double b) { return __builtin_fmax(a, b); }
 __device__ __forceinline__ double read_lane(double x, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
@@ -93,128 +91,179 @@ __global__ __launch_bounds__(256) void k_rankmap(const int32_t* __restrict__ vli
   if (r < n_v) rankmap[vlist[r]] = (int32_t)r + 1;
 }
 
+// LOW = S = tree levels in global memory, HIGH >= number of levels in LDS: every step loads exactly
+// LOW + HIGH query nodes and LOW + HIGH update-path nodes per lane, unconditionally (slot 0 of
+// either array is the permanently empty "no node" record), so that one s_waitcnt covers them all --
+// a conditional load per level costs a full memory round trip each.
+#ifdef DA_CHAIN_STAMPS          // diagnostic build only: cycles per phase into meta[2..7]
+#define DA_STAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += t_ - stamp_t; stamp_t = t_; }
+#else
+#define DA_STAMP(k)
+#endif
+
+template <int LOW, int HIGH>
 __global__ __launch_bounds__(64) void k_chain_forward(ChainArgs a) {
+#ifdef DA_CHAIN_STAMPS
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
   extern __shared__ uint4 s_hi[];                    // tree levels with span >= 2^S: node h covers ranks ((h - lowbit(h)) << S, h << S]
   const int lane = threadIdx.x;
   const uint32_t n_ranks = (uint32_t)a.n_ranks;
-  const int S = a.S;
+  constexpr int S = LOW;
   const uint32_t H = n_ranks >> S;
   for (uint32_t h = lane; h <= H; h += 64) s_hi[h] = uint4{0u, 0u, 0u, 0u};
   __syncthreads();
-  uint4* __restrict__ lo = a.tree_lo;                // index = rank; [0] stays empty (the "no node" slot)
+  uint4* __restrict__ lo = a.tree_lo;                // index = rank; [0] stays empty
   const int32_t n_rows = *a.d_nrows;
-  const uint32_t lowmask = (1u << S) - 1u;
-  const double NEG = -__builtin_huge_val();
+  constexpr uint32_t lowmask = (1u << S) - 1u;
+  const double NEG = -1.0e300;                       // below every sum; adding a quality leaves it there
   double best_c = 0.0;
   uint32_t best_i = 0u;                              // id + 1; 0 = none
+  uint32_t best_r = 0xFFFFFFFFu;                     // its video rank
   const int32_t n = (int32_t)a.n;
 
-  int32_t rb = n_rows > 0 ? a.row_start[0] : 0;
-  int32_t re = n_rows > 1 ? a.row_start[1] : n;
-  // first chunk of the current row, prefetched one row ahead
-  uint32_t r_pf = 0u; double q_pf = 0.0;
-  if (n_rows > 0 && rb + lane < re) { r_pf = (uint32_t)a.rank[rb + lane]; q_pf = a.q[rb + lane]; }
+  // Row boundaries: 64 at a time, one per lane, two blocks held (the current one and the next), so the
+  // scalar "where does the next row end" never waits for memory.  rs(j) = first match of row j (n past the end).
+  int32_t rs_base = 0;
+  auto load_block = [&](int32_t base) -> int32_t {
+    const int32_t j = base + lane;
+    return j < n_rows ? a.row_start[j] : n;
+  };
+  int32_t rs_cur = load_block(0), rs_nxt = load_block(64);
+  auto rs = [&](int32_t j) -> int32_t {               // j in [rs_base, rs_base + 128)
+    const int32_t o = j - rs_base;
+    return o < 64 ? __builtin_amdgcn_readlane(rs_cur, o) : __builtin_amdgcn_readlane(rs_nxt, o - 64);
+  };
+  int32_t row = 0;
+  int32_t rb = n_rows > 0 ? rs(0) : 0, re = n_rows > 0 ? rs(1) : 0;
+  int32_t c = rb;
+  // the step's points (video rank, quality), prefetched one step ahead
+  uint32_t r_cur = 0u; double q_cur = 0.0;
+  if (c + lane < re) { r_cur = (uint32_t)a.rank[c + lane]; q_cur = a.q[c + lane]; }
+  double carry = NEG;
 
-  for (int32_t row = 0; row < n_rows; ++row) {
-    const int32_t nb = re;
-    const int32_t ne = (row + 2 < n_rows) ? a.row_start[row + 2] : n;
-    uint32_t r_nx = 0u; double q_nx = 0.0;
-    if (row + 1 < n_rows && nb + lane < ne) { r_nx = (uint32_t)a.rank[nb + lane]; q_nx = a.q[nb + lane]; }
-
-    double carry = NEG;
-    for (int32_t c = rb; c < re; c += 64) {
+  while (row < n_rows) {
+    {
       const int cnt = (re - c) < 64 ? (re - c) : 64;
       const int32_t k = c + lane;
       const bool valid = lane < cnt;
-      uint32_t r; double qv;
-      if (c == rb) { r = valid ? r_pf : 0u; qv = valid ? q_pf : 0.0; }
-      else { r = valid ? (uint32_t)a.rank[k] : 0u; qv = valid ? a.q[k] : 0.0; }
+      const uint32_t r = valid ? r_cur : 0u;
+      const double qv = valid ? q_cur : 0.0;
       uint32_t rnext = (uint32_t)__shfl_down((int)r, 1);
       if (lane + 1 >= cnt) rnext = 0xFFFFFFFFu;
+      // where the next step is: the rest of this row, or the start of the next row
+      const bool same_row = c + 64 < re;
+      if (!same_row && row + 1 - rs_base >= 64) {      // slide the boundary blocks
+        rs_base += 64; rs_cur = rs_nxt; rs_nxt = load_block(rs_base + 64);
+      }
+      const int32_t n_c = same_row ? c + 64 : re;
+      const int32_t n_re = same_row ? re : (row + 1 < n_rows ? rs(row + 2) : n);
 
-      // ---- all tree loads of this step: query nodes and the nodes of the update path
-      uint4 ql[kLowMax], qh[kHighMax], ul[kLowMax], uh[kHighMax];
-      uint32_t uli[kLowMax], uhi[kHighMax];
+      DA_STAMP(0)
+      // ---- all tree loads of this step: query nodes and the nodes of the update path.
+      // Shortcut: the heaviest point so far is the prefix maximum of every rank at or right of its
+      // own, so a step whose points all lie there (about half of the steps of a wide row) needs no
+      // query at all.
+      const bool no_query = __all(!valid || r >= best_r);
+      uint4 ql[LOW], qh[HIGH], ul[LOW], uh[HIGH];
+      uint32_t uli[LOW], uhi[HIGH];
+      // Query path, level by level: the node of span 2^t on it is r with the bits below t cleared,
+      // present iff bit t of r is set (no dependence between levels: plain bit masks).
+      if (!no_query) {
+#pragma unroll
+        for (int t = 0; t < LOW; ++t)
+          ql[t] = lo[(r & (1u << t)) ? (r & ~((1u << t) - 1u)) : 0u];
+        const uint32_t rh = r >> S;
+#pragma unroll
+        for (int t = 0; t < HIGH; ++t)
+          qh[t] = s_hi[(rh & (1u << t)) ? (rh & ~((1u << t) - 1u)) : 0u];     // 0: the empty record
+      }
+      // Update path, level by level: r rounded up to a multiple of 2^t is the node when its quotient
+      // is odd (otherwise it belongs to a higher level); the walk stops below `limit`: past the last
+      // rank, or at the first node that also covers the next lane's rank.
       {
-        uint32_t x = r;
+        const uint32_t limit = valid ? (rnext <= n_ranks ? rnext : n_ranks + 1u) : 0u;
 #pragma unroll
-        for (int t = 0; t < kLowMax; ++t) {
-          const bool on = (x & lowmask) != 0u;
-          ql[t] = uint4{0u, 0u, 0u, 0u};
-          if (__any(on)) {
-            ql[t] = lo[on ? x : 0u];
-            x = on ? (x & (x - 1u)) : x;
-          }
+        for (int t = 0; t < LOW; ++t) {
+          const uint32_t y = (r + ((1u << t) - 1u)) & ~((1u << t) - 1u);
+          uli[t] = ((y & (1u << t)) && y < limit) ? y : 0u;
+          ul[t] = lo[uli[t]];
         }
-        uint32_t xh = r >> S;
+        const uint32_t rh = (r + lowmask) >> S;        // r rounded up to a multiple of 2^S, in units of 2^S
+        const uint32_t limit_h = (limit + lowmask) >> S;                       // y << S < limit  <=>  y < ceil(limit / 2^S)
 #pragma unroll
-        for (int t = 0; t < kHighMax; ++t) {
-          const bool on = xh != 0u;
-          qh[t] = uint4{0u, 0u, 0u, 0u};
-          if (__any(on)) {
-            qh[t] = s_hi[on ? xh : 0u];
-            xh = on ? (xh & (xh - 1u)) : xh;
-          }
-        }
-        uint32_t ux = r;
-        bool live = valid;
-#pragma unroll
-        for (int t = 0; t < kLowMax; ++t) {
-          live = live && ux <= n_ranks && ux < rnext;
-          const bool on = live && (ux & lowmask) != 0u;
-          uli[t] = on ? ux : 0u;
-          ul[t] = uint4{0u, 0u, 0u, 0u};
-          if (__any(on)) {
-            ul[t] = lo[uli[t]];
-            ux = on ? ux + (ux & (0u - ux)) : ux;
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < kHighMax; ++t) {
-          live = live && ux <= n_ranks && ux < rnext;
-          const bool on = live;                        // ux is a multiple of 2^S here
-          uhi[t] = on ? (ux >> S) : 0u;
-          uh[t] = uint4{0u, 0u, 0u, 0u};
-          if (__any(on)) {
-            uh[t] = s_hi[uhi[t]];
-            ux = on ? ux + (ux & (0u - ux)) : ux;
-          }
+        for (int t = 0; t < HIGH; ++t) {
+          const uint32_t y = (rh + ((1u << t) - 1u)) & ~((1u << t) - 1u);
+          uhi[t] = ((y & (1u << t)) && y < limit_h) ? y : 0u;
+          uh[t] = s_hi[uhi[t]];
         }
       }
-      // ---- best predecessor among earlier rows (and earlier chunks of this row)
-      double gc = 0.0; uint32_t gi = 0u;
+      // next step's points: issued behind the tree loads, so the (in-order) wait for those does not
+      // include this HBM round trip
+      uint32_t r_nx = 0u; double q_nx = 0.0;
+      if (n_c + lane < n_re) { r_nx = (uint32_t)a.rank[n_c + lane]; q_nx = a.q[n_c + lane]; }
+      DA_STAMP(1)
+      // ---- best predecessor among earlier rows (and earlier chunks of this row): the largest sum,
+      // and among equal sums the largest id
+      double gc = best_c; uint32_t gi = best_i;
+      if (!no_query) {
+        gc = 0.0; gi = 0u;
 #pragma unroll
-      for (int t = 0; t < kLowMax; ++t) {
-        const double cc = node_cum(ql[t]);
-        if (beats(cc, ql[t].z, gc, gi)) { gc = cc; gi = ql[t].z; }
-      }
+        for (int t = 0; t < LOW; ++t) gc = max_f64(gc, node_cum(ql[t]));
 #pragma unroll
-      for (int t = 0; t < kHighMax; ++t) {
-        const double cc = node_cum(qh[t]);
-        if (beats(cc, qh[t].z, gc, gi)) { gc = cc; gi = qh[t].z; }
+        for (int t = 0; t < HIGH; ++t) gc = max_f64(gc, node_cum(qh[t]));
+#pragma unroll
+        for (int t = 0; t < LOW; ++t) gi = (node_cum(ql[t]) == gc && ql[t].z > gi) ? ql[t].z : gi;
+#pragma unroll
+        for (int t = 0; t < HIGH; ++t) gi = (node_cum(qh[t]) == gc && qh[t].z > gi) ? qh[t].z : gi;
       }
-      // ---- chaining inside the row: f[s] = q[s] + max(g[s], f[s-1]), exact and in order
-      double f = NEG;
-      for (int it = 0; it < cnt; ++it) f = qv + max_f64(gc, left_neighbour(f, carry));
-      const double fp = left_neighbour(f, carry);
+      DA_STAMP(2)
+      // ---- chaining inside the row: f[s] = q[s] + max(g[s], f[s-1]), exact and in order.  A Jacobi
+      // sweep: every lane re-evaluates from its left neighbour; the values only grow, so a block of
+      // sweeps that changes nothing is the fixed point (left of the heaviest point runs are short).
+      // Lane 0's left neighbour is the last point of the row's previous step (`carry`); folded into
+      // its g, so the shift can feed it a zero (sums are >= 0).
+      const double ge = lane == 0 ? max_f64(gc, carry) : gc;
+      double f = qv + ge;                              // sweep 0
+      for (int it = 1; it < cnt; it += 8) {
+        const double f0 = f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) f = qv + max_f64(ge, left_neighbour(f));
+        if (!__any(valid && f != f0)) break;
+      }
+      DA_STAMP(3)
+      const double fleft = left_neighbour(f);          // by ALL lanes: a DPP read of a lane masked off by a branch returns 0
+      const double fp = lane == 0 ? carry : fleft;
       const bool from_row = fp >= gc;                  // the row's own point is the later one: it wins ties
       const uint32_t id1 = (uint32_t)k + 1u;
       if (valid) a.pred[k] = from_row ? (k - 1) : ((int32_t)gi - 1);
-      // ---- tree update (disjoint node sets per lane, see header)
+      // ---- tree update (disjoint node sets per lane, see header).  This point is the latest, so
+      // it also wins every tie: f >= node's sum.
+      // Branch-free: a lane with nothing to write stores to its own scrap record behind the tree (one
+      // shared scrap address would serialise the 64 lanes of an LDS write).
+      {
+        const uint4 me = make_node(f, id1);
 #pragma unroll
-      for (int t = 0; t < kLowMax; ++t)
-        if (uli[t] != 0u && beats(f, id1, node_cum(ul[t]), ul[t].z)) lo[uli[t]] = make_node(f, id1);
+        for (int t = 0; t < LOW; ++t)
+          lo[(uli[t] != 0u && f >= node_cum(ul[t])) ? uli[t] : n_ranks + 1u + lane] = me;
 #pragma unroll
-      for (int t = 0; t < kHighMax; ++t)
-        if (uhi[t] != 0u && beats(f, id1, node_cum(uh[t]), uh[t].z)) s_hi[uhi[t]] = make_node(f, id1);
+        for (int t = 0; t < HIGH; ++t)
+          s_hi[(uhi[t] != 0u && f >= node_cum(uh[t])) ? uhi[t] : H + 1u + lane] = me;
+      }
+      DA_STAMP(4)
       // the row's last point carries its largest sum
       const double fl = read_lane(f, cnt - 1);
-      carry = fl;
-      if (fl >= best_c) { best_c = fl; best_i = (uint32_t)(c + cnt); }
+      if (fl >= best_c) { best_c = fl; best_i = (uint32_t)(c + cnt); best_r = (uint32_t)__builtin_amdgcn_readlane((int)r, cnt - 1); }
+      carry = same_row ? fl : NEG;
+      if (!same_row) ++row;
+      c = n_c; re = n_re; r_cur = r_nx; q_cur = q_nx;
     }
-    rb = nb; re = ne; r_pf = r_nx; q_pf = q_nx;
   }
   if (lane == 0) { a.meta[0] = (int64_t)best_i - 1; a.meta[1] = 0; }
+#ifdef DA_CHAIN_STAMPS
+  if (lane == 0) for (int t = 0; t < 6; ++t) a.meta[2 + t] = (int64_t)stamp_acc[t];
+#endif
 }
 
 // Back-track from the heaviest point through pred[] (:690-697).  The chain's ids decrease, and a
@@ -270,7 +319,7 @@ __global__ __launch_bounds__(256) void k_chain_gather(const unsigned long long* 
 int chain_tree_shift(int64_t n_ranks) {
   // LDS holds the levels with span >= 2^S: (n_ranks >> S) + 1 nodes of 16 B within 128 KiB
   int S = 6;
-  while (S < kLowMax && ((n_ranks >> S) + 2) * 16 > 128 * 1024) ++S;
+  while (S < kLowMax && ((n_ranks >> S) + 2 + kScrap) * 16 > 128 * 1024) ++S;
   return S;
 }
 
@@ -285,7 +334,7 @@ size_t chain_rows_temp_bytes(int64_t n) {
 int launch_chain_prep(const ChainLaunch& c, hipStream_t s) {
   if (c.n > 0x7fffffffLL || c.n_ranks >= (1LL << 24)) return -1;
   const int S = chain_tree_shift(c.n_ranks);
-  if (((c.n_ranks >> S) + 2) * 16 > 150 * 1024) return -1;
+  if (((c.n_ranks >> S) + 2 + kScrap) * 16 > 150 * 1024) return -1;
   if (c.n <= 0) return 0;
   const unsigned blocks = (unsigned)((c.n + 255) / 256);
   hipLaunchKernelGGL(k_chain_prep, dim3(blocks), dim3(256), 0, s, c.keys, c.q, c.n, c.rankmap, c.rankmap_len, c.rank, c.flags, c.err);
@@ -302,9 +351,19 @@ int launch_chain_dp(const ChainLaunch& c, hipStream_t s) {
   ChainArgs a{};
   a.q = c.q; a.rank = c.rank; a.row_start = c.row_start; a.d_nrows = c.d_nrows; a.n = c.n;
   a.n_ranks = c.n_ranks; a.S = S; a.tree_lo = reinterpret_cast<uint4*>(c.tree_lo); a.pred = c.pred; a.meta = c.meta;
-  const size_t lds = (size_t)((c.n_ranks >> S) + 2) * 16;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_chain_forward, dim3(1), dim3(64), lds, s, a);
+  const size_t lds = (size_t)((c.n_ranks >> S) + 2 + kScrap) * 16;
+  int hbits = 0;
+  while (((int64_t)1 << hbits) <= (c.n_ranks >> S)) ++hbits;          // levels held in LDS
+  auto go = [&](auto kernel) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(64), lds, s, a);
+  };
+  const int hsel = hbits <= 10 ? 10 : (hbits <= 13 ? 13 : 16);
+#define DA_CHAIN_CASE(L, Hh) if (S == L && hsel == Hh) go(k_chain_forward<L, Hh>);
+  DA_CHAIN_CASE(6, 10) DA_CHAIN_CASE(6, 13) DA_CHAIN_CASE(6, 16)
+  DA_CHAIN_CASE(7, 10) DA_CHAIN_CASE(7, 13) DA_CHAIN_CASE(7, 16)
+  DA_CHAIN_CASE(8, 10) DA_CHAIN_CASE(8, 13) DA_CHAIN_CASE(8, 16)
+#undef DA_CHAIN_CASE
   hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(256), 0, s, c.pred, c.n, c.path_ids, c.meta);
   hipLaunchKernelGGL(k_chain_gather, dim3(256), dim3(256), 0, s, c.keys, c.path_ids, c.meta, c.out_i, c.out_v);
   return 0;
