@@ -305,6 +305,7 @@ def main():
                   help="host worker processes (pass 1, LP); -1 = sized for this rank's share of the host; 0 = strictly sequential align()")
   args = ap.parse_args()
 
+  import torch          # noqa: F401  -- FIRST: its bundled HIP runtime must be the one libdalign.so binds to
   from describealign_amd import distrib
   # DALIGN_DIST_BACKEND=gloo and DALIGN_BENCH_DEVICE=<id> exist so that the multi-rank launch path
   # can be exercised on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device)

@@ -672,6 +672,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
   L.row_start = sl.rows.as<int32_t>(); L.d_nrows = sl.small.as<int32_t>(); L.err = sl.small.as<int32_t>() + 1;
   L.temp = sl.temp.p; L.temp_bytes = tb;
   L.tree_lo = sl.tree.p; L.pred = sl.pred.as<int32_t>(); L.path_ids = sl.ids.as<int32_t>();
+  L.xcd = (int)(c->next_ticket % 8);       // successive DPs go to successive XCDs
   L.meta = sl.small.as<int64_t>() + 1; L.out_i = sl.out_iv.as<int32_t>(); L.out_v = sl.out_iv.as<int32_t>() + nn;
   if (rank_from_vlist) {
     // the rank map is built from this match's video row list on the MAIN stream (the next

@@ -101,8 +101,33 @@ __global__ __launch_bounds__(256) void k_rankmap(const int32_t* __restrict__ vli
 #define DA_STAMP(k)
 #endif
 
+// Placement.  The DP is ONE workgroup that runs for seconds beside the similarity GEMMs of later pairs.
+// The hardware deals the workgroups of a grid round-robin over the 8 XCDs, so a one-block grid would
+// put every pair's DP on the same XCD -- and a GEMM, whose workgroups are dealt statically over the
+// XCDs too, then waits for the one XCD that has lost a quarter of its CUs.  The kernel is therefore
+// launched with one block per XCD; the block that finds itself on XCD `a.xcd` does the work and the
+// others leave at once.  Nothing but speed depends on the placement: if no block sits on the wanted
+// XCD, the block that arrives last takes the job.
+__device__ __forceinline__ bool chain_block_elected(const ChainArgs& a) {
+  __shared__ int s_me;
+  if (threadIdx.x == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xfu;      // HW_REG_XCC_ID[3:0]
+    int me = 0;
+    if (gridDim.x == 1) me = 1;
+    else {
+      if ((int)xcc == a.xcd) me = atomicCAS(a.claim, 0, 1) == 0;
+      const int arrived = atomicAdd(a.claim + 1, 1);
+      if (!me && arrived == (int)gridDim.x - 1) me = atomicCAS(a.claim, 0, 1) == 0;
+    }
+    s_me = me;
+  }
+  __syncthreads();
+  return s_me != 0;
+}
+
 template <int LOW, int HIGH>
 __global__ __launch_bounds__(64) void k_chain_forward(ChainArgs a) {
+  if (!chain_block_elected(a)) return;
 #ifdef DA_CHAIN_STAMPS
   unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
@@ -350,13 +375,14 @@ int launch_chain_dp(const ChainLaunch& c, hipStream_t s) {
   if (hipcub::DeviceSelect::Flagged(c.temp, bytes, ids, c.flags, c.row_start, c.d_nrows, (int)c.n, s) != hipSuccess) return -1;
   ChainArgs a{};
   a.q = c.q; a.rank = c.rank; a.row_start = c.row_start; a.d_nrows = c.d_nrows; a.n = c.n;
+  a.xcd = c.xcd; a.claim = c.d_nrows + 24;         // two ints of the slot's `small` block, zeroed with it
   a.n_ranks = c.n_ranks; a.S = S; a.tree_lo = reinterpret_cast<uint4*>(c.tree_lo); a.pred = c.pred; a.meta = c.meta;
   const size_t lds = (size_t)((c.n_ranks >> S) + 2 + kScrap) * 16;
   int hbits = 0;
   while (((int64_t)1 << hbits) <= (c.n_ranks >> S)) ++hbits;          // levels held in LDS
   auto go = [&](auto kernel) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kernel, dim3(1), dim3(64), lds, s, a);
+    hipLaunchKernelGGL(kernel, dim3(c.xcd >= 0 ? 8 : 1), dim3(64), lds, s, a);
   };
   const int hsel = hbits <= 10 ? 10 : (hbits <= 13 ? 13 : 16);
 #define DA_CHAIN_CASE(L, Hh) if (S == L && hsel == Hh) go(k_chain_forward<L, Hh>);

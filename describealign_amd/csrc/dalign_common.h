@@ -127,6 +127,7 @@ struct ChainArgs {                         // k_chain_forward
   uint4* tree_lo;                          // [n_ranks + 1] 16-byte (sum, id + 1) nodes, zeroed
   int32_t* pred;                           // [n] predecessor ids (-1 = none)
   int64_t* meta;                           // [0] id of the heaviest point (-1 = none), [1] path length
+  int xcd; int* claim;                     // wanted XCD (-1: one block, no election); claim[0] taken, claim[1] arrivals
 };
 struct ChainLaunch {
   const unsigned long long* keys; const double* q; int64_t n;   // sorted (i << 32 | v), qualities
@@ -136,6 +137,7 @@ struct ChainLaunch {
   void* temp; size_t temp_bytes;                                // hipCUB select scratch (chain_rows_temp_bytes)
   void* tree_lo; int32_t* pred; int32_t* path_ids; int64_t* meta;
   int32_t* out_i; int32_t* out_v;                               // the path, ascending
+  int xcd;                                                      // XCD the persistent DP workgroup should sit on (-1: any)
 };
 int chain_tree_shift(int64_t n_ranks);
 size_t chain_rows_temp_bytes(int64_t n);
