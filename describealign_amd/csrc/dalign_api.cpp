@@ -463,10 +463,10 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
     HIP_TRY(c, hipMemcpyAsync(&n_surv, d_cnt, sizeof n_surv, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float ms = 0.f; (void)hipEventElapsedTime(&ms, c->gemm_e0, c->gemm_e1); c->st.gemm_ms = ms;
-    if (std::getenv("DALIGN_DEBUG_STAMPS")) {
+    if (std::getenv("DALIGN_DEBUG_STAMPS")) {               // diagnostic builds (-DDA_DBG_STAMPS) only
       unsigned long long st[16]; debug_read_stamps(st);
-      unsigned long long tot = 0; for (int k = 0; k < 10; ++k) tot += st[k];
-      if (tot) { std::fprintf(stderr, "stamps(%%):"); for (int k = 0; k < 10; ++k) std::fprintf(stderr, " %d:%.1f", k, 100.0 * st[k] / tot); std::fprintf(stderr, "  total_cycles_per_wave=%.0f\n", (double)tot); }
+      if (st[3]) std::fprintf(stderr, "bf16 consumer wave 0 of every block: %.1f cycles per phase (9 MFMAs = 288), barrier wait %.1f, exposed fragment load %.1f per phase; %.2f ms\n",
+                              (double)st[0] / st[3], (double)st[1] / st[3], (double)st[2] / st[3], ms);
     }
     if (n_surv <= cap) break;
     if (attempt == 2) return fail(c, DA_ERR_DEVICE, "da_match: survivor list kept overflowing");

@@ -380,28 +380,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 1) void k_match_f32(MatchArgs 
 // K = 41 padded to 48 = three K-steps of 16, permuted so that lane half h, step s, element e holds
 // k = 24 h + 8 s + e (each lane's operands are 24 consecutive bf16; two shifted copies of the row
 // make any start 4-byte aligned).  Spare slots k = 42, 43 carry the audio window norm split into
-// two bf16 (A holds 1 there): the accumulator ends as |A| (1 - corr) and the epilogue is
-// 2 multiplies + 1 compare against thr |A|_0 |A|_1 |A|_2.
+// two bf16 (A holds 1 there): the accumulator ends as |A| (1 - corr) and the epilogue per video row
+// is three VALU instructions: p = a0 a1;  d = p a2 - thr |A|_0 |A|_1 |A|_2;  mask = (mask << 1) | sign(d).
 //
-// Workgroup = 4 waves x 64 video rows (two 32-row MFMA tiles per wave, A operand in 72 VGPRs).
-// The streamed audio operand is shared by all four waves: it is staged in LDS in MFMA fragment
-// order [tile][feature][step][lane] (1 KiB per fragment) by direct global->LDS DMA, one group of
-// four 32-column tiles at a time, double buffered: the DMA of group g+1 is in flight while group
-// g is consumed (wave w stages tile w of the group).  Two workgroups per CU = two waves per SIMD,
-// so one wave's VALU epilogue runs under the other's MFMAs.
+// Workgroup = 8 waves, one per CU (152 KB of LDS), two waves per SIMD (256 VGPRs each):
+//   4 consumer waves, one per SIMD, 64 video rows each (two 32-row MFMA tiles, A operand resident in
+//     72 VGPRs).  A consumer is alone on its SIMD's matrix pipe and software-pipelines ITSELF: the
+//     threshold epilogue of the previous row tile (its own second accumulator set) and the LDS reads
+//     of the next column tile's fragments are interleaved between the 9 MFMAs of the current row tile;
+//   4 producer waves, one per SIMD, never touch the matrix pipe: they stage the streamed audio operand,
+//     shared by all consumers, in LDS in MFMA fragment order [buffer][tile][feature][step][lane]
+//     (1 KiB per fragment, conflict-free ds_read_b128) by direct global->LDS DMA (per-lane source =
+//     the unaligned run), patch the two norm slots and the per-column threshold, and publish a group
+//     of 8 column tiles per barrier; two LDS buffers: the DMA of group g+1 has all of group g's
+//     MFMA time (~4600 cycles) to land.
 // ------------------------------------------------------------------------------------------
-constexpr int kBfGroup = 4;                           // 32-column tiles per staged group
+constexpr int kBfGroup = 8;                           // 32-column tiles per staged group
 constexpr int kBfTileBytes = 9 * 1024;                // 3 features x 3 steps x 64 lanes x 16 B
 constexpr int kBfBufBytes = kBfGroup * kBfTileBytes;  // one group
-constexpr int kBfSurv = 128;                          // survivor staging slots per consumer wave
-constexpr int kBfConsumers = 8;                       // consumer waves per workgroup (32 video rows each)
-constexpr int kBfProducers = 4;                       // producer waves (one tile of every group each)
-constexpr int kBfBuffers = 3;                         // staged groups in LDS (producers run two groups ahead)
-#ifndef DA_BF_STAGGER
-#define DA_BF_STAGGER 0
-#endif
-constexpr int kBfStagger = DA_BF_STAGGER;             // x64 cycles of delay for the second consumer of each SIMD
+constexpr int kBfBuffers = 2;
+constexpr int kBfSurv = 256;                          // survivor staging slots per consumer wave (flushed when the next column tile could overflow it)
+constexpr int kBfConsumers = 4;                       // consumer waves per workgroup
+constexpr int kBfRowTiles = 2;                        // 32-row MFMA tiles per consumer
+constexpr int kBfProducers = 4;                       // producer waves (two tiles of every group each)
 constexpr int kBfThreads = 64 * (kBfConsumers + kBfProducers);
+constexpr int kBfRowsPerBlock = 32 * kBfRowTiles * kBfConsumers;
+constexpr int kBfSurvStride = kBfSurv + 64;           // + one scrap slot per lane (lanes without a survivor write there)
+constexpr int kBfSmem = kBfBuffers * kBfBufBytes + kBfConsumers * kBfSurvStride * 8 + kBfBuffers * kBfGroup * 32 * (4 + 4);
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -424,14 +429,73 @@ __device__ __forceinline__ void stage_tile_bf16(const MatchArgs& a, unsigned cha
 __device__ unsigned long long g_stamps[16];
 #endif
 
-// Warp-specialised: producer waves never touch the matrix pipe, consumer waves never issue DMA.
-// LDS: [3 buffers][4 tiles][9 KiB] operand fragments, per-column threshold / frame number, and
-// the consumers' survivor staging.  One workgroup per CU, three waves per SIMD.
-__global__ __launch_bounds__(kBfThreads, 3) void k_match_bf16(MatchArgs a) {
+// threshold epilogue of one accumulator row of a finished tile: three VALU instructions.
+// The three accumulator blocks of a tile are 16 registers apart, i.e. in the same VGPR bank for equal
+// row index g, and two operands from one bank cost the instruction an extra cycle.  Feature j's A
+// operand is therefore built with its rows rotated by j inside every group of four (bf_arow), so that
+// video row g's three values sit in registers g, g^+1, g^+2 (rotation inside the group of four): three
+// different banks.
+__device__ __forceinline__ constexpr int bf_rot(int g, int j) { return (g & ~3) | ((g + j) & 3); }
+// video row (0..31 within the MFMA tile) that lane r of feature j's A operand carries
+__device__ __forceinline__ int bf_arow(int r, int j) { return (r & ~3) | ((r - j) & 3); }
+__device__ __forceinline__ void bf_row(const f32x16 (&acc)[3], int g, float thr, uint32_t& mask) {
+  const float p = acc[0][g] * acc[1][bf_rot(g, 1)];
+  const float d = __builtin_fmaf(p, acc[2][bf_rot(g, 2)], -thr);    // < 0  <=>  a0 a1 a2 < thr |A|0 |A|1 |A|2
+  mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(d), 31);   // (mask << 1) | sign(d): rows fed 15..0
+}
+
+// Survivors of one finished tile, straight-line (no branch: it sits between two runs of MFMAs and
+// is scheduled into them): every lane with a non-zero row mask stages one record at the next free
+// slot of its wave's LDS buffer; the others write to their own scrap slot behind it.  The caller flushes
+// the buffer before it can overflow (bf_flush_if_needed).
+__device__ __forceinline__ void bf_emit(SurvSink& sk, int h, int64_t vtile, uint32_t mask, int32_t ic) {
+  const unsigned long long m = __ballot(mask != 0u);
+  if (m == 0ull) return;               // the wave is instruction-issue bound: ~4 in 10 tiles have no survivor at all
+  const int pos = sk.count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  // record = ic << 41 | vtile << 17 | h << 16 | mask, as two dwords (vtile < 2^24: its bits end at 40)
+  const uint32_t lo = mask | ((uint32_t)h << 16) | ((uint32_t)vtile << 17);
+  const uint32_t hi = ((uint32_t)ic << 9) | (uint32_t)(vtile >> 15);
+  if (mask != 0u) reinterpret_cast<uint2*>(sk.s_buf)[pos] = uint2{lo, hi};
+  sk.count += __popcll(m);
+}
+__device__ __forceinline__ void bf_flush_if_needed(SurvSink& sk, const MatchArgs& a, int lane) {
+  if (sk.count > kBfSurv - 128) sink_flush(sk, a, lane);          // a column tile (two row tiles) adds at most 128 records
+}
+
+// 9 MFMAs of one (32 video rows x 32 audio columns) tile into `acc`, with the epilogue of the
+// previously finished tile (`accp`, `thr_p`) -- and, when NEXT, the LDS reads of the next column
+// tile's fragments into the registers the MFMAs have just consumed -- interleaved between them.
+template <bool NEXT>
+__device__ __forceinline__ void bf_tile(const bf16x8 (&A)[3][3], bf16x8 (&frag)[3][3], f32x16 (&acc)[3],
+                                        const f32x16 (&accp)[3], float thr_p, uint32_t& mask_p,
+                                        const unsigned char* next_frags) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) acc[j] = f32x16{0};
+  int row = 15;
+#pragma unroll
+  for (int m = 0; m < 9; ++m) {
+    const int j = m / 3, s = m % 3;
+    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][s], frag[j][s], acc[j], 0, 0, 0);
+    if (NEXT) *reinterpret_cast<uint4*>(&frag[j][s]) = *reinterpret_cast<const uint4*>(next_frags + m * 1024);
+#ifndef DA_DBG_BF_NOEPI
+    const int nrows = m < 7 ? 2 : 1;                 // 16 rows over 9 MFMA slots
+#pragma unroll
+    for (int t = 0; t < nrows; ++t) { bf_row(accp, row, thr_p, mask_p); --row; }
+#endif
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
+    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);               // then up to six VALU
+    if (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // and one LDS read
+  }
+#ifdef DA_DBG_BF_NOEPI
+  asm volatile("" ::"v"(accp[0][0]), "v"(accp[1][7]), "v"(accp[2][15]), "v"(thr_p));
+#endif
+}
+
+__global__ __launch_bounds__(kBfThreads, 2) void k_match_bf16(MatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_b = smem;                                                        // [kBfBuffers][kBfGroup][9 KiB]
   unsigned long long* s_surv = reinterpret_cast<unsigned long long*>(smem + kBfBuffers * kBfBufBytes);     // [consumers][kBfSurv]
-  float* s_thr = reinterpret_cast<float*>(smem + kBfBuffers * kBfBufBytes + kBfConsumers * kBfSurv * 8);   // [kBfBuffers][kBfGroup][32]
+  float* s_thr = reinterpret_cast<float*>(smem + kBfBuffers * kBfBufBytes + kBfConsumers * kBfSurvStride * 8);   // [kBfBuffers][kBfGroup][32]
   int32_t* s_ic = reinterpret_cast<int32_t*>(s_thr + kBfBuffers * kBfGroup * 32);                           // [kBfBuffers][kBfGroup][32]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -441,65 +505,71 @@ __global__ __launch_bounds__(kBfThreads, 3) void k_match_bf16(MatchArgs a) {
   int64_t a_end = a_begin + (int64_t)a.audio_tiles_per_block * 32;
   if (a_end > a.n_a) a_end = a.n_a;
   if (a_begin >= a_end) return;                                           // uniform per block
-  const int64_t n_groups = (a_end - a_begin + 32 * kBfGroup - 1) / (32 * kBfGroup);
+  const int64_t n_tiles = (a_end - a_begin + 31) / 32;
+  const int64_t n_groups = (n_tiles + kBfGroup - 1) / kBfGroup;
   auto tile_pos = [&](int64_t g, int w) { return a_begin + (g * kBfGroup + w) * 32; };
 
   if (producer) {
     // ------------------------------------------------------------------ producer wave
-    // Stages tile `pw` of every group, two groups ahead of the consumers (three LDS buffers), so
-    // the DMA issued in one iteration has a whole iteration to land before it is waited for.
+    // Stages tiles pw and pw + 4 of every group, one group ahead of the consumers.
     const int pw = wave - kBfConsumers;
     auto fetch_patch = [&](int32_t ic, uint32_t (&pv)[3]) {
       if (h) { pv[0] = a.nrmpk_a[0][ic]; pv[1] = a.nrmpk_a[1][ic]; pv[2] = a.nrmpk_a[2][ic]; }
       else { pv[0] = __float_as_uint(a.prod_a[ic]); pv[1] = 0; pv[2] = 0; }
     };
-    int32_t ic0, ic1 = 0, ic2 = 0;                       // frame numbers of groups g, g+1, g+2
-    uint32_t pv0[3], pv1[3] = {0, 0, 0}, pv2[3] = {0, 0, 0};
-    ic0 = fetch_index(a, tile_pos(0, pw), a_end, r);
-    fetch_patch(ic0, pv0);
-    stage_tile_bf16(a, s_b + 0 * kBfBufBytes + pw * kBfTileBytes, ic0, h);
-    if (n_groups > 1) {
-      ic1 = fetch_index(a, tile_pos(1, pw), a_end, r);
-      fetch_patch(ic1, pv1);
-      stage_tile_bf16(a, s_b + 1 * kBfBufBytes + pw * kBfTileBytes, ic1, h);
+    int32_t ic_c[2], ic_n[2];                            // frame numbers: group being published / group in flight
+    uint32_t pv_c[2][3], pv_n[2][3];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      ic_c[u] = fetch_index(a, tile_pos(0, pw + 4 * u), a_end, r);
+      fetch_patch(ic_c[u], pv_c[u]);
+      stage_tile_bf16(a, s_b + (pw + 4 * u) * kBfTileBytes, ic_c[u], h);
+      ic_n[u] = fetch_index(a, tile_pos(1, pw + 4 * u), a_end, r);
     }
-    ic2 = fetch_index(a, tile_pos(2, pw), a_end, r);
     for (int64_t g = 0; g < n_groups; ++g) {
-      const int cur = (int)(g % kBfBuffers);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // DMA of group g (and g+1) has landed
-      {
-        unsigned char* tile = s_b + cur * kBfBufBytes + pw * kBfTileBytes;
+      const int cur = (int)(g & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of group g has landed
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int w = pw + 4 * u;
+        unsigned char* tile = s_b + cur * kBfBufBytes + w * kBfTileBytes;
         if (h) {
 #pragma unroll
           for (int j = 0; j < 3; ++j)
-            *reinterpret_cast<uint32_t*>(tile + (3 * j + 2) * 1024 + lane * 16 + 4) = pv0[j];
+            *reinterpret_cast<uint32_t*>(tile + (3 * j + 2) * 1024 + lane * 16 + 4) = pv_c[u][j];
         } else {
-          s_thr[(cur * kBfGroup + pw) * 32 + r] = ((tile_pos(g, pw) + r) < a_end) ? a.thr * __uint_as_float(pv0[0]) : -__builtin_inff();
-          s_ic[(cur * kBfGroup + pw) * 32 + r] = ic0;
+          s_thr[(cur * kBfGroup + w) * 32 + r] = ((tile_pos(g, w) + r) < a_end) ? a.thr * __uint_as_float(pv_c[u][0]) : -__builtin_inff();
+          s_ic[(cur * kBfGroup + w) * 32 + r] = ic_c[u];
         }
       }
-      __syncthreads();                           // group g published; buffer (g+2)%3 = (g-1)%3 is free again
-      if (g + 2 < n_groups) {
-        fetch_patch(ic2, pv2);
-        stage_tile_bf16(a, s_b + (int)((g + 2) % kBfBuffers) * kBfBufBytes + pw * kBfTileBytes, ic2, h);
+      __syncthreads();                           // group g published; the consumers have left buffer cur ^ 1
+      if (g + 1 < n_groups) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          fetch_patch(ic_n[u], pv_n[u]);
+          stage_tile_bf16(a, s_b + (cur ^ 1) * kBfBufBytes + (pw + 4 * u) * kBfTileBytes, ic_n[u], h);
+        }
       }
-      ic0 = ic1; pv0[0] = pv1[0]; pv0[1] = pv1[1]; pv0[2] = pv1[2];
-      ic1 = ic2; pv1[0] = pv2[0]; pv1[1] = pv2[1]; pv1[2] = pv2[2];
-      ic2 = fetch_index(a, tile_pos(g + 3, pw), a_end, r);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        ic_c[u] = ic_n[u]; pv_c[u][0] = pv_n[u][0]; pv_c[u][1] = pv_n[u][1]; pv_c[u][2] = pv_n[u][2];
+        ic_n[u] = fetch_index(a, tile_pos(g + 2, pw + 4 * u), a_end, r);
+      }
     }
     return;
   }
 
   // -------------------------------------------------------------------- consumer wave
-  const int64_t vt0 = ((int64_t)blockIdx.x * kBfConsumers + wave) * 32;   // this wave's 32 video rows
-  SurvSink sk{s_surv + wave * kBfSurv, 0, kBfSurv};
-  bf16x8 A[3][3];
-  {
-    const int64_t vr = vt0 + r;
-    const bool vok = vr < a.n_v;
-    const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
+  const int64_t vt0 = ((int64_t)blockIdx.x * kBfConsumers + wave) * (32 * kBfRowTiles);   // this wave's 64 video rows
+  SurvSink sk{s_surv + wave * kBfSurvStride, 0, kBfSurv};
+  bf16x8 A[kBfRowTiles][3][3];
+#pragma unroll
+  for (int rt = 0; rt < kBfRowTiles; ++rt) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
+      const int64_t vr = vt0 + 32 * rt + bf_arow(r, j);          // rows rotated per feature: see bf_row
+      const bool vok = vr < a.n_v;
+      const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
       const double sc = vok ? -(double)a.inv_v[j][v] : 0.0;
       const double* p = a.msd_v[j] + v;
 #pragma unroll
@@ -510,69 +580,107 @@ __global__ __launch_bounds__(kBfThreads, 3) void k_match_bf16(MatchArgs a) {
           uint16_t x = 0;
           if (k < kWin) x = f32_to_bf16((float)(p[k] * sc));
           else if (k == 42 || k == 43) x = 0x3F80;            // 1.0: the norm slots
-          A[j][s][e] = (short)x;
+          A[rt][j][s][e] = (short)x;
         }
     }
   }
-  const int64_t vtile = vt0 >> 5;
-  for (int64_t g = 0; g < n_groups; ++g) {
-    const int cur = (int)(g % kBfBuffers);
-    __syncthreads();                                               // group g is in buffer cur
-    // stagger: the two consumer waves of a SIMD (w and w+4) leave the barrier together and would
-    // run in lockstep -- both on the matrix pipe, then both in the epilogue.  Delaying one of them
-    // by about half an iteration lets one wave's epilogue run under the other's MFMAs.
-    if (kBfStagger > 0 && wave >= kBfConsumers / 2) __builtin_amdgcn_s_sleep(kBfStagger);     // measured: no effect (0, 3, 5, 8 x 64 cycles)
-    const unsigned char* gbase = s_b + cur * kBfBufBytes + lane * 16;
-    bf16x8 frag[3][3];
+  const int64_t vtile0 = vt0 >> 5;
+  // Software pipeline over "phases" (one row tile x one column tile = 9 MFMAs).  Phase order:
+  //   rt0(0) | rt1(0) rt0(1) | rt1(1) rt0(2) | ...      ( | = loop back-edge )
+  // Each phase's MFMAs carry, interleaved: the threshold epilogue of the PREVIOUS phase's accumulators
+  // (two accumulator sets), and -- in rt1 phases -- the LDS reads of the next column tile's fragments
+  // into the registers the MFMAs have just consumed; the survivor records of the phase before that
+  // are written at the start of the phase.  The loop is rotated so that its back-edge sits behind an
+  // rt0 phase: every LDS operation in flight there is at least nine MFMAs old, and the
+  // s_waitcnt lgkmcnt(0) the compiler places at a loop header costs nothing.
+  f32x16 accX[3], accY[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(&frag[j][s]) = *reinterpret_cast<const uint4*>(gbase + (3 * j + s) * 1024);
-    float thr_n = s_thr[(cur * kBfGroup + 0) * 32 + r];            // -inf: column past the end
-    int32_t ic_n = s_ic[(cur * kBfGroup + 0) * 32 + r];
-#pragma unroll 1
-    for (int w = 0; w < kBfGroup; ++w) {
-      if (tile_pos(g, w) >= a_end) break;
-      const float thr_c = thr_n;
-      const int32_t ic = ic_n;
-      f32x16 acc[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc[j] = f32x16{0};
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][s], frag[j][s], acc[j], 0, 0, 0);
-      if (w + 1 < kBfGroup) {                                      // next tile's fragments: latency hides under the epilogue
-        const unsigned char* nt = gbase + (w + 1) * kBfTileBytes;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(&frag[j][s]) = *reinterpret_cast<const uint4*>(nt + (3 * j + s) * 1024);
-        thr_n = s_thr[(cur * kBfGroup + w + 1) * 32 + r];
-        ic_n = s_ic[(cur * kBfGroup + w + 1) * 32 + r];
-      }
-      // rows 15..0: packed products for two rows at a time, then mask = 2*mask + (prod <= thr)
-      // as one compare + one add-with-carry per row (row q ends at bit q)
-      uint32_t mask = 0;
-#ifdef DA_DBG_BF_NOEPI
-      asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][7]), "v"(acc[2][15]), "v"(thr_c), "v"(ic));
+  for (int j = 0; j < 3; ++j) accY[j] = f32x16{0};
+  float thr_y = -__builtin_inff();                     // threshold row for accY's columns; -inf: nothing owed, no row passes
+  int32_t ic_y = 0;
+  uint32_t pend_mask = 0; int32_t pend_ic = 0; int pend_rt = 0;      // finished epilogue whose records are not staged yet
+  bf16x8 frag[3][3];
+#ifdef DA_DBG_STAMPS
+  unsigned long long st_acc[4] = {0, 0, 0, 0};
+  unsigned long long st_t = __builtin_amdgcn_s_memtime();
+#define BF_STAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t; st_t = t_; }
 #else
-#pragma unroll
-      for (int q = 14; q >= 0; q -= 2) {
-        const f32x2 x0 = {acc[0][q], acc[0][q + 1]};
-        const f32x2 x1 = {acc[1][q], acc[1][q + 1]};
-        const f32x2 x2 = {acc[2][q], acc[2][q + 1]};
-        const f32x2 pr = x0 * x1 * x2;
-        asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[1]), "v"(thr_c) : "vcc");
-        asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[0]), "v"(thr_c) : "vcc");
-      }
+#define BF_STAMP(k)
 #endif
+  for (int64_t g = 0; g < n_groups; ++g) {
+    const int cur = (int)(g & 1);
+    BF_STAMP(0)                                                    // phases of the previous group
+    __syncthreads();                                               // group g is in buffer cur
+    BF_STAMP(1)                                                    // barrier wait
+    const unsigned char* gbase = s_b + cur * kBfBufBytes + lane * 16;
+#pragma unroll
+    for (int m = 0; m < 9; ++m) *reinterpret_cast<uint4*>(&frag[m / 3][m % 3]) = *reinterpret_cast<const uint4*>(gbase + m * 1024);
+#ifdef DA_DBG_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BF_STAMP(2)                                                    // exposed fragment load
+#endif
+    int64_t left = n_tiles - g * kBfGroup;                         // column tiles of this group
+    if (left > kBfGroup) left = kBfGroup;
+    float thr_x = s_thr[(cur * kBfGroup) * 32 + r];                // -inf: column past the end
+    int32_t ic_x = s_ic[(cur * kBfGroup) * 32 + r];
+    auto stage_pending = [&]() {
 #ifndef DA_DBG_BF_NOEMIT
-      emit_tile(sk, a, lane, h, vtile, mask, ic);
+      bf_emit(sk, h, vtile0 + pend_rt, pend_mask, pend_ic);
 #else
-      asm volatile("" ::"v"(mask));
+      asm volatile("" ::"v"(pend_mask));
+#endif
+    };
+    // rt0 of the group's first column tile; owed: rt1 of the previous group's last column tile
+    {
+      stage_pending();
+      uint32_t mask = 0;
+      bf_tile<false>(A[0], frag, accX, accY, thr_y, mask, nullptr);
+      pend_mask = mask; pend_ic = ic_y; pend_rt = 1;
+    }
+#pragma unroll 1
+    for (int w = 0; w + 1 < (int)left; ++w) {
+      // rt1(w): epilogue of rt0(w); fragments of column tile w + 1 stream in
+      stage_pending();
+      uint32_t mask = 0;
+      bf_tile<true>(A[1], frag, accY, accX, thr_x, mask, gbase + (w + 1) * kBfTileBytes);
+      pend_mask = mask; pend_ic = ic_x; pend_rt = 0;
+      thr_y = thr_x; ic_y = ic_x;
+      thr_x = s_thr[(cur * kBfGroup + w + 1) * 32 + r];
+      ic_x = s_ic[(cur * kBfGroup + w + 1) * 32 + r];
+      // rt0(w + 1): epilogue of rt1(w)
+      stage_pending();
+      mask = 0;
+      bf_tile<false>(A[0], frag, accX, accY, thr_y, mask, nullptr);
+      pend_mask = mask; pend_ic = ic_y; pend_rt = 1;
+#ifndef DA_DBG_BF_NOEMIT
+      bf_flush_if_needed(sk, a, lane);
 #endif
     }
+    // rt1 of the group's last column tile (the next fragments come from the other buffer, after the barrier)
+    {
+      stage_pending();
+      uint32_t mask = 0;
+      bf_tile<false>(A[1], frag, accY, accX, thr_x, mask, nullptr);
+      pend_mask = mask; pend_ic = ic_x; pend_rt = 0;
+      thr_y = thr_x; ic_y = ic_x;
+#ifndef DA_DBG_BF_NOEMIT
+      bf_flush_if_needed(sk, a, lane);
+#endif
+    }
+  }
+#ifdef DA_DBG_STAMPS
+  BF_STAMP(0)
+  if (wave == 0 && lane == 0) {
+    for (int t = 0; t < 3; ++t) atomicAdd(&g_stamps[t], st_acc[t]);
+    atomicAdd(&g_stamps[3], (unsigned long long)(n_tiles * 2));    // phases executed
+  }
+#endif
+  {                                                                // drain: staged record of rt0, epilogue + record of the last rt1
+    bf_emit(sk, h, vtile0 + pend_rt, pend_mask, pend_ic);
+    uint32_t mask = 0;
+#pragma unroll
+    for (int g = 15; g >= 0; --g) bf_row(accY, g, thr_y, mask);
+    bf_emit(sk, h, vtile0 + 1, mask, ic_y);
   }
   sink_flush(sk, a, lane);
 }
@@ -600,14 +708,12 @@ void launch_match_f32(const MatchArgs& a, hipStream_t s) {
 }
 void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   if (a.n_v <= 0 || a.n_a <= 0) return;
-  const int smem = kBfBuffers * kBfBufBytes + kBfConsumers * kBfSurv * 8 + kBfBuffers * kBfGroup * 32 * (4 + 4);
   // per launch: the attribute is per device and contexts on several devices / threads share this code
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  const int64_t rows_per_block = 32 * kBfConsumers;
-  const int64_t bx = (a.n_v + rows_per_block - 1) / rows_per_block;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, kBfSmem);
+  const int64_t bx = (a.n_v + kBfRowsPerBlock - 1) / kBfRowsPerBlock;
   const int64_t atiles = (a.n_a + 31) / 32;
   const int64_t by = (atiles + a.audio_tiles_per_block - 1) / a.audio_tiles_per_block;
-  hipLaunchKernelGGL(k_match_bf16, dim3((unsigned)bx, (unsigned)by), dim3(kBfThreads), smem, s, a);
+  hipLaunchKernelGGL(k_match_bf16, dim3((unsigned)bx, (unsigned)by), dim3(kBfThreads), kBfSmem, s, a);
 }
 
 // diagnostics: the correlations exactly as the GEMM precision forms them, for explicit pairs.

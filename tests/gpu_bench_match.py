@@ -6,9 +6,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden
 from describealign_amd import _native, synth
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 1320.0
 ch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only = sys.argv[3] if len(sys.argv) > 3 else None          # "f32" / "bf16": just that precision
 pair = synth.make_pair(5, secs, n_jumps=10, first_gap=200.0, channels=ch)
 ref = None
 for prec, name, peak in ((_native.PREC_F32, "f32", 157.3), (_native.PREC_BF16, "bf16", 2500.0)):
+  if only and name != only:
+    continue
   c = _native.Context(0, prec)
   c.pcm_upload(0, pair.video); c.pcm_upload(1, pair.audio)
   fts = []
