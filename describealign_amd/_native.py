@@ -27,7 +27,7 @@ ERR_MISMATCH = -4
 
 EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm_upload",
            "da_features_resident", "da_features", "da_match", "da_match_begin", "da_match_finish", "da_match_fetch",
-           "da_match_corr", "da_chain", "da_chain_begin", "da_chain_finish", "da_chain_resident", "da_chain_poll",
+           "da_match_corr", "da_match_dump_tile", "da_chain", "da_chain_begin", "da_chain_finish", "da_chain_resident", "da_chain_poll",
            "da_refine", "da_stats", "da_replace_segments", "da_stretch_resident", "da_stretch_schedule"]
 
 
@@ -87,6 +87,7 @@ def load():
     lib.da_match_finish.argtypes = [vp, P(i64)]
     lib.da_match_fetch.argtypes = [vp, vp, vp, vp, i64]
     lib.da_match_corr.argtypes = [vp, vp, vp, i64, vp]
+    lib.da_match_dump_tile.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.da_chain.argtypes = [vp, vp, vp, vp, i64, C.c_double, vp, vp, P(i64)]
     lib.da_chain_begin.argtypes = [vp, P(C.c_uint64)]
     lib.da_chain_finish.argtypes = [vp, C.c_uint64, C.c_double, vp, vp, P(i64)]
@@ -269,6 +270,14 @@ class Context:
     out = np.empty((len(i), 3), dtype=np.float32)
     self._check(self._lib.da_match_corr(self._h, _ptr(i), _ptr(v), len(i), _ptr(out)))
     return out
+
+  def match_dump_tile(self, video_tile: int, audio_tile: int):
+    """Raw MFMA accumulators |A|_j (1 - corr_j) of one 32 x 32 tile of the last match:
+    (acc[3, 32 rows, 32 cols] float32, video_frames[32], audio_frames[32])."""
+    acc = np.empty((3, 32, 32), dtype=np.float32)
+    vfr = np.empty(32, dtype=np.int32); afr = np.empty(32, dtype=np.int32)
+    self._check(self._lib.da_match_dump_tile(self._h, int(video_tile), int(audio_tile), _ptr(acc), _ptr(vfr), _ptr(afr)))
+    return acc, vfr, afr
 
   def chain(self, i, v, q, min_len: float = 0.0):
     """Heaviest non-decreasing chain -- describealign.py:654-698.  Returns (path_i, path_v)."""

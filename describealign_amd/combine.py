@@ -355,7 +355,10 @@ def _worker(gpu, indices, pairs, kwargs, precision, n_workers=1):
     # processes split the host's cores between them instead of all pinning to the same ones
     os.environ["LOCAL_WORLD_SIZE"] = str(n_workers)
     os.environ["LOCAL_RANK"] = str(gpu)
-  ctx = _native.Context(gpu, precision)
+  # DALIGN_DEVICE_OVERRIDE=<id>: every worker uses that device (exercising the sharded path on a box
+  # with fewer GPUs than workers)
+  dev = int(os.environ["DALIGN_DEVICE_OVERRIDE"]) if os.environ.get("DALIGN_DEVICE_OVERRIDE") else gpu
+  ctx = _native.Context(dev, precision)
   todo = [pairs[k] for k in indices]
   if len(todo) >= 3:
     process_batch(todo, ctx, prepend=kwargs["prepend"], no_pitch_correction=kwargs["no_pitch_correction"],

@@ -592,6 +592,26 @@ extern "C" int da_match_corr(da_ctx* c, const int32_t* pi, const int32_t* pv, in
   return DA_OK;
 }
 
+extern "C" int da_match_dump_tile(da_ctx* c, int64_t video_tile, int64_t audio_tile, float* acc, int32_t* video_frames,
+                                  int32_t* audio_frames) {
+  if (!c) return DA_ERR_ARG;
+  if (!c->match_ready) return fail(c, DA_ERR_STATE, "da_match_dump_tile: call da_match first");
+  const MatchArgs& m = c->last_match;
+  if (!acc || !video_frames || !audio_frames || video_tile < 0 || audio_tile < 0 || video_tile * 32 >= m.n_v || audio_tile * 32 >= m.n_a)
+    return fail(c, DA_ERR_ARG, "da_match_dump_tile: tile (%lld, %lld) outside the %lld x %lld row lists", (long long)video_tile,
+                (long long)audio_tile, (long long)((m.n_v + 31) / 32), (long long)((m.n_a + 31) / 32));
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, c->pair_c.ensure(sizeof(float) * 3 * 32 * 32)); HIP_TRY(c, c->pair_i.ensure(sizeof(int32_t) * 64));
+  launch_dump_tile(m, video_tile, audio_tile, c->precision == DA_PREC_BF16, c->pair_c.as<float>(), c->pair_i.as<int32_t>(),
+                   c->pair_i.as<int32_t>() + 32, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(acc, c->pair_c.p, sizeof(float) * 3 * 32 * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(video_frames, c->pair_i.p, sizeof(int32_t) * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(audio_frames, c->pair_i.as<int32_t>() + 32, sizeof(int32_t) * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return DA_OK;
+}
+
 // ------------------------------------------------------------------------------------- chain DP
 // Heaviest chain non-decreasing in both coordinates (describealign.py:654-656, :674-697).  With a
 // context it runs on the device (dalign_chain.hip); with a NULL context the host utility below is

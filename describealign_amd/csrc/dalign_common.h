@@ -83,6 +83,9 @@ struct CorrArgs {   // diagnostics: GEMM-precision correlations for explicit pai
   MatchArgs m; const int32_t* pi; const int32_t* pv; int64_t n; float* corr; int precision;
 };
 void launch_corr(const CorrArgs& a, hipStream_t s);
+// raw MFMA accumulators of one 32 x 32 tile: out [3][32 rows][32 cols], the frames of its rows / columns (-1 = past the end)
+void launch_dump_tile(const MatchArgs& a, int64_t vtile, int64_t atile, int bf16, float* d_out, int32_t* d_vframes, int32_t* d_aframes,
+                      hipStream_t s);
 
 // ---- exact verification --------------------------------------------------------------------
 struct VerifyArgs {

@@ -716,6 +716,87 @@ void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_match_bf16, dim3((unsigned)bx, (unsigned)by), dim3(kBfThreads), kBfSmem, s, a);
 }
 
+// diagnostics: the raw MFMA accumulators of ONE (32 video rows x 32 audio columns) tile, formed with
+// the production kernels' own operand construction and instruction sequence (K permutation, norm
+// slots, bf16 rounding, per-feature row rotation): out[j][row][col] = |A|_j(col) (1 - corr_j(row, col)).
+// One wavefront.  The matrix instructions are deterministic, so these are the values the threshold
+// epilogue of k_match_f32 / k_match_bf16 sees for that tile.
+__global__ __launch_bounds__(64) void k_dump_tile(MatchArgs a, int64_t vtile, int64_t atile, int bf16, float* __restrict__ out,
+                                                  int32_t* __restrict__ vframes, int32_t* __restrict__ aframes) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t at = atile * 32;
+  const int32_t ic = fetch_index(a, at, a.n_a, r);
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) acc[j] = f32x16{0};
+  if (!bf16) {
+    const int64_t vr = vtile * 32 + r;
+    const bool vok = vr < a.n_v;
+    const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
+    float A[3][21], b[3][21];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float sc = vok ? -a.inv_v[j][v] : 0.f;
+      const float* p = a.ms_v[j] + v + 21 * h;
+#pragma unroll
+      for (int s = 0; s < 21; ++s) A[j][s] = (21 * h + s < kWin) ? p[s] * sc : 1.0f;
+    }
+    TileMeta m;
+    load_tile_b(a, at, a.n_a, r, h, ic, b, m);
+#pragma unroll
+    for (int s = 0; s < 21; ++s)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j][s], b[j][s], acc[j], 0, 0, 0);
+    if (h == 0) { vframes[r] = vok ? v : -1; aframes[r] = (at + r) < a.n_a ? ic : -1; }
+  } else {
+    bf16x8 A[3][3], B[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int64_t vr = vtile * 32 + bf_arow(r, j);
+      const bool vok = vr < a.n_v;
+      const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
+      const double sc = vok ? -(double)a.inv_v[j][v] : 0.0;
+      const double* p = a.msd_v[j] + v;
+      const uint32_t pk = a.nrmpk_a[j][ic];
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 24 * h + 8 * s + e;
+          uint16_t x = 0;
+          if (k < kWin) x = f32_to_bf16((float)(p[k] * sc));
+          else if (k == 42 || k == 43) x = 0x3F80;
+          A[j][s][e] = (short)x;
+          uint16_t y = a.bfa_even[j][ic + k];                         // what the LDS-DMA stages (either copy holds the same values)
+          if (k == 42) y = (uint16_t)(pk & 0xFFFFu);                  // the producers' norm patch: hi, lo halves of |A|
+          if (k == 43) y = (uint16_t)(pk >> 16);
+          B[j][s][e] = (short)y;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][s], B[j][s], acc[j], 0, 0, 0);
+    if (h == 0) {
+      const int64_t vr = vtile * 32 + r;
+      vframes[r] = vr < a.n_v ? a.vlist[vr] : -1;
+      aframes[r] = (at + r) < a.n_a ? ic : -1;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      out[(j * 32 + row) * 32 + r] = bf16 ? acc[j][bf_rot(g, j)] : acc[j][g];
+  }
+}
+void launch_dump_tile(const MatchArgs& a, int64_t vtile, int64_t atile, int bf16, float* d_out, int32_t* d_vframes, int32_t* d_aframes,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(k_dump_tile, dim3(1), dim3(64), 0, s, a, vtile, atile, bf16, d_out, d_vframes, d_aframes);
+}
+
 // diagnostics: the correlations exactly as the GEMM precision forms them, for explicit pairs.
 // One wave per 32 pairs would be the MFMA way; this path is test-only, so it uses plain FMAs on
 // identically rounded operands (f32: same k-ordered fmaf chain as the MFMA; bf16: same rounding

@@ -99,6 +99,16 @@ int da_match_fetch(da_ctx* ctx, int32_t* out_i, int32_t* out_v, double* out_q, i
  * corr receives [n][3].  Uses the feature rows of the last da_match call. */
 int da_match_corr(da_ctx* ctx, const int32_t* i, const int32_t* v, int64_t n, float* corr);
 
+/* The raw matrix-core accumulators of the similarity GEMM for ONE tile of 32 video rows x 32 audio
+ * columns of the last da_match (tile indices into its row lists: every 4th non-quiet video frame,
+ * the non-quiet audio frames), formed with the production kernel's own operand construction and
+ * MFMA sequence in the context's precision: acc[j][row][col] = |A|_j(col) (1 - corr_j(row, col)),
+ * j = 0..2, i.e. exactly what the threshold epilogue tests.  video_frames[32] / audio_frames[32]
+ * receive the frame numbers of the rows / columns (-1 past the end of a list).  Testing /
+ * diagnostics ("similarity values within 1e-3 relative", north_star). */
+int da_match_dump_tile(da_ctx* ctx, int64_t video_tile, int64_t audio_tile, float* acc, int32_t* video_frames,
+                       int32_t* audio_frames);
+
 /* ---- stage 2 DP: heaviest chain -------------------------------------------------------------
  * describealign.py:654-656, :674-698: heaviest chain non-decreasing in both coordinates over
  * matches sorted by (i, v).  *n_path in: capacity, out: length.  min_len = the reference's
