@@ -16,10 +16,13 @@ Workloads (BASELINE.json configs):
   cfg1  configs[1] stand-in: 1320 s video / ~1558 s AD, 10 jumps + 200 s intro, mono, fp32 GEMM
         (reported as the `secondary` object of the same JSON line at N = 1)
 
-Timed region (steady state of a directory batch).  The pairs go through ONE primed pipeline:
-W warm-up pairs, K timed pairs and a tail that keeps the pipeline full are submitted as one
-stream; results come back in order; the clock runs from the arrival of result W (the last
-warm-up result; the start of the run when W = 0) to the arrival of result W + K.  A barrier and a
+Timed region (steady state of a directory batch).  The pairs go through ONE primed pipeline: an
+untimed lead-in of max(W, two LP solves per host worker) pairs, K timed pairs and a tail that keeps
+the pipeline full are submitted as one stream; results come back in order; the clock runs from the
+arrival of the last lead-in result to the arrival of the K-th result after it.  (The lead-in is
+longer than --warmup because a pair spends ~9 s in the host LP but only ~0.3 s on the GPU: the first
+results of a fresh pipeline come out in a burst at the GPU stage's rate, before the LP stage has had
+to sustain anything; `--prime 0` disables it.)  A barrier and a
 device synchronisation bracket the run of the stream (before the first job is submitted, after the
 last result); inside it the K timed results are complete on the host when the clock stops, so no
 work of the timed steps is left out -- what is NOT waited for at that instant is the in-flight
@@ -85,6 +88,7 @@ def cpu_baseline(channels, workload_seconds, sample_seconds=None):
 class Bench:
   def __init__(self, args, grp, device):
     self.args, self.grp, self.device = args, grp, device
+    self.pairs = {}
 
   def sync(self):
     import torch
@@ -92,7 +96,7 @@ class Bench:
     self.grp.barrier()
     torch.cuda.synchronize()
 
-  def run(self, workload, steps, warmup, with_cpu_baseline, with_stretch):
+  def run(self, workload, steps, warmup, with_cpu_baseline, with_stretch, include_h2d=False, quick=False):
     import contextlib, io, threading
     from describealign_amd import _native, synth
     from describealign_amd import align as A
@@ -106,26 +110,44 @@ class Bench:
       workers = A.default_worker_count(int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     ctx = _native.Context(self.device, prec)
     # every rank aligns its own pair (seed differs per rank): a sharded directory batch
-    pair = synth.make_pair(5 + rank, wl["seconds"], n_jumps=wl["n_jumps"], first_gap=wl["first_gap"], channels=wl["channels"])
+    if workload not in self.pairs:
+      self.pairs[workload] = synth.make_pair(5 + rank, wl["seconds"], n_jumps=wl["n_jumps"], first_gap=wl["first_gap"], channels=wl["channels"])
+    pair = self.pairs[workload]
     gpu_ctxs = [ctx] + [_native.Context(self.device, prec) for _ in range(max(1, args.gpu_streams) - 1 if workers > 0 else 0)]
+    include_h2d = include_h2d or args.include_h2d
     for c in gpu_ctxs:                       # the PCM is resident in HBM before anything is timed
-      c.pcm_upload(_native.SIDE_VIDEO, pair.video)
-      c.pcm_upload(_native.SIDE_AUDIO, pair.audio)
+      if include_h2d:
+        # PCIe-inclusive mode: the PCM sits in page-locked host memory, where a decoder would have
+        # written it (da_host_alloc); every step re-uploads it asynchronously (da_pcm_upload_async)
+        if not hasattr(self, "pinned"):
+          self.pinned = {}
+        if workload not in self.pinned:
+          pv = _native.pinned_empty(pair.video.shape); pv[...] = pair.video
+          pa = _native.pinned_empty(pair.audio.shape); pa[...] = pair.audio
+          self.pinned[workload] = (pv, pa)
+        c.pcm_upload_async(_native.SIDE_VIDEO, self.pinned[workload][0])
+        c.pcm_upload_async(_native.SIDE_AUDIO, self.pinned[workload][1])
+      else:
+        c.pcm_upload(_native.SIDE_VIDEO, pair.video)
+        c.pcm_upload(_native.SIDE_AUDIO, pair.audio)
     h2d_ms = ctx.stats()["h2d_ms"]
+    h2d_acc = []
     feat = {}
     lock = threading.Lock()
 
     def make_job(idx):
       def job(c):
-        if args.include_h2d:
-          c.pcm_upload(_native.SIDE_VIDEO, pair.video)
-          c.pcm_upload(_native.SIDE_AUDIO, pair.audio)
+        if include_h2d:
+          c.pcm_upload_async(_native.SIDE_VIDEO, self.pinned[workload][0])
+          c.pcm_upload_async(_native.SIDE_AUDIO, self.pinned[workload][1])
         vf = c.features_resident(_native.SIDE_VIDEO)
         s_v = c.stats()
         af = c.features_resident(_native.SIDE_AUDIO)
         s_a = c.stats()
         with lock:
           feat[idx] = (s_v["features_ms"] + s_a["features_ms"], s_v["features_bytes"] + s_a["features_bytes"])
+          if include_h2d:
+            h2d_acc.append(s_v["h2d_ms"] + s_a["h2d_ms"])
         return vf, af
       return job
 
@@ -134,6 +156,15 @@ class Bench:
     # tail: pairs submitted behind the timed ones so that the stages are still all busy when the
     # clock stops; once fewer than `workers` pairs are left the LP stage starts to drain
     tail = 0 if workers <= 0 else (args.tail if args.tail >= 0 else min(workers, 8 if wl["seconds"] > 3000 else workers))
+    # Priming.  A pair spends seconds in the host LP stage (2 h pair: ~9 s), far longer than the
+    # 0.3 s between pairs, so the first results of a fresh pipeline arrive in a burst at the GPU
+    # stage's rate: every worker is still on its FIRST solve and the LP stage has not yet had to
+    # keep up.  The untimed lead-in is therefore at least `prime` pairs (two solves per worker by
+    # default), so that the timed pairs see the rate a long directory batch sustains.
+    declared_warmup = warmup
+    if workers > 0:
+      prime = args.prime if args.prime >= 0 else (2 * workers if not quick else workers // 2)
+      warmup = max(warmup, prime)
     total = warmup + steps + tail
     pipe = None
     if workers > 0:
@@ -204,7 +235,7 @@ class Bench:
       peak = PEAK_TFLOPS[prec_name]
       res = {
         "metric": "aligned audio-hours/sec", "value": value, "unit": "audio-hours/s", "n_gpus": world,
-        "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "steps": steps, "warmup": declared_warmup, "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if prec_name == "f32" else "bf16", "data": "synthetic",
         "config": {"workload": wl["desc"] + f", {prec_name} similarity GEMM", "pairs_per_rank_per_step": 1,
@@ -212,7 +243,7 @@ class Bench:
                    "channels": wl["channels"], "parallelism": f"pairs sharded over {world} GPU(s), no collectives"},
         "realtime_factor": wl["seconds"] * world * steps / elapsed,
         "timed_region": {"kind": "steady state of one primed pipeline" if pipe is not None else "sequential align() calls",
-                         "pairs_streamed": total, "tail_pairs": tail,
+                         "pairs_streamed": total, "untimed_lead_in_pairs": warmup, "tail_pairs": tail,
                          "whole_stream_s": round(t_end - t_start, 2), "timed_s": round(elapsed, 3)},
         "single_pair_latency_s": round(acc["align_s"] / k, 3),
         "single_pair_realtime_factor": round(wl["seconds"] / (acc["align_s"] / k), 1),
@@ -234,8 +265,9 @@ class Bench:
         "counts": {"gemm_pairs": acc["gemm_pairs"] / k, "survivors": acc["survivors"] / k, "matches": acc["matches"] / k,
                    "path_points": acc["n_path1"] / k, "lp_fit_points": acc["n_fit_points"] / k},
         "max_offset_err_vs_injected_ms": round(inj_err_ms, 3),
-        "pcm_resident_in_hbm": not args.include_h2d,
+        "pcm_resident_in_hbm": not include_h2d,
         "pcm_h2d_ms_audio_side": round(h2d_ms, 2),
+        "pcm_h2d_ms_per_step": round(sum(h2d_acc) / max(1, len(h2d_acc)), 2) if include_h2d else None,
       }
       # HBM traffic of the dominant kernel from the committed PMC profile of this workload (PMC
       # collection needs its own rocprofv3 passes; bench.py itself only times with HIP events)
@@ -291,11 +323,14 @@ def main():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=24, help="pairs in the timed region")
   ap.add_argument("--warmup", type=int, default=6, help="pairs streamed through the pipeline before the clock starts")
+  ap.add_argument("--prime", type=int, default=-1,
+                  help="minimum untimed lead-in pairs before the clock starts (-1: two LP solves per worker process; 0: just --warmup)")
   ap.add_argument("--tail", type=int, default=-1, help="pairs submitted behind the timed ones (-1: enough to keep the host stage full)")
   ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
   ap.add_argument("--precision", default=None, choices=["f32", "bf16"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-sample-seconds", type=float, default=None)
+  ap.add_argument("--no-pcie", action="store_true", help="skip the short PCIe-inclusive measurement reported as `pcie_inclusive`")
   ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] measurement reported as `secondary`")
   ap.add_argument("--include-h2d", action="store_true",
                   help="diagnostic: re-upload the PCM over PCIe inside every step (the PCIe-inclusive rate; never the headline value)")
@@ -316,6 +351,14 @@ def main():
   b = Bench(args, grp, device)
   single = grp.world == 1
   res = b.run(args.workload, args.steps, args.warmup, with_cpu_baseline=single and not args.no_cpu_baseline, with_stretch=True)
+  if single and not args.include_h2d and not args.no_pcie and res is not None:
+    # the same workload with the PCM re-uploaded from page-locked host memory in every step: never the headline value
+    px = b.run(args.workload, max(6, args.steps // 2), 4, with_cpu_baseline=False, with_stretch=False, include_h2d=True, quick=True)
+    res["pcie_inclusive"] = {"value": px["value"], "unit": px["unit"], "steps": px["steps"], "warmup": px["warmup"],
+                             "ms_per_step": px["ms_per_step"], "h2d_ms_per_step": px["pcm_h2d_ms_per_step"],
+                             "h2d_bytes_per_step": int(2 * sum(a.size for a in (b.pairs[args.workload].video, b.pairs[args.workload].audio))),
+                             "note": "PCM in page-locked host memory (da_host_alloc), uploaded asynchronously on the copy stream "
+                                     "(da_pcm_upload_async) in every step; value = whole-step rate including that transfer"}
   if single and args.workload == "cfg2" and not args.no_secondary and args.precision is None:
     sec = b.run("cfg1", max(args.steps, 64), max(args.warmup, 8), with_cpu_baseline=False, with_stretch=False)
     if res is not None and sec is not None:

@@ -25,7 +25,7 @@ MATCH_RESIDENT_ROWS = 0x100
 ERR_CAPACITY = -3
 ERR_MISMATCH = -4
 
-EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm_upload",
+EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm_upload", "da_pcm_upload_async", "da_host_alloc", "da_host_free",
            "da_features_resident", "da_features", "da_match", "da_match_begin", "da_match_finish", "da_match_fetch",
            "da_match_corr", "da_match_dump_tile", "da_chain", "da_chain_begin", "da_chain_finish", "da_chain_resident", "da_chain_poll",
            "da_refine", "da_stats", "da_replace_segments", "da_stretch_resident", "da_stretch_schedule"]
@@ -80,6 +80,9 @@ def load():
     lib.da_destroy.argtypes = [vp]; lib.da_destroy.restype = None
     lib.da_last_error.argtypes = [vp]; lib.da_last_error.restype = C.c_char_p
     lib.da_pcm_upload.argtypes = [vp, i32, vp, i64, i32, i32]
+    lib.da_pcm_upload_async.argtypes = [vp, i32, vp, i64, i32, i32]
+    lib.da_host_alloc.argtypes = [C.c_size_t, P(vp)]
+    lib.da_host_free.argtypes = [vp]
     lib.da_features_resident.argtypes = [vp, i32, vp, i64, P(i64)]
     lib.da_features.argtypes = [vp, vp, i64, i32, i32, vp, i64, P(i64)]
     lib.da_match.argtypes = [vp, vp, i64, P(i64), vp, i64, P(i64), i32, i64, i64, vp, vp, vp, P(i64)]
@@ -106,6 +109,34 @@ def load():
 
 def _ptr(a: np.ndarray):
   return a.ctypes.data_as(C.c_void_p)
+
+
+class _Pinned:
+  """Owner of one page-locked allocation; freed when the last array viewing it is collected."""
+
+  def __init__(self, nbytes):
+    self._lib = load()
+    self.ptr = C.c_void_p()
+    if self._lib.da_host_alloc(int(nbytes), C.byref(self.ptr)) != 0 or not self.ptr:
+      raise MemoryError(f"da_host_alloc({nbytes}) failed")
+
+  def __del__(self):
+    try:
+      if self.ptr:
+        self._lib.da_host_free(self.ptr)
+        self.ptr = C.c_void_p()
+    except Exception:
+      pass
+
+
+def pinned_empty(shape, dtype=np.int16) -> np.ndarray:
+  """A page-locked numpy array (da_host_alloc): the buffer a decoder fills for pcm_upload_async."""
+  count = int(np.prod(shape))
+  nbytes = max(1, count * np.dtype(dtype).itemsize)
+  owner = _Pinned(nbytes)
+  buf = (C.c_uint8 * nbytes).from_address(owner.ptr.value)
+  buf._owner = owner                     # every numpy view keeps `buf` (its base) alive, and `buf` the allocation
+  return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
 
 def chain_host(i, v, q, min_len: float = 0.0):
@@ -139,6 +170,7 @@ class Context:
     self._n = {}
     self._channels = {}
     self._rows = {}
+    self._inflight = {}
 
   def close(self):
     if getattr(self, "_h", None) is not None and self._h:
@@ -184,16 +216,40 @@ class Context:
     self._rows.pop(side, None)
     return n, channels
 
+  def pcm_upload_async(self, side: int, pcm: np.ndarray):
+    """Enqueue the host->device copy of `pcm` (int16 (C, N) or (N, C), ideally page-locked: see
+    pinned_empty) and return at once; the side's next features_resident waits for it on the device.
+    `pcm` must stay alive and unchanged until that call has returned (a reference is kept here)."""
+    pcm = np.asarray(pcm)
+    if pcm.dtype != np.int16 or pcm.ndim != 2 or not pcm.flags.c_contiguous:
+      raise ValueError("PCM must be a C-contiguous 2-D int16 array")
+    planar = 1
+    if pcm.shape[0] in (1, 2):
+      channels, n = pcm.shape
+    elif pcm.shape[1] in (1, 2):
+      n, channels = pcm.shape
+      planar = 0
+    else:
+      raise ValueError("PCM must have 1 or 2 channels")
+    self._check(self._lib.da_pcm_upload_async(self._h, side, _ptr(pcm), n, channels, planar))
+    self._inflight[side] = pcm
+    self._n[side] = n
+    self._channels[side] = channels
+    self._rows.pop(side, None)
+    return n, channels
+
   def features_resident(self, side: int, download: bool = True):
     """Run the fused feature kernel on the PCM already resident for `side`.
     Returns the five rows (describealign.py:1101-1104) as float32 arrays, or None."""
     lengths = (C.c_int64 * 2)()
     if not download:
       self._check(self._lib.da_features_resident(self._h, side, None, 0, lengths))
+      self._inflight.pop(side, None)
       return None
     le = ((self._n[side] // 105) + 1) // 2
     out = np.empty((5, max(le, 1)), dtype=np.float32)
     self._check(self._lib.da_features_resident(self._h, side, _ptr(out), out.shape[1], lengths))
+    self._inflight.pop(side, None)               # the asynchronous upload (if any) has been consumed
     le, lo = lengths[0], lengths[1]
     self._rows[side] = (out, le, lo)           # match_begin recognises these rows and skips their upload
     return [out[0, :le]] + [out[k, :lo] for k in range(1, 5)]      # row views of one buffer

@@ -260,6 +260,37 @@ def process_pair(video_file, audio_desc_file, has_audio_extension, ctx, stretch_
                       no_pitch_correction, alignment_dir)
 
 
+class _PinnedPool:
+  """Page-locked PCM buffers for the decoder threads of a directory batch (da_host_alloc): a decoded
+  file lands where the GPU can fetch it by DMA, so its upload (da_pcm_upload_async) overlaps the
+  kernels of the pair before.  Buffers are recycled: locking pages costs more than filling them."""
+
+  def __init__(self):
+    import threading
+    self._free, self._lock = [], threading.Lock()
+
+  def alloc(self, shape):
+    from . import _native
+    need = int(np.prod(shape))
+    with self._lock:
+      fit = [b for b in self._free if b.size >= need]
+      flat = min(fit, key=lambda b: b.size) if fit else None
+      if flat is not None:
+        self._free = [b for b in self._free if b is not flat]
+    if flat is None:
+      flat = _native.pinned_empty((need + need // 8 + 64,), np.int16)
+    view = flat[:need].reshape(shape)
+    return view
+
+  def release(self, view):
+    flat = view
+    while isinstance(flat, np.ndarray) and isinstance(flat.base, np.ndarray):
+      flat = flat.base                                  # back to the whole page-locked array
+    with self._lock:
+      if all(b is not flat for b in self._free):
+        self._free.append(flat)
+
+
 def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_dir=default_output_dir,
                   alignment_dir=default_alignment_dir, lp_workers=None, decode_ahead=3, stretch_audio=False):
   """A directory batch on one GPU: same results and files as calling process_pair for every
@@ -300,10 +331,12 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
   max_held = workers + 2
   held = threading.BoundedSemaphore(max_held)
 
+  pool = _PinnedPool()
+
   def request(k):
     if k < len(work) and k not in decoded:
-      decoded[k] = (decoders.submit(media.parse_audio_from_file, work[k][0], num_channels),
-                    decoders.submit(media.parse_audio_from_file, work[k][1], num_channels))
+      decoded[k] = (decoders.submit(media.parse_audio_from_file, work[k][0], num_channels, pool.alloc),
+                    decoders.submit(media.parse_audio_from_file, work[k][1], num_channels, pool.alloc))
 
   def make_job(k):
     def job(c):
@@ -315,8 +348,13 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
       video_arr, audio_desc_arr = fv.result(), fa.result()
       if stretch_audio:
         kept[k] = (video_arr, audio_desc_arr)
-      vf = c.features(video_arr, _native.SIDE_VIDEO)
-      af = c.features(audio_desc_arr, _native.SIDE_AUDIO)
+      # both uploads are enqueued before the first feature kernel: the second copy runs under it
+      c.pcm_upload_async(_native.SIDE_VIDEO, video_arr)
+      c.pcm_upload_async(_native.SIDE_AUDIO, audio_desc_arr)
+      vf = c.features_resident(_native.SIDE_VIDEO)
+      af = c.features_resident(_native.SIDE_AUDIO)
+      if not stretch_audio:
+        pool.release(video_arr); pool.release(audio_desc_arr)
       return vf, af
     return job
 
@@ -334,6 +372,7 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
         video_arr, audio_desc_arr = kept.pop(k)
         stretch_ctx.pcm_upload(_native.SIDE_VIDEO, video_arr)
         stretch_ctx.pcm_upload(_native.SIDE_AUDIO, audio_desc_arr)
+        pool.release(video_arr); pool.release(audio_desc_arr)
         del video_arr, audio_desc_arr
       try:
         results.append(_finish_pair(outputs, video_file, audio_desc_file, has_audio_extension,

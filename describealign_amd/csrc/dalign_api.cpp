@@ -39,11 +39,13 @@ struct DevBuf {
 
 struct Side {
   DevBuf pcm;  int64_t n = 0; int channels = 0; int planar = 1;
+  hipEvent_t up0 = nullptr, up1 = nullptr; bool upload_pending = false;   // async upload: timing + "PCM has landed"
   DevBuf feat; int64_t feat_stride = 0; int64_t len[2] = {0, 0};
   // match-prep buffers
   DevBuf mfeat;                  // 5 rows uploaded by da_match
   DevBuf ms[5], nrm[5], dig[5], flg[5], ms32[3], inv32[3], nrm32[3], nrmpk[3], prod32, bfe[3], bfo[3];
   int64_t mlen[5] = {0, 0, 0, 0, 0}; int64_t lmax = 0;
+  const float* prep_feat = nullptr;   // device rows the last preparation read (resident rows or the uploaded copy)
 };
 
 // One set of buffers for a stage-2 chain DP in flight (or for the results of the last match):
@@ -83,7 +85,7 @@ struct da_ctx {
   std::string err;
   Side side[2];
   DevBuf tables, hann41;
-  DevBuf vlist, alist, surv, counters, keys0, q0, sort_tmp, rankmap;
+  DevBuf vlist, alist, surv, counters, keys0, q0, sort_tmp, rankmap, rowscratch;
   std::vector<ChainSlot*> slots;  // sorted match lists live in slots (see ChainSlot)
   int res_slot = -1;              // slot holding the results of the last finished match
   unsigned long long next_ticket = 1;
@@ -98,7 +100,6 @@ struct da_ctx {
   int pend_mode = 0; int64_t pend_nv = 0; size_t pend_cap = 0;
   hipEvent_t gemm_e0 = nullptr, gemm_e1 = nullptr, prep_e0 = nullptr, prep_e1 = nullptr;
   hipStream_t copy_stream = nullptr;
-  std::vector<int32_t> h_vlist, h_alist;
   MatchArgs last_match{};
   da_stats_t st{};
   // audio replacement (--stretch_audio)
@@ -217,13 +218,15 @@ void da_destroy(da_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (Side& s : c->side) {
+    if (s.up0) (void)hipEventDestroy(s.up0);
+    if (s.up1) (void)hipEventDestroy(s.up1);
     s.pcm.release(); s.feat.release(); s.mfeat.release();
     for (int j = 0; j < 5; ++j) { s.ms[j].release(); s.nrm[j].release(); s.dig[j].release(); s.flg[j].release(); }
     for (int j = 0; j < 3; ++j) { s.ms32[j].release(); s.inv32[j].release(); s.nrm32[j].release(); s.nrmpk[j].release(); s.bfe[j].release(); s.bfo[j].release(); }
     s.prod32.release();
   }
   DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->counters, &c->keys0,
-                   &c->q0, &c->sort_tmp, &c->rankmap, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
+                   &c->q0, &c->sort_tmp, &c->rankmap, &c->rowscratch, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
                    &c->band_y, &c->band_q, &c->band_part};
   for (DevBuf* b : all) b->release();
   for (ChainSlot* sl : c->slots) { if (sl->stream) (void)hipStreamSynchronize(sl->stream); sl->release(); delete sl; }
@@ -257,6 +260,39 @@ int da_pcm_upload(da_ctx* c, int side, const int16_t* pcm, int64_t n, int channe
   if (bytes) HIP_TRY(c, hipMemcpyAsync(s.pcm.p, pcm, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->st.h2d_ms = now_ms() - t0;
+  s.upload_pending = false;
+  s.n = n; s.channels = channels; s.planar = planar ? 1 : 0;
+  s.len[0] = s.len[1] = 0;
+  return DA_OK;
+}
+
+// Overlapped ingest: the decoder writes the PCM into page-locked memory from da_host_alloc;
+// da_pcm_upload_async enqueues the host->device copy on the copy stream and returns at once; the feature
+// kernel of that side waits for the copy on the device, not on the host.
+int da_host_alloc(size_t bytes, void** out) {
+  if (!out) return DA_ERR_ARG;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes ? bytes : 64, hipHostMallocDefault) == hipSuccess ? DA_OK : DA_ERR_DEVICE;
+}
+
+int da_host_free(void* p) {
+  if (!p) return DA_OK;
+  return hipHostFree(p) == hipSuccess ? DA_OK : DA_ERR_DEVICE;
+}
+
+int da_pcm_upload_async(da_ctx* c, int side, const int16_t* pcm, int64_t n, int channels, int planar) {
+  if (!c) return DA_ERR_ARG;
+  if (side < 0 || side > 1 || !pcm || n < 0 || (channels != 1 && channels != 2))
+    return fail(c, DA_ERR_ARG, "da_pcm_upload_async: bad argument");
+  Side& s = c->side[side];
+  const size_t bytes = sizeof(int16_t) * (size_t)n * channels;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, s.pcm.ensure(bytes + 64));
+  if (!s.up0) { HIP_TRY(c, hipEventCreate(&s.up0)); HIP_TRY(c, hipEventCreate(&s.up1)); }
+  HIP_TRY(c, hipEventRecord(s.up0, c->copy_stream));
+  if (bytes) HIP_TRY(c, hipMemcpyAsync(s.pcm.p, pcm, bytes, hipMemcpyHostToDevice, c->copy_stream));
+  HIP_TRY(c, hipEventRecord(s.up1, c->copy_stream));
+  s.upload_pending = true;
   s.n = n; s.channels = channels; s.planar = planar ? 1 : 0;
   s.len[0] = s.len[1] = 0;
   return DA_OK;
@@ -281,6 +317,7 @@ int da_features_resident(da_ctx* c, int side, float* feats, int64_t row_stride, 
   if (s.planar) { a.stride_c = s.n; a.stride_n = 1; } else { a.stride_c = 1; a.stride_n = s.channels; }
   a.n_energy = 105 * nb; a.n_band = 210 * lo; a.len_energy = le; a.len_other = lo;
   a.out = s.feat.as<float>(); a.row_stride = dstride;
+  if (s.upload_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, s.up1, 0));       // the PCM copy of da_pcm_upload_async
   HIP_TRY(c, hipMemsetAsync(s.feat.p, 0, sizeof(float) * 5 * (size_t)dstride, c->stream));
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
   launch_features(a, s.channels, c->tables.as<FeatTables>(), c->stream);
@@ -292,6 +329,10 @@ int da_features_resident(da_ctx* c, int side, float* feats, int64_t row_stride, 
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
   c->st.features_ms = ms;
+  if (s.upload_pending) {                                  // the stream has been synchronised: the copy is done
+    float up = 0.f; (void)hipEventElapsedTime(&up, s.up0, s.up1); c->st.h2d_ms = up;
+    s.upload_pending = false;
+  }
   c->st.features_bytes = 2.0 * s.channels * (double)s.n + 5.0 * 4.0 * (double)lo;
   return DA_OK;
 }
@@ -332,6 +373,7 @@ int upload_and_prep(da_ctx* c, Side& s, const float* feat, int64_t stride, const
     }
     p.feat = s.mfeat.as<float>();
   }
+  s.prep_feat = p.feat;                                    // row 0 = the energy row the row lists are built from
   p.row_stride = dstride; p.lmax = lmax; p.is_video = is_video;
   const size_t n = (size_t)dstride;
   for (int j = 0; j < 5; ++j) {
@@ -390,26 +432,32 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
   HIP_TRY(c, hipEventRecord(c->prep_e1, c->stream));
 
   // row lists from the energy rows (describealign.py:629-630, :657-658)
-  std::vector<int32_t>& vlist = c->h_vlist; std::vector<int32_t>& alist = c->h_alist;
-  vlist.clear(); alist.clear();
+  int64_t n_v = 0, n_a = 0;
   {
-    const int64_t nv = v_lengths[0] - kWin;
-    int64_t k = 0;
-    for (int64_t i = 0; i < nv; ++i)
-      if (vfeat[i] > 0.5f) { if ((k & 3) == 0) vlist.push_back((int32_t)i); ++k; }
-    const int64_t na = a_lengths[0] - kWin;
-    const int64_t b = std::max<int64_t>(0, row_begin), e = (row_end < 0) ? na : std::min(na, row_end);
-    for (int64_t i = b; i < e; ++i)
-      if (afeat[i] > 0.5f) alist.push_back((int32_t)i);
+    const int64_t nv = std::max<int64_t>(0, v_lengths[0] - kWin);
+    const int64_t na = std::max<int64_t>(0, a_lengths[0] - kWin);
+    const int64_t b = std::min(na, std::max<int64_t>(0, row_begin)), e = (row_end < 0) ? na : std::max(b, std::min(na, row_end));
+    HIP_TRY(c, c->vlist.ensure(sizeof(int32_t) * (size_t)std::max<int64_t>(1, nv)));
+    HIP_TRY(c, c->alist.ensure(sizeof(int32_t) * (size_t)std::max<int64_t>(1, na)));
+    {
+      // compacted on the device from the energy rows the preparation kernels read (resident or just
+      // uploaded); only the two counts come back
+      const size_t tb = da::select_rows_temp_bytes(std::max(nv, na));
+      HIP_TRY(c, c->sort_tmp.ensure(tb + 256));
+      HIP_TRY(c, c->rowscratch.ensure(sizeof(int32_t) * (size_t)std::max<int64_t>(1, nv)));
+      int32_t* d_cnt32 = c->counters.as<int32_t>() + 8;             // [8..9] video, [10..11] audio (bytes 32..47 of `counters`)
+      if (da::select_rows(V.prep_feat, 0, nv, true, c->rowscratch.as<int32_t>(), c->vlist.as<int32_t>(), d_cnt32, c->sort_tmp.p, tb, c->stream) != 0 ||
+          da::select_rows(A.prep_feat, b, e, false, nullptr, c->alist.as<int32_t>(), d_cnt32 + 2, c->sort_tmp.p, tb, c->stream) != 0)
+        return fail(c, DA_ERR_DEVICE, "da_match: row list compaction failed");
+      int32_t h_cnt[4] = {0, 0, 0, 0};
+      HIP_TRY(c, hipMemcpyAsync(h_cnt, d_cnt32, sizeof h_cnt, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      n_v = h_cnt[0]; n_a = h_cnt[2];
+    }
   }
-  const int64_t n_v = (int64_t)vlist.size(), n_a = (int64_t)alist.size();
   c->st.gemm_pairs = (double)n_v * (double)n_a;
   c->st.gemm_flops = 246.0 * c->st.gemm_pairs;
   c->st.survivors = 0; c->st.matches = 0; c->st.gemm_ms = 0; c->st.verify_ms = 0;
-  HIP_TRY(c, c->vlist.ensure(sizeof(int32_t) * (size_t)std::max<int64_t>(1, n_v)));
-  HIP_TRY(c, c->alist.ensure(sizeof(int32_t) * (size_t)std::max<int64_t>(1, n_a)));
-  if (n_v) HIP_TRY(c, hipMemcpyAsync(c->vlist.p, vlist.data(), sizeof(int32_t) * n_v, hipMemcpyHostToDevice, c->stream));
-  if (n_a) HIP_TRY(c, hipMemcpyAsync(c->alist.p, alist.data(), sizeof(int32_t) * n_a, hipMemcpyHostToDevice, c->stream));
 
   MatchArgs m{};
   for (int j = 0; j < 3; ++j) {

@@ -107,6 +107,12 @@ void launch_unpack_keys(const unsigned long long* keys, int64_t n, int32_t* out_
 int sort_pairs(unsigned long long* keys_in, unsigned long long* keys_out, double* vals_in, double* vals_out,
                int64_t n, void* temp, size_t* temp_bytes, hipStream_t s);
 
+// row lists on the device: frames i in [lo, hi) with energy[i] > 0.5 (optionally every 4th of them) -> out,
+// count -> d_count[0] (d_count[1] is scratch); `scratch` holds hi - lo ints when every_fourth
+size_t select_rows_temp_bytes(int64_t n);
+int select_rows(const float* energy, int64_t lo, int64_t hi, bool every_fourth, int32_t* scratch, int32_t* out, int32_t* d_count,
+                void* temp, size_t temp_bytes, hipStream_t s);
+
 // ---- pass 2: banded evaluation -------------------------------------------------------------
 struct BandArgs {
   const double* a_scaled; int64_t La;     // [La][3]

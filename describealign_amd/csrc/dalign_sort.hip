@@ -2,6 +2,7 @@
 // Kept in its own translation unit: the library templates dominate compile time.
 #include "dalign_common.h"
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
 
 namespace da {
 
@@ -11,6 +12,43 @@ int sort_pairs(unsigned long long* keys_in, unsigned long long* keys_out, double
   hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, *temp_bytes, keys_in, keys_out, vals_in, vals_out,
                                                     (int)n, 0, 64, s);
   return e == hipSuccess ? 0 : -1;
+}
+
+// ---- row lists of the matching stage, built on the device from a resident energy row ----------
+// describealign.py:629-630 (every 4th non-quiet video frame) and :657-658 (non-quiet audio frames
+// inside the requested row range): frames i in [lo, hi) with energy[i] > 0.5, in order.
+namespace {
+struct NonQuiet {
+  const float* e;
+  __device__ bool operator()(const int32_t& i) const { return e[i] > 0.5f; }
+};
+__global__ void k_every_fourth(const int32_t* __restrict__ all, const int32_t* __restrict__ n_all, int32_t* __restrict__ out,
+                               int32_t* __restrict__ n_out) {
+  const int32_t n = *n_all;
+  const int32_t m = (n + 3) / 4;
+  for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) out[k] = all[4 * k];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = m;
+}
+}  // namespace
+
+size_t select_rows_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  hipcub::CountingInputIterator<int32_t> ids(0);
+  (void)hipcub::DeviceSelect::If(nullptr, bytes, ids, (int32_t*)nullptr, (int32_t*)nullptr, (int)std::max<int64_t>(1, n), NonQuiet{nullptr});
+  return bytes;
+}
+
+int select_rows(const float* energy, int64_t lo, int64_t hi, bool every_fourth, int32_t* scratch, int32_t* out, int32_t* d_count,
+                void* temp, size_t temp_bytes, hipStream_t s) {
+  const int64_t n = hi - lo;
+  if (n <= 0) return hipMemsetAsync(d_count, 0, sizeof(int32_t), s) == hipSuccess ? 0 : -1;
+  if (n > 0x7fffffffLL) return -1;
+  hipcub::CountingInputIterator<int32_t> ids((int32_t)lo);
+  int32_t* first = every_fourth ? scratch : out;
+  int32_t* cnt = every_fourth ? d_count + 1 : d_count;
+  if (hipcub::DeviceSelect::If(temp, temp_bytes, ids, first, cnt, (int)n, NonQuiet{energy}, s) != hipSuccess) return -1;
+  if (every_fourth) hipLaunchKernelGGL(k_every_fourth, dim3(256), dim3(256), 0, s, scratch, cnt, out, d_count);
+  return 0;
 }
 
 }  // namespace da

@@ -30,7 +30,17 @@ def find_ffprobe():
   return exe
 
 
-def _read_native(media_file, ext, num_channels):
+def _deliver(planar_view, alloc):
+  """The decoded (C, N) int16 array, C-contiguous: written into `alloc((C, N))` when the caller provides
+  an allocator (page-locked memory for an asynchronous upload), else a fresh numpy array."""
+  if alloc is None:
+    return np.ascontiguousarray(planar_view)
+  out = alloc(planar_view.shape)
+  out[...] = planar_view
+  return out
+
+
+def _read_native(media_file, ext, num_channels, alloc=None):
   """44.1 kHz 16-bit PCM WAV / raw s16le without ffmpeg.  Returns None when the file is not
   exactly what ffmpeg would hand back untouched (other rate / width / channel count, extensible
   or float WAV headers, ragged raw files): those go through ffmpeg, whose resampler and downmix
@@ -41,11 +51,11 @@ def _read_native(media_file, ext, num_channels):
         if w.getframerate() != AUDIO_SAMPLE_RATE or w.getsampwidth() != 2 or w.getnchannels() != num_channels:
           return None
         raw = w.readframes(w.getnframes())
-      return np.ascontiguousarray(np.frombuffer(raw, dtype="<i2").reshape(-1, num_channels).T)
+      return _deliver(np.frombuffer(raw, dtype="<i2").reshape(-1, num_channels).T, alloc)
     pcm = np.fromfile(media_file, dtype="<i2")        # raw files carry no header: taken as num_channels s16le
     if len(pcm) % num_channels:
       return None
-    return np.ascontiguousarray(pcm.reshape(-1, num_channels).T)
+    return _deliver(pcm.reshape(-1, num_channels).T, alloc)
   except (wave.Error, EOFError, OSError, ValueError):
     return None
 
@@ -76,10 +86,13 @@ def _read_wav_any_channels(media_file):
     return None
 
 
-def parse_audio_from_file(media_file, num_channels=2) -> np.ndarray:
+def parse_audio_from_file(media_file, num_channels=2, alloc=None) -> np.ndarray:
+  """describealign.parse_audio_from_file (:149-157) returning the int16 values as int16 (C, N).
+  alloc: optional allocator shape -> int16 array the result is written into (combine hands out
+  page-locked buffers, so the upload of this file overlaps the kernels of the previous pair)."""
   ext = os.path.splitext(media_file)[1].lower()
   if ext in (".wav", ".raw", ".s16le", ".pcm"):
-    pcm = _read_native(media_file, ext, num_channels)
+    pcm = _read_native(media_file, ext, num_channels, alloc)
     if pcm is not None:
       return pcm
   exe = find_ffmpeg()
@@ -88,7 +101,7 @@ def parse_audio_from_file(media_file, num_channels=2) -> np.ndarray:
       pcm = _read_wav_any_channels(media_file)
       pcm = None if pcm is None else _downmix_like_swresample(pcm, num_channels)
       if pcm is not None:
-        return np.ascontiguousarray(pcm)
+        return _deliver(pcm, alloc)
     raise RuntimeError(f"cannot decode {media_file}: no ffmpeg binary on PATH "
                        "(only 44.1 kHz 16-bit .wav and raw s16le are read natively)")
   cmd = [exe, "-i", media_file, "-f", "s16le", "-acodec", "pcm_s16le", "-af", "aresample=async=1:first_pts=0",
@@ -99,7 +112,7 @@ def parse_audio_from_file(media_file, num_channels=2) -> np.ndarray:
     print("FFmpeg error:")
     print(res.stderr.decode("utf-8", "replace"))
     raise RuntimeError("FFmpeg error.")
-  return np.ascontiguousarray(np.frombuffer(res.stdout, np.int16).reshape((-1, num_channels)).T)
+  return _deliver(np.frombuffer(res.stdout, np.int16).reshape((-1, num_channels)).T, alloc)
 
 
 def write_wav(path, pcm: np.ndarray):

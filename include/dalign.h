@@ -35,8 +35,8 @@ enum { DA_MATCH_HASHED = 0,  /* reference candidate vote (:649-660) applied to G
        DA_MATCH_DENSE = 1,   /* every pair under the correlation threshold (no hash vote) */
        DA_MATCH_RESIDENT_ROWS = 0x100 }; /* OR-ed into `mode`: the rows passed are exactly those the last
                                 da_features_resident calls produced for both sides; their device copies
-                                are used in place and nothing is uploaded (the host rows are still read
-                                for the non-quiet frame lists) */
+                                are used in place and nothing is uploaded.  (Either way the non-quiet
+                                frame lists are compacted on the device; the host rows are not read.) */
 
 int  da_create(int device_id, int precision, da_ctx** out);
 void da_destroy(da_ctx* ctx);
@@ -50,6 +50,18 @@ int  da_abi_version(void);
  * s16le frames as ffmpeg emits them.  The copy into HBM happens here (host->device). */
 int da_pcm_upload(da_ctx* ctx, int side, const int16_t* pcm, int64_t n_samples, int channels,
                   int planar);
+
+/* Overlapped ingest (replaces the blocking pipe read + cast of
+ * describealign.py:149-157).  da_host_alloc returns page-locked host memory for the decoder to write the
+ * PCM into (no context needed; da_host_free releases it).  da_pcm_upload_async enqueues the host->device
+ * copy on the context's copy stream and returns immediately; the next da_features_resident of that side
+ * waits for the copy ON THE DEVICE.  The source buffer must stay untouched until that
+ * da_features_resident call has returned.  So the decode of pair k+1 and its PCIe transfer overlap the
+ * kernels of pair k.  (From pageable memory the call still works, but the runtime stages the copy.)
+ * da_stats().h2d_ms then holds the copy's own duration (HIP events), after that da_features_resident. */
+int da_host_alloc(size_t bytes, void** out);
+int da_host_free(void* p);
+int da_pcm_upload_async(da_ctx* ctx, int side, const int16_t* pcm, int64_t n_samples, int channels, int planar);
 
 /* ---- features -------------------------------------------------------------------------------
  * get_energy + get_zero_crossings + get_freq_bands (describealign.py:545-593) as one fused

@@ -597,6 +597,24 @@ def test_resident_rows_fast_path_equals_uploaded_rows(ctx, native):
   assert ctx._resident_rows(0, vf) is None
 
 
+def test_async_pinned_upload_equals_blocking_upload(ctx, native):
+  """da_host_alloc + da_pcm_upload_async (page-locked source, copy on the copy stream, the feature
+  kernel waits on the device) gives the same rows as the blocking da_pcm_upload, for both layouts;
+  the copy's duration is reported."""
+  pair = cases.align_case("e180s")
+  want_v = [f.copy() for f in ctx.features(pair.video, 0)]
+  want_a = [f.copy() for f in ctx.features(pair.audio, 1)]
+  pv = native.pinned_empty(pair.video.shape); pv[...] = pair.video
+  pa = native.pinned_empty((pair.audio.shape[1], 2)); pa[...] = pair.audio.T            # interleaved frames
+  ctx.pcm_upload_async(0, pv); ctx.pcm_upload_async(1, pa)
+  got_v = ctx.features_resident(0)
+  assert ctx.stats()["h2d_ms"] > 0
+  got_a = ctx.features_resident(1)
+  for g_, w_ in zip(got_v + got_a, want_v + want_a):
+    assert np.array_equal(g_, w_)
+  del pv, pa                                            # frees the page-locked memory with the last view
+
+
 def test_bench_launch_contract_two_ranks(tmp_path):
   """The driver launches bench.py under torch.distributed.run, one rank per GPU.  With only one
   GPU here both ranks share it (gloo instead of RCCL, which refuses two ranks on one device): rank 0
