@@ -153,9 +153,11 @@ class Bench:
 
     quiet = contextlib.redirect_stdout(io.StringIO())
     tms, outs = [], []
-    # tail: pairs submitted behind the timed ones so that the stages are still all busy when the
-    # clock stops; once fewer than `workers` pairs are left the LP stage starts to drain
-    tail = 0 if workers <= 0 else (args.tail if args.tail >= 0 else min(workers, 8 if wl["seconds"] > 3000 else workers))
+    # tail: pairs submitted behind the timed ones so that every stage is as busy when the clock stops as
+    # in the middle of a long batch: the LP solves of the timed pairs must run beside a full set of
+    # other solves (they share the host's caches and memory bandwidth: alone a 2 h pair's LP takes 6 s,
+    # beside 23 others 10 s), so one whole generation of solves follows the last timed pair
+    tail = 0 if workers <= 0 else (args.tail if args.tail >= 0 else (workers if not quick else workers // 3))
     # Priming.  A pair spends seconds in the host LP stage (2 h pair: ~9 s), far longer than the
     # 0.3 s between pairs, so the first results of a fresh pipeline arrive in a burst at the GPU
     # stage's rate: every worker is still on its FIRST solve and the LP stage has not yet had to

@@ -568,6 +568,7 @@ def _proc_mid(fname, fsize, n, le_v, lo_v, le_a, lo_a):
   mm = np.memmap(fname, dtype=np.uint8, mode="r+", shape=(fsize,))
   px, py, vf, af, a_out, v_out = _block_views(mm, lay, le_v, lo_v, le_a, lo_a)
   tm = {}
+  t_in = time.perf_counter()
   fx, fy, a_s, v_s = _stage_pass1(px, py, vf, af, tm)
   t0 = time.perf_counter()
   lp = solve_trend_lp(fx, fy)
@@ -579,6 +580,7 @@ def _proc_mid(fname, fsize, n, le_v, lo_v, le_a, lo_a):
   v_out[:] = v_s
   mm.flush()
   del mm
+  tm["worker_s"] = time.perf_counter() - t_in
   return clusters, float(lp["median_slope"]), tm
 
 
@@ -665,6 +667,11 @@ class AlignPipeline:
     self._dir = tempfile.mkdtemp(prefix=f"dalign_{os.getpid()}_", dir=shm)
     self._seq = 0
     self._free = []        # reusable (file name, bytes) blocks: fresh tmpfs pages cost ~0.2 ms per MB
+    self.pace = int(os.environ.get("DALIGN_PIPELINE_PACE", "1")) != 0
+    self._work_ema = None  # worker seconds per pair (pass 1 + LP + clustering), exponential average
+    self._last_admit = 0.0
+    self._n_admitted = 0   # pairs whose GPU stage has started / pairs whose worker stage has finished
+    self._n_done = 0
     self._queued = {}      # per GPU context: pairs submitted to its thread that have not started yet
     self._chains = {}      # per GPU context: pairs whose chain DP is enqueued (ticket, ...), oldest first
     self.max_chains = int(os.environ.get("DALIGN_MAX_CHAINS", "12"))      # DPs in flight per context (the library allows 16)
@@ -716,6 +723,7 @@ class AlignPipeline:
     try:
       with self._lock:
         self._queued[id(ctx)] = self._queued.get(id(ctx), 0) - 1
+      self._pace(ctx)
       t0 = time.perf_counter()
       vf, af = job(ctx) if callable(job) else job
       tm["features_s"] = time.perf_counter() - t0
@@ -729,7 +737,34 @@ class AlignPipeline:
       ticket = ctx.chain_begin()
       self._chains.setdefault(id(ctx), []).append((ticket, vf, af, tm, fname, done, time.perf_counter()))
     except BaseException as e:
+      with self._lock:
+        self._n_done += 1
       done.set_exception(e)
+
+  def _pace(self, ctx):
+    """Admission pacing.  When the host stage is the slower one (a 2 h pair: ~10 s of LP per pair on one
+    of `depth` workers against 0.3 s on the GPU) pairs are admitted `worker seconds per pair / depth`
+    apart instead of as fast as the GPU can take them: the workers then start -- and finish -- evenly
+    spread in time, the queue in front of them (and the /dev/shm blocks it pins) stays short, and the
+    pipeline's output rate is the sustainable one from the first generation of solves on, not a burst
+    at the GPU's rate followed by a stall.  No effect while the GPU stage is the slower one."""
+    if not self.pace:
+      return
+    while True:
+      with self._lock:
+        ema, in_flight = self._work_ema, self._n_admitted - self._n_done
+      if ema is None:
+        # nothing has come back yet: no queue in front of the workers until their speed is known
+        wait = 0.004 if in_flight >= self.depth * max(1, len(self.gpu_ctxs)) else 0.0
+      else:
+        wait = self._last_admit + 0.97 * ema / (self.depth * max(1, len(self.gpu_ctxs))) - time.perf_counter()
+      if wait <= 0:
+        break
+      self._collect_chains(ctx)                          # finished DPs are still handed on while waiting
+      time.sleep(min(wait, 0.004))
+    with self._lock:
+      self._n_admitted += 1
+    self._last_admit = time.perf_counter()
 
   def _collect_chains(self, ctx, block_above=None):
     """Hand every pair whose chain DP has finished to the worker processes, in order.  With
@@ -779,6 +814,9 @@ class AlignPipeline:
       mid = self.pool.submit(_proc_mid, state["fname"], fsize, n, *dims)
 
       def on_mid(f):
+        with self._lock:
+          self._n_done += 1               # the pair has left the worker stage (whatever the outcome)
+
         def work():
           try:
             done.set_result(self._refine_stage(f.result(), state, dims, tm))
@@ -788,10 +826,16 @@ class AlignPipeline:
 
       mid.add_done_callback(on_mid)
     except BaseException as e:
+      with self._lock:
+        self._n_done += 1
       done.set_exception(e)
 
   def _refine_stage(self, mid_result, state, dims, tm):
     clusters, med, wtm = mid_result
+    busy = wtm.get("worker_s")
+    if busy is not None:
+      with self._lock:
+        self._work_ema = busy if self._work_ema is None else 0.8 * self._work_ema + 0.2 * busy
     dev = tm.get("device", {})
     dev.update(wtm.pop("device", {}))
     tm.update(wtm); tm["device"] = dev
