@@ -27,7 +27,7 @@ ERR_MISMATCH = -4
 
 EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm_upload", "da_pcm_upload_async", "da_host_alloc", "da_host_free",
            "da_features_resident", "da_features", "da_match", "da_match_begin", "da_match_finish", "da_match_fetch",
-           "da_match_corr", "da_match_dump_tile", "da_chain", "da_chain_begin", "da_chain_finish", "da_chain_resident", "da_chain_poll",
+           "da_match_corr", "da_match_dump_tile", "da_match_export_device", "da_match_import_device", "da_chain", "da_chain_begin", "da_chain_finish", "da_chain_resident", "da_chain_poll",
            "da_refine", "da_stats", "da_replace_segments", "da_stretch_resident", "da_stretch_schedule"]
 
 
@@ -90,6 +90,8 @@ def load():
     lib.da_match_finish.argtypes = [vp, P(i64)]
     lib.da_match_fetch.argtypes = [vp, vp, vp, vp, i64]
     lib.da_match_corr.argtypes = [vp, vp, vp, i64, vp]
+    lib.da_match_export_device.argtypes = [vp, vp, vp, i64]
+    lib.da_match_import_device.argtypes = [vp, vp, vp, i64]
     lib.da_match_dump_tile.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.da_chain.argtypes = [vp, vp, vp, vp, i64, C.c_double, vp, vp, P(i64)]
     lib.da_chain_begin.argtypes = [vp, P(C.c_uint64)]
@@ -326,6 +328,16 @@ class Context:
     out = np.empty((len(i), 3), dtype=np.float32)
     self._check(self._lib.da_match_corr(self._h, _ptr(i), _ptr(v), len(i), _ptr(out)))
     return out
+
+  def match_export_device(self, d_keys: int, d_q: int, n: int):
+    """Copy the n resident matches device-to-device into caller-owned device buffers (addresses):
+    uint64 keys (i << 32 | v) and float64 qualities."""
+    self._check(self._lib.da_match_export_device(self._h, C.c_void_p(d_keys), C.c_void_p(d_q), int(n)))
+
+  def match_import_device(self, d_keys: int, d_q: int, n: int):
+    """Make a sorted match list that lives in device memory the resident result of this context
+    (chain_begin / chain_resident then run on it)."""
+    self._check(self._lib.da_match_import_device(self._h, C.c_void_p(d_keys), C.c_void_p(d_q), int(n)))
 
   def match_dump_tile(self, video_tile: int, audio_tile: int):
     """Raw MFMA accumulators |A|_j (1 - corr_j) of one 32 x 32 tile of the last match:

@@ -424,29 +424,39 @@ def align_tiled(video_features, audio_desc_features, video_energy, audio_desc_en
                 timings=None, mode=_native.MATCH_HASHED):
   """One long pair across all ranks of `group` (BASELINE config 5): the quadratic matching stage
   is split into contiguous audio-row blocks, one per GPU (each rank holds all video features);
-  the verified match lists are exchanged with a single all-gather (RCCL over xGMI), after which
-  every rank holds the full list and finishes the (sequential, host-side) rest identically.
-  Returns the same tuple as align() on every rank."""
+  the verified match lists are gathered on rank 0 in ONE exchange (RCCL over xGMI, device to device:
+  Group.gather_matches_to_root), rank 0 alone runs what is sequential -- chain DP on its GPU, the
+  host LP, pass 2 -- and broadcasts the result.  Returns the same tuple as align() on every rank."""
   from .distrib import row_blocks
   ctx = ctx or default_context()
   tm = timings if timings is not None else {}
   n_ve, n_ae = len(video_energy), len(audio_desc_energy)
   t0 = time.perf_counter()
   rb, re = row_blocks(max(0, n_ae - (2 * NODE_FRAMES - 1)), group.world)[group.rank]
-  mi, mv, mq = ctx.match(video_features, audio_desc_features, mode=mode, rows=(rb, re))
-  tm["device"] = ctx.stats()
+  n_local = _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm, rows=(rb, re))
   t1 = time.perf_counter()
-  mi, mv, mq = group.all_gather_matches(mi, mv, mq)
+  total = group.gather_matches_to_root(ctx, n_local)
   t2 = time.perf_counter()
-  tm.update(match_s=t1 - t0, gather_s=t2 - t1, n_matches=len(mi), rows=(rb, re))
-  px, py = ctx.chain(mi, mv, mq, min_len=min_path_length(n_ve, n_ae))
-  tm["device"]["chain_ms"] = ctx.stats()["chain_ms"]
-  tm["chain_s"] = time.perf_counter() - t2
-  fx, fy, a_scaled, v_scaled = _stage_pass1(px, py, video_features, audio_desc_features, tm)
-  t3 = time.perf_counter()
-  lp = solve_trend_lp(fx, fy)
-  tm["lp_s"] = time.perf_counter() - t3
-  out = _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm)
+  tm.update(match_s=t1 - t0, gather_s=t2 - t1, n_matches=total if total is not None else n_local, rows=(rb, re))
+  out, err = None, None
+  if group.rank == 0:
+    try:
+      gathered = getattr(ctx, "_gathered", None)
+      if gathered is not None:                              # host-staged lists (gloo): upload + device DP
+        ctx._gathered = None
+        px, py = ctx.chain(*gathered, min_len=min_path_length(n_ve, n_ae))
+      else:
+        px, py = ctx.chain_resident(min_len=min_path_length(n_ve, n_ae))
+      tm["device"]["chain_ms"] = ctx.stats()["chain_ms"]
+      tm["chain_s"] = time.perf_counter() - t2
+      fx, fy, a_scaled, v_scaled = _stage_pass1(px, py, video_features, audio_desc_features, tm)
+      t3 = time.perf_counter()
+      lp = solve_trend_lp(fx, fy)
+      tm["lp_s"] = time.perf_counter() - t3
+      out = _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm)
+    except RuntimeError as e:
+      err = str(e)
+  out = group.broadcast_result(out, err)
   tm["total_s"] = time.perf_counter() - t0
   return out
 

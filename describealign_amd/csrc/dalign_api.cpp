@@ -622,6 +622,50 @@ extern "C" int da_match_fetch(da_ctx* c, int32_t* out_i, int32_t* out_v, double*
   return DA_OK;
 }
 
+// Device-to-device hand-over of the resident match list (multi-GPU long-pair mode: the lists travel
+// between ranks by RCCL in device memory, never through the host).
+extern "C" int da_match_export_device(da_ctx* c, uint64_t* d_keys, double* d_q, int64_t n) {
+  if (!c) return DA_ERR_ARG;
+  if (!c->fetch_ready) return fail(c, DA_ERR_STATE, "da_match_export_device: no finished match is resident");
+  if (n < 0 || (uint64_t)n > c->n_match_resident) return fail(c, DA_ERR_ARG, "da_match_export_device: n out of range");
+  if (n == 0) return DA_OK;
+  if (!d_keys || !d_q || c->res_slot < 0) return fail(c, DA_ERR_ARG, "da_match_export_device: null output");
+  HIP_TRY(c, hipSetDevice(c->device));
+  ChainSlot& sl = *c->slots[c->res_slot];
+  HIP_TRY(c, hipMemcpyAsync(d_keys, sl.keys.p, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d_q, sl.q.p, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return DA_OK;
+}
+
+extern "C" int da_match_import_device(da_ctx* c, const uint64_t* d_keys, const double* d_q, int64_t n) {
+  if (!c) return DA_ERR_ARG;
+  if (!c->match_ready) return fail(c, DA_ERR_STATE, "da_match_import_device: call da_match on this context first (its video row list ranks the matches)");
+  if (n < 0 || (n > 0 && (!d_keys || !d_q))) return fail(c, DA_ERR_ARG, "da_match_import_device: bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->res_slot >= 0 && c->slots[c->res_slot]->state == 1) c->slots[c->res_slot]->state = 0;
+  c->res_slot = -1;
+  const int si = acquire_slot(c);
+  if (si < 0) return fail(c, DA_ERR_STATE, "da_match_import_device: all chain slots are in flight");
+  ChainSlot& sl = *c->slots[si];
+  const size_t nn = (size_t)std::max<int64_t>(1, n);
+  HIP_TRY(c, sl.keys.ensure(sizeof(uint64_t) * nn)); HIP_TRY(c, sl.q.ensure(sizeof(double) * nn));
+  if (n > 0) {
+    HIP_TRY(c, hipMemcpyAsync(sl.keys.p, d_keys, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(sl.q.p, d_q, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, c->keys0.ensure(sizeof(uint64_t) * nn));
+    launch_unpack_keys(sl.keys.as<unsigned long long>(), n, c->keys0.as<int32_t>(), c->keys0.as<int32_t>() + n, c->stream);
+    HIP_TRY(c, hipGetLastError());
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  sl.n = n; sl.n_ranks = c->pend_nv; sl.state = 1;
+  c->res_slot = si;
+  c->n_match_resident = (unsigned long long)n;
+  c->st.matches = (double)n;
+  c->fetch_ready = true;
+  return DA_OK;
+}
+
 extern "C" int da_match_corr(da_ctx* c, const int32_t* pi, const int32_t* pv, int64_t n, float* corr) {
   if (!c) return DA_ERR_ARG;
   if (!c->match_ready) return fail(c, DA_ERR_STATE, "da_match_corr: call da_match first");

@@ -50,35 +50,88 @@ class Group:
     self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
     return float(t.item())
 
-  def all_gather_matches(self, mi, mv, mq):
-    """The one exchange step of a single long pair tiled over ranks: every
-    rank matched its own contiguous block of audio rows; gather counts, then the padded (i, v, q)
-    lists, and concatenate in rank order -- which is (i, v) order, because blocks are contiguous
-    and each rank's list is already sorted.  With RCCL the tensors live in HBM and travel over
-    xGMI; with gloo (tests) they are host tensors."""
+  def gather_matches_to_root(self, ctx, n_local):
+    """The one exchange step of a single long pair tiled over ranks: every rank
+    has matched its own contiguous block of audio rows and holds its sorted list on ITS device.
+    The lists are gathered on rank 0 and become the resident match list of rank 0's context, in rank
+    order -- which is (i, v) order, because the blocks are contiguous and each list is sorted.
+
+    RCCL (backend "nccl"): the lists never touch the host -- exported device-to-device into the
+    tensors RCCL sends over xGMI, imported device-to-device on rank 0 (16 B per match: ~1e9 matches of
+    an 8 h pair = 16 GB into rank 0's 288 GB).  gloo (CPU tests): staged through host tensors.
+    Returns the total number of matches on rank 0, None elsewhere."""
     import numpy as np
-    if self.dist is None:
-      return mi, mv, mq
     import torch
-    dev = self.device
-    n = torch.tensor([len(mi)], dtype=torch.int64, device=dev)
+    if self.dist is None:
+      return n_local
+    dist, dev = self.dist, self.device
+    n = torch.tensor([n_local], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
-    self.dist.all_gather(counts, n)
+    dist.all_gather(counts, n)
     counts = [int(c.item()) for c in counts]
     cap = max(1, max(counts))
-    # one int64 payload: i, v and the float64 quality bit pattern, padded to the largest count
-    buf = np.zeros((3, cap), dtype=np.int64)
-    buf[0, :len(mi)] = mi; buf[1, :len(mv)] = mv
-    buf[2, :len(mq)] = np.ascontiguousarray(mq, dtype=np.float64).view(np.int64)
-    mine = torch.from_numpy(buf).to(dev)
-    parts = [torch.empty_like(mine) for _ in range(self.world)]
-    self.dist.all_gather(parts, mine)
-    out_i, out_v, out_q = [], [], []
-    for r, c in enumerate(counts):
-      a = parts[r].cpu().numpy()
-      out_i.append(a[0, :c].astype(np.int32)); out_v.append(a[1, :c].astype(np.int32))
-      out_q.append(a[2, :c].copy().view(np.float64))
-    return np.concatenate(out_i), np.concatenate(out_v), np.concatenate(out_q)
+    on_gpu = self.backend == "nccl"
+    keys = torch.zeros(cap, dtype=torch.int64, device=dev)
+    qual = torch.zeros(cap, dtype=torch.float64, device=dev)
+    if on_gpu:
+      if n_local:
+        ctx.match_export_device(keys.data_ptr(), qual.data_ptr(), n_local)
+    else:
+      mi, mv, mq = ctx.match_fetch(n_local)
+      keys[:n_local] = torch.from_numpy((mi.astype(np.int64) << 32) | mv.astype(np.int64))
+      qual[:n_local] = torch.from_numpy(np.ascontiguousarray(mq, dtype=np.float64))
+    root = self.rank == 0
+    got_k = [torch.empty_like(keys) for _ in range(self.world)] if root else None
+    got_q = [torch.empty_like(qual) for _ in range(self.world)] if root else None
+    dist.gather(keys, got_k, dst=0)
+    dist.gather(qual, got_q, dst=0)
+    if not root:
+      return None
+    all_k = torch.cat([got_k[r][:counts[r]] for r in range(self.world)])
+    all_q = torch.cat([got_q[r][:counts[r]] for r in range(self.world)])
+    total = int(all_k.numel())
+    if on_gpu:
+      torch.cuda.synchronize(dev)
+      ctx.match_import_device(all_k.data_ptr(), all_q.data_ptr(), total)
+    else:
+      k = all_k.numpy()
+      # host lists: hand them to the context through a device upload of its own
+      ctx._gathered = ((k >> 32).astype(np.int32), (k & 0xffffffff).astype(np.int32), all_q.numpy().copy())
+    return total
+
+  def broadcast_result(self, result, error=None):
+    """Rank 0's align() result -- (audio_times, video_times, similarity, path, median_slope) -- to every
+    rank (rank 0 alone runs the sequential host stages of a tiled pair).  `error`: rank 0's failure
+    message, raised as RuntimeError on every rank."""
+    import numpy as np
+    import torch
+    if self.dist is None:
+      if error:
+        raise RuntimeError(error)
+      return result
+    dist, dev = self.dist, self.device
+    head = torch.zeros(4, dtype=torch.float64, device=dev)
+    if self.rank == 0:
+      if error:
+        head[0] = -1.0
+      else:
+        x, y, sim, path, med = result
+        head = torch.tensor([len(x), path.shape[0], float(sim), float(med)], dtype=torch.float64, device=dev)
+    dist.broadcast(head, src=0)
+    if head[0].item() < 0:
+      msg = [error]
+      dist.broadcast_object_list(msg, src=0)
+      raise RuntimeError(msg[0])
+    nx, rows = int(head[0].item()), int(head[1].item())
+    body = torch.empty(2 * nx + 5 * rows, dtype=torch.float64, device=dev)
+    if self.rank == 0:
+      flat = np.concatenate([np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64), np.ascontiguousarray(path, dtype=np.float64).ravel()])
+      body.copy_(torch.from_numpy(flat))
+    dist.broadcast(body, src=0)
+    if self.rank == 0:
+      return result
+    flat = body.cpu().numpy()
+    return flat[:nx].copy(), flat[nx:2 * nx].copy(), float(head[2].item()), flat[2 * nx:].reshape(rows, 5).copy(), float(head[3].item())
 
   def close(self):
     if self.dist is not None:

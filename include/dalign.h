@@ -106,6 +106,16 @@ int da_match_finish(da_ctx* ctx, int64_t* n_matches);
  * DA_ERR_CAPACITY and the count) and then fetch into exactly sized buffers. */
 int da_match_fetch(da_ctx* ctx, int32_t* out_i, int32_t* out_v, double* out_q, int64_t n);
 
+/* Device-to-device hand-over of the resident match list, for the single-long-pair mode tiled over
+ * several GPUs: every rank matches its block of audio rows, exports its sorted
+ * list into device buffers of the communication library (RCCL all-gather over xGMI), and the gathered
+ * list -- concatenated in rank order it is sorted by (i, v) -- is imported as "the resident matches" of
+ * the context that runs the chain DP (da_chain_begin).  d_keys holds (i << 32 | v), d_q the qualities;
+ * both are DEVICE pointers.  da_match_import_device needs a da_match on the same pair first (any row
+ * range): the video row list of that match provides the video ranks. */
+int da_match_export_device(da_ctx* ctx, uint64_t* d_keys, double* d_q, int64_t n);
+int da_match_import_device(da_ctx* ctx, const uint64_t* d_keys, const double* d_q, int64_t n);
+
 /* Correlation values of the similarity GEMM for explicit (i, v) pairs, as the selected
  * precision computes them (testing/diagnostics: "similarity values within 1e-3").
  * corr receives [n][3].  Uses the feature rows of the last da_match call. */

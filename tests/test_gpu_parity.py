@@ -597,6 +597,37 @@ def test_resident_rows_fast_path_equals_uploaded_rows(ctx, native):
   assert ctx._resident_rows(0, vf) is None
 
 
+def test_match_list_device_export_import(ctx, native):
+  """The device-to-device hand-over used by the multi-GPU long-pair mode (RCCL buffers): the resident
+  match list exported into torch CUDA tensors equals the fetched one; imported back in two pieces
+  glued together, the device chain DP gives the path of the whole list."""
+  import torch
+  pair = cases.align_case("e180")
+  vf = ctx.features(pair.video, 0); af = ctx.features(pair.audio, 1)
+  mi, mv, mq = ctx.match(vf, af)
+  want = native.chain_host(mi, mv, mq)
+  n = len(mi)
+  keys = torch.zeros(n, dtype=torch.int64, device="cuda"); qual = torch.zeros(n, dtype=torch.float64, device="cuda")
+  ctx.match_export_device(keys.data_ptr(), qual.data_ptr(), n)
+  assert np.array_equal(keys.cpu().numpy(), (mi.astype(np.int64) << 32) | mv) and np.array_equal(qual.cpu().numpy(), mq)
+  # two "ranks": the audio-row halves matched separately, gathered on the device, imported
+  la = len(af[0]) - 41
+  parts_k, parts_q = [], []
+  for rows in ((0, la // 2), (la // 2, la)):
+    k = ctx.match_begin(vf, af, rows=rows); m = ctx.match_finish()
+    pk = torch.zeros(max(m, 1), dtype=torch.int64, device="cuda"); pq = torch.zeros(max(m, 1), dtype=torch.float64, device="cuda")
+    ctx.match_export_device(pk.data_ptr(), pq.data_ptr(), m)
+    parts_k.append(pk[:m]); parts_q.append(pq[:m])
+  all_k = torch.cat(parts_k); all_q = torch.cat(parts_q)
+  torch.cuda.synchronize()
+  assert torch.equal(all_k, keys) and torch.equal(all_q, qual)
+  ctx.match_import_device(all_k.data_ptr(), all_q.data_ptr(), int(all_k.numel()))
+  fi, fv, fq = ctx.match_fetch(n)                      # the imported list is "the resident match" in every respect
+  assert np.array_equal(fi, mi) and np.array_equal(fv, mv) and np.array_equal(fq, mq)
+  gi, gv = ctx.chain_resident()                         # (collecting the DP releases the list)
+  assert np.array_equal(gi, want[0]) and np.array_equal(gv, want[1])
+
+
 def test_async_pinned_upload_equals_blocking_upload(ctx, native):
   """da_host_alloc + da_pcm_upload_async (page-locked source, copy on the copy stream, the feature
   kernel waits on the device) gives the same rows as the blocking da_pcm_upload, for both layouts;

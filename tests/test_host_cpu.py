@@ -268,15 +268,34 @@ m = g.max_over_ranks(10.0 + g.rank)
 s = g.sum_over_ranks(float(len(mine)))
 assert m == 10.0 + g.world - 1, m
 assert s == 5.0, s
-# the one exchange step of the tiled single-pair mode: ragged per-rank match lists
+# the one exchange step of the tiled single-pair mode: ragged per-rank match lists gathered on rank 0
 import numpy as np
 n = 3 + 4 * g.rank
 mi = (np.arange(n) + 100 * g.rank).astype(np.int32); mv = (np.arange(n) * 4).astype(np.int32)
 mq = np.linspace(0.5, 50.0, n) + g.rank
-gi, gv, gq = g.all_gather_matches(mi, mv, mq)
-assert len(gi) == 3 + 7 and gi.dtype == np.int32 and gq.dtype == np.float64
-assert np.array_equal(gi[:3], np.arange(3)) and np.array_equal(gi[3:], np.arange(7) + 100)
-assert np.array_equal(gq[3:], np.linspace(0.5, 50.0, 7) + 1)
+class FakeCtx:                      # what Group.gather_matches_to_root needs of a context on the gloo path
+  _gathered = None
+  def match_fetch(self, k):
+    return mi[:k], mv[:k], mq[:k]
+ctx = FakeCtx()
+total = g.gather_matches_to_root(ctx, n)
+if g.rank == 0:
+  gi, gv, gq = ctx._gathered
+  assert total == 3 + 7 and gi.dtype == np.int32 and gq.dtype == np.float64
+  assert np.array_equal(gi[:3], np.arange(3)) and np.array_equal(gi[3:], np.arange(7) + 100)
+  assert np.array_equal(gv[3:], np.arange(7) * 4) and np.array_equal(gq[3:], np.linspace(0.5, 50.0, 7) + 1)
+else:
+  assert total is None and ctx._gathered is None
+# rank 0 finishes the pair alone and broadcasts the result; failures are raised everywhere
+res = (np.array([0.0, 1.5, 9.25]), np.array([0.5, 2.0, 9.0]), 87.5, np.arange(20.0).reshape(4, 5), 1.0001) if g.rank == 0 else None
+x, y, sim, path, med = g.broadcast_result(res)
+assert np.array_equal(x, [0.0, 1.5, 9.25]) and np.array_equal(y, [0.5, 2.0, 9.0]) and sim == 87.5 and med == 1.0001
+assert path.shape == (4, 5) and path[3, 4] == 19.0
+try:
+  g.broadcast_result(None, "Alignment failed, are the input files mismatched?" if g.rank == 0 else None)
+  raise SystemExit("no error raised")
+except RuntimeError as e:
+  assert "mismatched" in str(e)
 g.barrier()
 g.close()
 print("rank", g.rank, "ok", mine)
