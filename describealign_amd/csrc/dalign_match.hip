@@ -10,6 +10,8 @@
 // float64, applies the reference's hash vote (:649-660) in its closed form, and emits
 // (i, v, quality).
 #include "dalign_common.h"
+#include <cstdlib>
+#include <string>
 
 namespace da {
 
@@ -474,9 +476,13 @@ __device__ __forceinline__ void bf_tile(const bf16x8 (&A)[3][3], bf16x8 (&frag)[
   int row = 15;
 #pragma unroll
   for (int m = 0; m < 9; ++m) {
-    const int j = m / 3, s = m % 3;
+#ifdef DA_BF_CHAINED
+    const int j = m / 3, s = m % 3;                  // three dependent MFMAs per accumulator in a row
+#else
+    const int j = m % 3, s = m / 3;                  // accumulators interleaved: an MFMA never waits for the one before it
+#endif
     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][s], frag[j][s], acc[j], 0, 0, 0);
-    if (NEXT) *reinterpret_cast<uint4*>(&frag[j][s]) = *reinterpret_cast<const uint4*>(next_frags + m * 1024);
+    if (NEXT) *reinterpret_cast<uint4*>(&frag[j][s]) = *reinterpret_cast<const uint4*>(next_frags + (3 * j + s) * 1024);
 #ifndef DA_DBG_BF_NOEPI
     const int nrows = m < 7 ? 2 : 1;                 // 16 rows over 9 MFMA slots
 #pragma unroll
