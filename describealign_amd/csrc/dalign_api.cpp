@@ -91,7 +91,7 @@ struct da_ctx {
   unsigned long long next_ticket = 1;
   int64_t res_lv = 0;             // video frames of the last match (rank map size)
   DevBuf pair_i, pair_v, pair_c;
-  DevBuf ascaled, vscaled, band_y, band_q, band_part;
+  DevBuf ascaled, vscaled, band_y, band_q, band_part, band_tab, band_cl, band_keys, band_ids, band_head, band_out, band_tmp;
   bool match_ready = false;
   unsigned long long n_match_resident = 0;
   // state carried from da_match_begin to da_match_finish
@@ -227,7 +227,8 @@ void da_destroy(da_ctx* c) {
   }
   DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->counters, &c->keys0,
                    &c->q0, &c->sort_tmp, &c->rankmap, &c->rowscratch, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
-                   &c->band_y, &c->band_q, &c->band_part};
+                   &c->band_y, &c->band_q, &c->band_part, &c->band_tab, &c->band_cl, &c->band_keys, &c->band_ids, &c->band_head,
+                   &c->band_out, &c->band_tmp};
   for (DevBuf* b : all) b->release();
   for (ChainSlot* sl : c->slots) { if (sl->stream) (void)hipStreamSynchronize(sl->stream); sl->release(); delete sl; }
   c->slots.clear();
@@ -1045,80 +1046,130 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
   double a_max = -1e300, v_max = -1e300;                                  // (:908-909)
   for (int64_t i = 0; i < La; ++i) a_max = std::max(a_max, a_scaled[3 * i]);
   for (int64_t i = 0; i < Lv; ++i) v_max = std::max(v_max, v_scaled[3 * i]);
-  const int kRefBlocks = 256;
-  HIP_TRY(c, c->band_part.ensure(sizeof(double) * 4 * kRefBlocks));
-  HIP_TRY(c, c->band_y.ensure(sizeof(double) * (size_t)La)); HIP_TRY(c, c->band_q.ensure(sizeof(double) * (size_t)La));
-  std::vector<double> ys((size_t)La), qs((size_t)La), part(4 * kRefBlocks);
-  std::vector<std::vector<BandPoint>> rows((size_t)La);
-  std::unordered_set<uint64_t> seen;
-  double kernel_ms = 0.0;
-  int64_t total_points = 0;
+  BandArgs base{};
+  base.a_scaled = c->ascaled.as<double>(); base.La = La; base.v_scaled = c->vscaled.as<double>(); base.Lv = Lv;
+  base.a_max = a_max; base.v_max = v_max;
   const int64_t extend = (int64_t)kFrameRate * 30;
+  const int kRefBlocks = 64;
+
+  // ---- every cluster's line, one launch per step (no per-cluster round trips)
+  struct Job { int ci; double offset, slope, xf, xl; int64_t lo, hi; bool refine; };
+  std::vector<Job> jobs;
   for (int ci = 0; ci < n_clusters; ++ci) {
-    double offset = cl_offset[ci];
-    const double slope = cl_slope[ci];
-    double xf = cl_x0[ci], xl = cl_x1[ci];
-    int64_t lo, hi;
-    x_limits(xf, xl, offset, slope, La, Lv, 0, lo, hi);
-    if (hi < lo + 5) continue;                                            // (:914-915)
-    BandArgs b{};
-    b.a_scaled = c->ascaled.as<double>(); b.La = La; b.v_scaled = c->vscaled.as<double>(); b.Lv = Lv;
-    b.slope = slope; b.a_max = a_max; b.v_max = v_max;
-    if (hi > lo + 100) {                                                  // (:916-930)
-      b.offset = offset; b.lo = lo; b.hi = hi;
-      HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-      launch_band_refine(b, c->band_part.as<double>(), kRefBlocks, c->stream);
-      HIP_TRY(c, hipGetLastError());
-      HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-      HIP_TRY(c, hipMemcpyAsync(part.data(), c->band_part.p, sizeof(double) * 4 * kRefBlocks, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-      float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); kernel_ms += ms;
-      double cnt = 0, sde = 0, sdd = 0, see = 0;
-      for (int k = 0; k < kRefBlocks; ++k) { cnt += part[4 * k]; sde += part[4 * k + 1]; sdd += part[4 * k + 2]; see += part[4 * k + 3]; }
-      if (cnt > 50 && sdd > 0 && see > 0) {
-        const double sol = sde / sdd;
-        const double resid = see - sol * sde;
-        const double explained = 1.0 - resid / see;
-        const double z = std::sqrt(explained * 3.0 * cnt) - 1.0;
-        if (z > 8 && std::fabs(sol) < 2) offset += sol;
-      }
-      xf = (double)lo; xl = (double)(hi - 1);       // the reference rebinds x to arange(lo, hi) here (:917)
-    }
-    x_limits(xf, xl, offset, slope, La, Lv, extend, lo, hi);
-    if (hi <= lo) continue;
-    b.offset = offset; b.lo = lo; b.hi = hi;
+    Job j{ci, cl_offset[ci], cl_slope[ci], cl_x0[ci], cl_x1[ci], 0, 0, false};
+    x_limits(j.xf, j.xl, j.offset, j.slope, La, Lv, 0, j.lo, j.hi);
+    if (j.hi < j.lo + 5) continue;                                        // (:914-915)
+    j.refine = j.hi > j.lo + 100;                                         // (:916)
+    jobs.push_back(j);
+  }
+  const int nj = (int)jobs.size();
+  std::vector<BandCluster> tab((size_t)std::max(1, nj));
+  HIP_TRY(c, c->band_tab.ensure(sizeof(BandCluster) * tab.size()));
+  float ms = 0.f; double kernel_ms = 0.0;
+  if (nj > 0) {
+    for (int k = 0; k < nj; ++k) tab[k] = BandCluster{jobs[k].offset, jobs[k].slope, jobs[k].lo, jobs[k].hi, 0, jobs[k].refine ? 1 : 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(c->band_tab.p, tab.data(), sizeof(BandCluster) * nj, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, c->band_part.ensure(sizeof(double) * 4 * kRefBlocks * nj));
+    std::vector<double> part((size_t)4 * kRefBlocks * nj);
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    launch_band_quality(b, c->band_y.as<double>(), c->band_q.as<double>(), c->stream);
+    launch_band_refine_all(base, c->band_tab.as<BandCluster>(), nj, c->band_part.as<double>(), kRefBlocks, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    const size_t n = (size_t)(hi - lo);
-    HIP_TRY(c, hipMemcpyAsync(ys.data(), c->band_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(qs.data(), c->band_q.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(part.data(), c->band_part.p, sizeof(double) * part.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); kernel_ms += ms;
-    for (size_t k = 0; k < n; ++k) {                                      // (:937-941)
-      const int64_t i = lo + (int64_t)k;
-      const uint64_t key = ((uint64_t)i << 32) | (uint32_t)(int64_t)ys[k];
-      if (seen.insert(key).second) { rows[i].push_back(BandPoint{ys[k], (int32_t)i, ci, qs[k]}); ++total_points; }
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); kernel_ms += ms;
+    for (int k = 0; k < nj; ++k) {
+      Job& j = jobs[k];
+      if (j.refine) {                                                     // (:916-930)
+        double cnt = 0, sde = 0, sdd = 0, see = 0;
+        for (int b = 0; b < kRefBlocks; ++b) {
+          const double* p4 = &part[4 * ((size_t)k * kRefBlocks + b)];
+          cnt += p4[0]; sde += p4[1]; sdd += p4[2]; see += p4[3];
+        }
+        if (cnt > 50 && sdd > 0 && see > 0) {
+          const double sol = sde / sdd;
+          const double resid = see - sol * sde;
+          const double explained = 1.0 - resid / see;
+          const double z = std::sqrt(explained * 3.0 * cnt) - 1.0;
+          if (z > 8 && std::fabs(sol) < 2) j.offset += sol;
+        }
+        j.xf = (double)j.lo; j.xl = (double)(j.hi - 1);                   // the reference rebinds x to arange(lo, hi) here (:917)
+      }
+      x_limits(j.xf, j.xl, j.offset, j.slope, La, Lv, extend, j.lo, j.hi);
     }
+  }
+  int64_t n_all = 0;
+  int nk = 0;
+  for (int k = 0; k < nj; ++k) {
+    const Job& j = jobs[k];
+    if (j.hi <= j.lo) continue;
+    tab[nk] = BandCluster{j.offset, j.slope, j.lo, j.hi, n_all, 0, j.ci};          // pad carries the caller's cluster index
+    n_all += j.hi - j.lo; ++nk;
+  }
+  // ---- quality of every banded point, de-duplication on (audio frame, int(video position)) keeping
+  // the first cluster's point (:937-941), in (audio frame, video position) order -- all on the device
+  std::vector<BandPoint> pts;
+  int64_t total_points = 0;
+  if (n_all > 0x7fffffffLL) return fail(c, DA_ERR_ARG, "da_refine: %lld banded points exceed the kernels' range", (long long)n_all);
+  if (n_all > 0) {
+    const size_t n = (size_t)n_all;
+    HIP_TRY(c, c->band_y.ensure(sizeof(double) * n)); HIP_TRY(c, c->band_q.ensure(sizeof(double) * n));
+    HIP_TRY(c, c->band_cl.ensure(sizeof(int32_t) * n)); HIP_TRY(c, c->band_keys.ensure(sizeof(unsigned long long) * 2 * n));
+    HIP_TRY(c, c->band_ids.ensure(sizeof(int32_t) * 3 * n + 64)); HIP_TRY(c, c->band_head.ensure(n));
+    HIP_TRY(c, c->band_out.ensure((sizeof(double) * 2 + sizeof(int32_t) * 2) * n));
+    unsigned long long* keys = c->band_keys.as<unsigned long long>(); unsigned long long* keys_s = keys + n;
+    int32_t* ids = c->band_ids.as<int32_t>(); int32_t* ids_s = ids + n; int32_t* kept = ids + 2 * n;
+    int32_t* d_cnt = c->counters.as<int32_t>() + 12;                      // bytes 48..51 of `counters`
+    size_t t1 = 0, t2 = 0;
+    if (sort_keys_ids(nullptr, nullptr, nullptr, nullptr, n_all, nullptr, &t1, c->stream) != 0 ||
+        select_flagged_ids(nullptr, nullptr, nullptr, nullptr, n_all, nullptr, &t2, c->stream) != 0)
+      return fail(c, DA_ERR_DEVICE, "da_refine: scratch sizing failed");
+    size_t tb = std::max(t1, t2);
+    HIP_TRY(c, c->band_tmp.ensure(tb + 256));
+    HIP_TRY(c, hipMemcpyAsync(c->band_tab.p, tab.data(), sizeof(BandCluster) * nk, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    launch_band_quality_all(base, c->band_tab.as<BandCluster>(), nk, n_all, c->band_y.as<double>(), c->band_q.as<double>(),
+                            c->band_cl.as<int32_t>(), keys, ids, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    if (sort_keys_ids(keys, keys_s, ids, ids_s, n_all, c->band_tmp.p, &tb, c->stream) != 0) return fail(c, DA_ERR_DEVICE, "da_refine: sort failed");
+    launch_band_heads(keys_s, n_all, c->band_head.as<uint8_t>(), c->stream);
+    tb = std::max(t1, t2);
+    if (select_flagged_ids(ids_s, c->band_head.as<uint8_t>(), kept, d_cnt, n_all, c->band_tmp.p, &tb, c->stream) != 0)
+      return fail(c, DA_ERR_DEVICE, "da_refine: selection failed");
+    double* o_j = c->band_out.as<double>(); double* o_q = o_j + n;
+    int32_t* o_i = reinterpret_cast<int32_t*>(o_q + n); int32_t* o_cl = o_i + n;
+    launch_band_gather(kept, d_cnt, c->band_y.as<double>(), c->band_q.as<double>(), c->band_cl.as<int32_t>(), keys, o_j, o_q, o_i, o_cl, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    int32_t n_kept = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_kept, d_cnt, sizeof n_kept, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); kernel_ms += ms;
+    total_points = n_kept;
+    std::vector<double> hj((size_t)n_kept), hq((size_t)n_kept);
+    std::vector<int32_t> hi_((size_t)n_kept), hcl((size_t)n_kept);
+    if (n_kept > 0) {
+      HIP_TRY(c, hipMemcpyAsync(hj.data(), o_j, sizeof(double) * n_kept, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(hq.data(), o_q, sizeof(double) * n_kept, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(hi_.data(), o_i, sizeof(int32_t) * n_kept, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(hcl.data(), o_cl, sizeof(int32_t) * n_kept, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    pts.resize((size_t)n_kept);
+    for (int32_t t = 0; t < n_kept; ++t) pts[t] = BandPoint{hj[t], hi_[t], tab[hcl[t]].pad, hq[t]};
   }
   c->st.refine_kernel_ms = kernel_ms;
   c->st.refine_points = (double)total_points;
   if (n_points) *n_points = total_points;
   const double t0 = now_ms();
-  std::vector<BandPoint> pts; pts.reserve((size_t)total_points);
   std::vector<int64_t> row_start((size_t)La + 1, 0);
-  for (int64_t i = 0; i < La; ++i) {
-    auto& r = rows[i];
-    std::sort(r.begin(), r.end(), [](const BandPoint& x, const BandPoint& y) {
-      if (x.j != y.j) return x.j < y.j;
-      if (x.cl != y.cl) return x.cl < y.cl;
-      return x.q < y.q;
-    });
-    row_start[i] = (int64_t)pts.size();
-    pts.insert(pts.end(), r.begin(), r.end());
+  {
+    size_t p = 0;
+    for (int64_t i = 0; i <= La; ++i) {
+      while (p < pts.size() && pts[p].i < i) ++p;
+      row_start[i] = (int64_t)p;
+    }
   }
-  row_start[La] = (int64_t)pts.size();
   std::vector<double> out;
   second_dp(pts, row_start, La, Lv, n_clusters, out);
   c->st.refine_dp_ms = now_ms() - t0;

@@ -128,6 +128,26 @@ void launch_band_refine(const BandArgs& a, double* d_partials, int n_blocks, hip
 void launch_band_quality(const BandArgs& a, double* d_y, double* d_q, hipStream_t s);
 void launch_colmax(const double* d, int64_t n, int stride, double* d_out, hipStream_t s);
 
+// pass 2 with every cluster in one launch
+struct BandCluster {
+  double offset, slope;
+  int64_t lo, hi;         // audio frames [lo, hi)
+  int64_t first;          // index of this cluster's first point in the concatenated point arrays
+  int32_t refine;         // 1: long enough for the sub-frame refinement (:916)
+  int32_t pad;
+};
+void launch_band_refine_all(const BandArgs& base, const BandCluster* d_cl, int n_clusters, double* d_partials, int n_blocks, hipStream_t s);
+void launch_band_quality_all(const BandArgs& base, const BandCluster* d_cl, int n_clusters, int64_t n_points, double* d_y, double* d_q,
+                             int32_t* d_cl_of, unsigned long long* d_keys, int32_t* d_ids, hipStream_t s);
+void launch_band_heads(const unsigned long long* d_sorted_keys, int64_t n, uint8_t* d_head, hipStream_t s);
+void launch_band_gather(const int32_t* d_kept, const int32_t* d_n_kept, const double* d_y, const double* d_q, const int32_t* d_cl_of,
+                        const unsigned long long* d_keys_unsorted, double* o_j, double* o_q, int32_t* o_i, int32_t* o_cl, hipStream_t s);
+// stable radix sort of (key, id) pairs and selection of flagged ids (hipCUB); temp sizing with d_temp = nullptr
+int sort_keys_ids(const unsigned long long* keys_in, unsigned long long* keys_out, const int32_t* ids_in, int32_t* ids_out, int64_t n,
+                  void* temp, size_t* temp_bytes, hipStream_t s);
+int select_flagged_ids(const int32_t* ids, const uint8_t* flags, int32_t* out, int32_t* d_count, int64_t n, void* temp, size_t* temp_bytes,
+                       hipStream_t s);
+
 // ---- stage-2 chain DP on the device (dalign_chain.hip) ---------------------------------------
 struct ChainArgs {                         // k_chain_forward
   const double* q; const int32_t* rank;    // per match, sorted by (i, v); rank = 1-based video rank

@@ -1021,6 +1021,113 @@ void launch_band_quality(const BandArgs& a, double* d_y, double* d_q, hipStream_
   hipLaunchKernelGGL(k_band_quality, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, d_y, d_q);
 }
 
+// ---- pass 2, all clusters in one launch -------------------------------------------------------
+// blockIdx.y = cluster: the sub-frame refinement sums of every long cluster (:916-930)
+__global__ __launch_bounds__(256) void k_band_refine_all(BandArgs base, const BandCluster* __restrict__ cl, double* __restrict__ partials) {
+  const BandCluster c = cl[blockIdx.y];
+  double cnt = 0, sde = 0, sdd = 0, see = 0;
+  if (c.refine) {
+    BandArgs a = base;
+    a.offset = c.offset; a.slope = c.slope; a.lo = c.lo; a.hi = c.hi;
+    for (int64_t x = a.lo + 1 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < a.hi - 1;
+         x += (int64_t)gridDim.x * blockDim.x) {
+      double vm[3], vp[3], vn[3];
+      interp3(a.v_scaled, a.Lv, a.slope * (double)x + a.offset, vm);
+      interp3(a.v_scaled, a.Lv, a.slope * (double)(x - 1) + a.offset, vp);
+      interp3(a.v_scaled, a.Lv, a.slope * (double)(x + 1) + a.offset, vn);
+      const double* am = a.a_scaled + 3 * x;
+      double e[3], mean = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { e[k] = am[k] - vm[k]; mean += e[k]; }
+      mean /= 3.0;
+      if (mean < 0.1) {
+        cnt += 1.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double d = (vn[k] - vp[k]) / 2.0;
+          sde = fma(d, e[k], sde); sdd = fma(d, d, sdd); see = fma(e[k], e[k], see);
+        }
+      }
+    }
+  }
+  __shared__ double red[4][256];
+  red[0][threadIdx.x] = cnt; red[1][threadIdx.x] = sde; red[2][threadIdx.x] = sdd; red[3][threadIdx.x] = see;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 4; ++k) partials[4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + k] = red[k][0];
+}
+void launch_band_refine_all(const BandArgs& base, const BandCluster* d_cl, int n_clusters, double* d_partials, int n_blocks, hipStream_t s) {
+  if (n_clusters <= 0) return;
+  hipLaunchKernelGGL(k_band_refine_all, dim3(n_blocks, n_clusters), dim3(256), 0, s, base, d_cl, d_partials);
+}
+
+// one thread per banded point of ANY cluster (clusters laid out one after another: first[c] = prefix of
+// their lengths): video position y, quality (:931-936), and the key (audio frame << 32 | int(y)) the
+// reference de-duplicates on (:937-941)
+__global__ __launch_bounds__(256) void k_band_quality_all(BandArgs base, const BandCluster* __restrict__ cl, int n_clusters, int64_t n_points,
+                                                          double* __restrict__ ys, double* __restrict__ qs, int32_t* __restrict__ cls,
+                                                          unsigned long long* __restrict__ keys, int32_t* __restrict__ ids) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_points) return;
+  int lo = 0, hi = n_clusters - 1;                      // last cluster with first <= p
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (cl[mid].first <= p) lo = mid; else hi = mid - 1;
+  }
+  const BandCluster c = cl[lo];
+  const int64_t x = c.lo + (p - c.first);
+  const double y = c.slope * (double)x + c.offset;
+  double vm[3];
+  interp3(base.v_scaled, base.Lv, y, vm);
+  const double* am = base.a_scaled + 3 * x;
+  double q = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) q += -0.5 - log10(1e-4 + fabs(am[k] - vm[k]));
+  double g = vm[0] + 2.5 - base.v_max; g = g < 0 ? 0 : (g > 1 ? 1 : g);
+  q *= g;
+  double ga = am[0] + 2.5 - base.a_max; ga = ga < 0 ? 0 : (ga > 1 ? 1 : ga);
+  q += ga * 0.1;
+  ys[p] = y; qs[p] = q; cls[p] = lo;
+  keys[p] = ((unsigned long long)(uint32_t)x << 32) | (uint32_t)(int64_t)y;
+  ids[p] = (int32_t)p;
+}
+void launch_band_quality_all(const BandArgs& base, const BandCluster* d_cl, int n_clusters, int64_t n_points, double* d_y, double* d_q,
+                             int32_t* d_cl_of, unsigned long long* d_keys, int32_t* d_ids, hipStream_t s) {
+  if (n_points <= 0) return;
+  hipLaunchKernelGGL(k_band_quality_all, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, s, base, d_cl, n_clusters, n_points,
+                     d_y, d_q, d_cl_of, d_keys, d_ids);
+}
+
+// after the stable sort by key: the first point of every key is the one the reference keeps (clusters
+// are visited in order); gather the kept points' fields in key order = (audio frame, video position) order
+__global__ __launch_bounds__(256) void k_band_heads(const unsigned long long* __restrict__ keys, int64_t n, uint8_t* __restrict__ head) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) head[t] = (t == 0 || keys[t] != keys[t - 1]) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_band_gather(const int32_t* __restrict__ kept, const int32_t* __restrict__ n_kept,
+                                                     const double* __restrict__ ys, const double* __restrict__ qs, const int32_t* __restrict__ cls,
+                                                     const unsigned long long* __restrict__ keys_unsorted, double* __restrict__ o_j,
+                                                     double* __restrict__ o_q, int32_t* __restrict__ o_i, int32_t* __restrict__ o_cl) {
+  const int32_t n = *n_kept;
+  for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const int32_t p = kept[t];
+    o_j[t] = ys[p]; o_q[t] = qs[p]; o_cl[t] = cls[p]; o_i[t] = (int32_t)(keys_unsorted[p] >> 32);
+  }
+}
+void launch_band_heads(const unsigned long long* d_sorted_keys, int64_t n, uint8_t* d_head, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_band_heads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_sorted_keys, n, d_head);
+}
+void launch_band_gather(const int32_t* d_kept, const int32_t* d_n_kept, const double* d_y, const double* d_q, const int32_t* d_cl_of,
+                        const unsigned long long* d_keys_unsorted, double* o_j, double* o_q, int32_t* o_i, int32_t* o_cl, hipStream_t s) {
+  hipLaunchKernelGGL(k_band_gather, dim3(512), dim3(256), 0, s, d_kept, d_n_kept, d_y, d_q, d_cl_of, d_keys_unsorted, o_j, o_q, o_i, o_cl);
+}
+
 __global__ void k_colmax(const double* __restrict__ d, int64_t n, int stride, double* out) {
   __shared__ double red[256];
   double m = -1e300;

@@ -14,6 +14,18 @@ int sort_pairs(unsigned long long* keys_in, unsigned long long* keys_out, double
   return e == hipSuccess ? 0 : -1;
 }
 
+int sort_keys_ids(const unsigned long long* keys_in, unsigned long long* keys_out, const int32_t* ids_in, int32_t* ids_out, int64_t n,
+                  void* temp, size_t* temp_bytes, hipStream_t s) {
+  if (n > 0x7fffffffLL) return -1;
+  return hipcub::DeviceRadixSort::SortPairs(temp, *temp_bytes, keys_in, keys_out, ids_in, ids_out, (int)n, 0, 64, s) == hipSuccess ? 0 : -1;
+}
+
+int select_flagged_ids(const int32_t* ids, const uint8_t* flags, int32_t* out, int32_t* d_count, int64_t n, void* temp, size_t* temp_bytes,
+                       hipStream_t s) {
+  if (n > 0x7fffffffLL) return -1;
+  return hipcub::DeviceSelect::Flagged(temp, *temp_bytes, ids, flags, out, d_count, (int)n, s) == hipSuccess ? 0 : -1;
+}
+
 // ---- row lists of the matching stage, built on the device from a resident energy row ----------
 // describealign.py:629-630 (every 4th non-quiet video frame) and :657-658 (non-quiet audio frames
 // inside the requested row range): frames i in [lo, hi) with energy[i] > 0.5, in order.
