@@ -18,8 +18,9 @@ Workloads (BASELINE.json configs):
 
 Timed region (steady state of a directory batch).  The pairs go through ONE primed pipeline: an
 untimed lead-in of max(W, two LP solves per host worker) pairs, K timed pairs and a tail that keeps
-the pipeline full are submitted as one stream; results come back in order; the clock runs from the
-arrival of the last lead-in result to the arrival of the K-th result after it.  (The lead-in is
+the pipeline full are submitted as one stream; the clock runs from the completion of the lead-in's last
+pair to the completion of K more pairs (completion times, not in-order delivery times: one slow LP solve
+holds back the delivery of the finished pairs behind it and then releases them in a burst).  (The lead-in is
 longer than --warmup because a pair spends ~9 s in the host LP but only ~0.3 s on the GPU: the first
 results of a fresh pipeline come out in a burst at the GPU stage's rate, before the LP stage has had
 to sustain anything; `--prime 0` disables it.)  A barrier and a
@@ -201,6 +202,14 @@ class Bench:
             t1 = now
     self.sync()
     t_end = time.perf_counter()
+    if pipe is not None:
+      # The clock is read on COMPLETION times, not on delivery: results are handed back in submission
+      # order, so one slow LP solve holds back the finished pairs behind it and releases them in a
+      # burst -- over 20 pairs that is +-25 % of noise.  t0 = the moment the lead-in's last pair
+      # completed, t1 = the moment K more pairs had completed (whichever pairs those were).
+      done_times = sorted(tm["done_t"] for tm in tms)
+      t0 = done_times[warmup - 1] if warmup > 0 else t_start
+      t1 = done_times[warmup + steps - 1]
     elapsed = grp.max_over_ranks(t1 - t0)
     out = outs[warmup + steps - 1]
     sel = tms[warmup:warmup + steps]

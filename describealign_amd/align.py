@@ -852,6 +852,7 @@ class AlignPipeline:
     ctx = self._thread_ctx()
     _, _, _, _, a_s, v_s = _block_views(state["mm"], state["lay"], *dims)
     out = _stage_refine(ctx, dict(median_slope=med), a_s, v_s, dims[0], dims[2], tm, clusters=clusters)
+    tm["done_t"] = time.perf_counter()          # completion time (results are DELIVERED in submission order, later)
     del a_s, v_s
     mm = state.pop("mm")
     del mm

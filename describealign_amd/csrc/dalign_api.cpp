@@ -773,7 +773,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
   HIP_TRY(c, sl.rank.ensure(sizeof(int32_t) * nn)); HIP_TRY(c, sl.flags.ensure(nn));
   HIP_TRY(c, sl.rows.ensure(sizeof(int32_t) * (nn + 1))); HIP_TRY(c, sl.pred.ensure(sizeof(int32_t) * nn));
   HIP_TRY(c, sl.ids.ensure(sizeof(int32_t) * nn)); HIP_TRY(c, sl.out_iv.ensure(sizeof(int32_t) * 2 * nn));
-  HIP_TRY(c, sl.tree.ensure(16 * ((size_t)sl.n_ranks + 2 + 64)));        // + one scrap record per lane
+  HIP_TRY(c, sl.tree.ensure(16 * ((size_t)sl.n_ranks + 2 + 256)));       // + one scrap record per thread
   HIP_TRY(c, sl.small.ensure(128));
   const size_t tb = da::chain_rows_temp_bytes(n);
   HIP_TRY(c, sl.temp.ensure(tb + 256));
@@ -797,6 +797,13 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
   }
   HIP_TRY(c, hipMemsetAsync(sl.small.p, 0, 128, c->stream));
   HIP_TRY(c, hipMemsetAsync(sl.tree.p, 0, 16 * ((size_t)sl.n_ranks + 2), c->stream));
+  {
+    // four wavefronts per row super-step (256 matches at a time) unless the input is tiny or
+    // DALIGN_CHAIN_WAVES=1 asks for the one-wavefront kernel: 1.76 s instead of 3.0 s per 2 h pair
+    // (255 matches per row), 157 instead of 192 ms per 22 min pair (55 per row)
+    const char* force = std::getenv("DALIGN_CHAIN_WAVES");
+    L.wide = force ? (std::atoi(force) >= 4) : (n >= 4096);
+  }
   if (da::launch_chain_prep(L, c->stream) != 0) return fail(c, DA_ERR_ARG, "da_chain: %lld matches / %lld video rows exceed the kernel's range", (long long)n, (long long)sl.n_ranks);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipEventRecord(sl.ready, c->stream));

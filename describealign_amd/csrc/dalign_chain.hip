@@ -33,7 +33,7 @@ namespace da {
 
 namespace {
 
-constexpr int kScrap = 64;         // scrap records behind either part of the tree, one per lane
+constexpr int kScrap = 256;        // scrap records behind either part of the tree, one per thread (up to 4 wavefronts)
 constexpr int kLowMax = 8;        // S <= 8 lowest tree levels in global memory; up to 16 levels in LDS: ranks < 2^24
 
 __device__ __forceinline__ bool beats(double ac, uint32_t ai, double bc, uint32_t bi) {
@@ -291,6 +291,155 @@ __global__ __launch_bounds__(64) void k_chain_forward(ChainArgs a) {
 #endif
 }
 
+// Four-wavefront form for wide rows (a 2 h pair has ~255 matches per audio row): a "super-step" takes up
+// to 256 matches of one row, 64 per wavefront.  Tree loads, reductions and tree updates of the four
+// chunks run in parallel on the CU's four SIMDs (every query of a row sees the tree as it was when the
+// row began; what the row's own earlier matches contribute is exactly the left neighbour in the Jacobi
+// chain, so only that chain is sequential: the wavefronts take turns, handing the running sum on
+// through LDS).  The node sets written by the lanes of a super-step are disjoint across wavefronts too:
+// the walk-stop rule uses the rank of the next match of the row, whichever wavefront holds it.
+constexpr int kW4 = 4;
+template <int LOW, int HIGH>
+__global__ __launch_bounds__(64 * kW4) void k_chain_forward_w4(ChainArgs a) {
+  if (!chain_block_elected(a)) return;
+  extern __shared__ uint4 s_hi[];
+  __shared__ double s_carry, s_best_c;
+  __shared__ uint32_t s_best_i, s_best_r;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const uint32_t n_ranks = (uint32_t)a.n_ranks;
+  constexpr int S = LOW;
+  const uint32_t H = n_ranks >> S;
+  for (uint32_t h = tid; h <= H; h += 64 * kW4) s_hi[h] = uint4{0u, 0u, 0u, 0u};
+  const double NEG = -1.0e300;
+  if (tid == 0) { s_carry = NEG; s_best_c = 0.0; s_best_i = 0u; s_best_r = 0xFFFFFFFFu; }
+  __syncthreads();
+  uint4* __restrict__ lo = a.tree_lo;
+  const int32_t n_rows = *a.d_nrows;
+  constexpr uint32_t lowmask = (1u << S) - 1u;
+  const int32_t n = (int32_t)a.n;
+
+  int32_t rs_base = 0;
+  auto load_block = [&](int32_t base) -> int32_t {
+    const int32_t j = base + lane;
+    return j < n_rows ? a.row_start[j] : n;
+  };
+  int32_t rs_cur = load_block(0), rs_nxt = load_block(64);
+  auto rs = [&](int32_t j) -> int32_t {
+    const int32_t o = j - rs_base;
+    return o < 64 ? __builtin_amdgcn_readlane(rs_cur, o) : __builtin_amdgcn_readlane(rs_nxt, o - 64);
+  };
+  int32_t row = 0;
+  int32_t rb = n_rows > 0 ? rs(0) : 0, re = n_rows > 0 ? rs(1) : 0;
+  int32_t c = rb;
+  // this thread's match of the super-step (video rank, quality, rank of the row's next match), prefetched
+  auto fetch = [&](int32_t base, int32_t end, uint32_t& r, double& q, uint32_t& rn) {
+    const int32_t k = base + tid;
+    r = 0u; q = 0.0; rn = 0xFFFFFFFFu;
+    if (k < end) { r = (uint32_t)a.rank[k]; q = a.q[k]; if (k + 1 < end) rn = (uint32_t)a.rank[k + 1]; }
+  };
+  uint32_t r_cur, rn_cur; double q_cur;
+  fetch(c, re, r_cur, q_cur, rn_cur);
+
+  while (row < n_rows) {
+    const int cnt_all = (re - c) < 64 * kW4 ? (re - c) : 64 * kW4;
+    const int nw = (cnt_all + 63) >> 6;                 // wavefronts with matches in this super-step
+    const int cnt = cnt_all - 64 * wave < 0 ? 0 : (cnt_all - 64 * wave > 64 ? 64 : cnt_all - 64 * wave);
+    const int32_t k = c + tid;
+    const bool valid = lane < cnt;
+    const uint32_t r = valid ? r_cur : 0u;
+    const double qv = valid ? q_cur : 0.0;
+    const uint32_t rnext = valid ? rn_cur : 0xFFFFFFFFu;
+    const double best_c = s_best_c; const uint32_t best_i = s_best_i, best_r = s_best_r;     // as the last super-step left them
+    const bool same_row = c + 64 * kW4 < re;
+    if (!same_row && row + 1 - rs_base >= 64) { rs_base += 64; rs_cur = rs_nxt; rs_nxt = load_block(rs_base + 64); }
+    const int32_t n_c = same_row ? c + 64 * kW4 : re;
+    const int32_t n_re = same_row ? re : (row + 1 < n_rows ? rs(row + 2) : n);
+
+    const bool no_query = __all(!valid || r >= best_r);
+    uint4 ql[LOW], qh[HIGH], ul[LOW], uh[HIGH];
+    uint32_t uli[LOW], uhi[HIGH];
+    if (!no_query) {
+#pragma unroll
+      for (int t = 0; t < LOW; ++t) ql[t] = lo[(r & (1u << t)) ? (r & ~((1u << t) - 1u)) : 0u];
+      const uint32_t rh = r >> S;
+#pragma unroll
+      for (int t = 0; t < HIGH; ++t) qh[t] = s_hi[(rh & (1u << t)) ? (rh & ~((1u << t) - 1u)) : 0u];
+    }
+    {
+      const uint32_t limit = valid ? (rnext <= n_ranks ? rnext : n_ranks + 1u) : 0u;
+#pragma unroll
+      for (int t = 0; t < LOW; ++t) {
+        const uint32_t y = (r + ((1u << t) - 1u)) & ~((1u << t) - 1u);
+        uli[t] = ((y & (1u << t)) && y < limit) ? y : 0u;
+        ul[t] = lo[uli[t]];
+      }
+      const uint32_t rh = (r + lowmask) >> S;
+      const uint32_t limit_h = (limit + lowmask) >> S;
+#pragma unroll
+      for (int t = 0; t < HIGH; ++t) {
+        const uint32_t y = (rh + ((1u << t) - 1u)) & ~((1u << t) - 1u);
+        uhi[t] = ((y & (1u << t)) && y < limit_h) ? y : 0u;
+        uh[t] = s_hi[uhi[t]];
+      }
+    }
+    uint32_t r_nx, rn_nx; double q_nx;
+    fetch(n_c, n_re, r_nx, q_nx, rn_nx);
+    double gc = best_c; uint32_t gi = best_i;
+    if (!no_query) {
+      gc = 0.0; gi = 0u;
+#pragma unroll
+      for (int t = 0; t < LOW; ++t) gc = max_f64(gc, node_cum(ql[t]));
+#pragma unroll
+      for (int t = 0; t < HIGH; ++t) gc = max_f64(gc, node_cum(qh[t]));
+#pragma unroll
+      for (int t = 0; t < LOW; ++t) gi = (node_cum(ql[t]) == gc && ql[t].z > gi) ? ql[t].z : gi;
+#pragma unroll
+      for (int t = 0; t < HIGH; ++t) gi = (node_cum(qh[t]) == gc && qh[t].z > gi) ? qh[t].z : gi;
+    }
+    // ---- the row's own chain: the wavefronts take turns, the running sum travels through LDS
+    double f = NEG, carry = NEG;
+    for (int t = 0; t < nw; ++t) {
+      if (wave == t) {
+        carry = s_carry;
+        const double ge = lane == 0 ? max_f64(gc, carry) : gc;
+        f = qv + ge;
+        for (int it = 1; it < cnt; it += 8) {
+          const double f0 = f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) f = qv + max_f64(ge, left_neighbour(f));
+          if (!__any(valid && f != f0)) break;
+        }
+        const double fl = read_lane(f, cnt - 1);
+        if (lane == 0) s_carry = fl;
+      }
+      __syncthreads();
+    }
+    const double fleft = left_neighbour(f);
+    const double fp = lane == 0 ? carry : fleft;
+    const bool from_row = fp >= gc;
+    const uint32_t id1 = (uint32_t)k + 1u;
+    if (valid) a.pred[k] = from_row ? (k - 1) : ((int32_t)gi - 1);
+    {
+      const uint4 me = make_node(f, id1);
+#pragma unroll
+      for (int t = 0; t < LOW; ++t)
+        lo[(uli[t] != 0u && f >= node_cum(ul[t])) ? uli[t] : n_ranks + 1u + tid] = me;
+#pragma unroll
+      for (int t = 0; t < HIGH; ++t)
+        s_hi[(uhi[t] != 0u && f >= node_cum(uh[t])) ? uhi[t] : H + 1u + tid] = me;
+    }
+    if (wave == nw - 1 && lane == cnt - 1) {            // the super-step's last match carries the row's largest sum so far
+      if (f >= best_c) { s_best_c = f; s_best_i = id1; s_best_r = r; }
+      if (!same_row) s_carry = NEG;                      // next super-step starts a new row
+    }
+    __syncthreads();                                     // tree, best and carry are published
+    if (!same_row) ++row;
+    c = n_c; re = n_re; r_cur = r_nx; q_cur = q_nx; rn_cur = rn_nx;
+  }
+  if (tid == 0) { a.meta[0] = (int64_t)s_best_i - 1; a.meta[1] = 0; }
+}
+
 // Back-track from the heaviest point through pred[] (:690-697).  The chain's ids decrease, and a
 // predecessor is rarely more than a few rows back, so pred[] is pulled through LDS in windows of
 // kBackWindow ids and chased there by one lane; ids are staged and written out coalesced.
@@ -385,11 +534,23 @@ int launch_chain_dp(const ChainLaunch& c, hipStream_t s) {
     hipLaunchKernelGGL(kernel, dim3(c.xcd >= 0 ? 8 : 1), dim3(64), lds, s, a);
   };
   const int hsel = hbits <= 10 ? 10 : (hbits <= 13 ? 13 : 16);
+  if (c.wide) {
+    auto go4 = [&](auto kernel) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kernel, dim3(c.xcd >= 0 ? 8 : 1), dim3(64 * kW4), lds, s, a);
+    };
+#define DA_CHAIN_CASE4(L, Hh) if (S == L && hsel == Hh) go4(k_chain_forward_w4<L, Hh>);
+    DA_CHAIN_CASE4(6, 10) DA_CHAIN_CASE4(6, 13) DA_CHAIN_CASE4(6, 16)
+    DA_CHAIN_CASE4(7, 10) DA_CHAIN_CASE4(7, 13) DA_CHAIN_CASE4(7, 16)
+    DA_CHAIN_CASE4(8, 10) DA_CHAIN_CASE4(8, 13) DA_CHAIN_CASE4(8, 16)
+#undef DA_CHAIN_CASE4
+  } else {
 #define DA_CHAIN_CASE(L, Hh) if (S == L && hsel == Hh) go(k_chain_forward<L, Hh>);
   DA_CHAIN_CASE(6, 10) DA_CHAIN_CASE(6, 13) DA_CHAIN_CASE(6, 16)
   DA_CHAIN_CASE(7, 10) DA_CHAIN_CASE(7, 13) DA_CHAIN_CASE(7, 16)
   DA_CHAIN_CASE(8, 10) DA_CHAIN_CASE(8, 13) DA_CHAIN_CASE(8, 16)
 #undef DA_CHAIN_CASE
+  }
   hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(256), 0, s, c.pred, c.n, c.path_ids, c.meta);
   hipLaunchKernelGGL(k_chain_gather, dim3(256), dim3(256), 0, s, c.keys, c.path_ids, c.meta, c.out_i, c.out_v);
   return 0;

@@ -167,6 +167,7 @@ struct ChainLaunch {
   void* tree_lo; int32_t* pred; int32_t* path_ids; int64_t* meta;
   int32_t* out_i; int32_t* out_v;                               // the path, ascending
   int xcd;                                                      // XCD the persistent DP workgroup should sit on (-1: any)
+  int wide;                                                     // 1: four wavefronts per row super-step (rows of > ~100 matches)
 };
 int chain_tree_shift(int64_t n_ranks);
 size_t chain_rows_temp_bytes(int64_t n);

@@ -351,11 +351,8 @@ template <int C> static void launch_one(const FeatArgs& a, const FeatTables* d_t
   using Cfg = FeatCfg<C>;
   const int64_t blocks = (a.len_energy + Cfg::kOut - 1) / Cfg::kOut;
   const int smem = FeatLds<C>::total;
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_features<C>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    once = true;
-  }
+  // per launch: the attribute is per device, and contexts on several devices / threads share this code
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_features<C>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   hipLaunchKernelGGL(k_features<C>, dim3((unsigned)blocks), dim3(Cfg::kThreads), smem, s, a, d_tables);
 }
 

@@ -196,15 +196,17 @@ def _random_chain_instance(rng, n, rows, cols, step=4, quals=(50.0, 50.0, 12.5, 
   return i, v, rng.choice(quals, len(i))
 
 
+@pytest.mark.parametrize("waves", ["1", "4"])
 @pytest.mark.parametrize("shape", ["wide_rows", "many_ranks", "sparse"])
-def test_chain_kernel_equals_host_utility(ctx, native, shape):
+def test_chain_kernel_equals_host_utility(ctx, native, shape, waves, monkeypatch):
   """The device DP (da_chain with a context) against the host utility (NULL context) on instances
-  that exercise what the goldens do not: rows with more than 64 points (several wavefront steps per
-  row, carried sums), more than 2^19 distinct video ranks (another LDS / L2 split of the tree) and
+  that exercise what the goldens do not: rows with more than 64 / 256 points (several steps per
+  row, sums carried between wavefronts and steps), more than 2^19 distinct video ranks (another LDS / L2 split of the tree) and
   rows of one or two points.  Qualities are drawn from a few values, so equal sums abound."""
+  monkeypatch.setenv("DALIGN_CHAIN_WAVES", waves)        # both forward kernels: one wavefront / four per row super-step
   rng = np.random.default_rng({"wide_rows": 1, "many_ranks": 2, "sparse": 3}[shape])
   if shape == "wide_rows":
-    i, v, q = _random_chain_instance(rng, 60000, 300, 5000)              # ~200 points per row
+    i, v, q = _random_chain_instance(rng, 120000, 300, 5000)             # ~400 points per row: more than one 256-match super-step
   elif shape == "many_ranks":
     i, v, q = _random_chain_instance(rng, 1500000, 40000, 1200000, step=1)
   else:
