@@ -839,13 +839,16 @@ void launch_corr(const CorrArgs& a, hipStream_t s) {
 // exact float64 re-evaluation of one pair; returns true and the quality when it is a match
 __device__ inline bool verify_pair(const VerifyArgs& a, int32_t i, int32_t v, double& q_out) {
   if (a.mode == 0) {
-    int hits012 = 0;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) hits012 += digit_hit(a.dig_a[j][i], a.dig_v[j][v], a.flg_v[j][v]) ? 1 : 0;
-    if (hits012 < 2) return false;
+    // (feature 3 or 4 hits) and (at least two of features 0-2 hit), cheapest rejection first: a
+    // hash hit of one feature is a ~1e-3 event for an unrelated pair, so testing the two-feature
+    // alternative first rejects almost every survivor after 3-6 gathers instead of 9-15
     const bool h3 = digit_hit(a.dig_a[3][i], a.dig_v[3][v], a.flg_v[3][v]);
-    const bool h4 = h3 ? true : digit_hit(a.dig_a[4][i], a.dig_v[4][v], a.flg_v[4][v]);
-    if (!h4) return false;
+    const bool h34 = h3 ? true : digit_hit(a.dig_a[4][i], a.dig_v[4][v], a.flg_v[4][v]);
+    if (!h34) return false;
+    const int h0 = digit_hit(a.dig_a[0][i], a.dig_v[0][v], a.flg_v[0][v]) ? 1 : 0;
+    const int h1 = digit_hit(a.dig_a[1][i], a.dig_v[1][v], a.flg_v[1][v]) ? 1 : 0;
+    if (h0 + h1 == 0) return false;
+    if (h0 + h1 < 2 && !digit_hit(a.dig_a[2][i], a.dig_v[2][v], a.flg_v[2][v])) return false;
   }
   double prob = 1.0;
 #pragma unroll
