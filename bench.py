@@ -15,6 +15,7 @@ Workloads (BASELINE.json configs):
         configuration and the north_star target                                      (default)
   cfg1  configs[1] stand-in: 1320 s video / ~1558 s AD, 10 jumps + 200 s intro, mono, fp32 GEMM
         (reported as the `secondary` object of the same JSON line at N = 1)
+  cfg3  configs[3], one GPU's share: 1800 s mono pairs, fp32 GEMM (--gpus 8 runs the whole config)
 
 Timed region (steady state of a directory batch).  The pairs go through ONE primed pipeline: an
 untimed lead-in of max(W, two LP solves per host worker) pairs, K timed pairs and a tail that keeps
@@ -45,6 +46,9 @@ WORKLOADS = {
                seconds=1320.0, n_jumps=10, first_gap=200.0, channels=1, precision="f32"),
   "cfg2": dict(desc="configs[2]: synthetic 7200 s (2 h) stereo pair, 10 injected offset jumps + 200 s intro",
                seconds=7200.0, n_jumps=10, first_gap=200.0, channels=2, precision="bf16"),
+  "cfg3": dict(desc="configs[3] per-GPU share: synthetic 1800 s (30 min) mono pairs, 10 jumps + 120 s intro (the batch of 32 shards "
+                    "embarrassingly: every rank streams its own pairs)",
+               seconds=1800.0, n_jumps=10, first_gap=120.0, channels=1, precision="f32"),
   "cfg-small": dict(desc="600 s mono pair, 5 jumps (CI-sized)",
                     seconds=600.0, n_jumps=5, first_gap=60.0, channels=1, precision="f32"),
 }

@@ -27,7 +27,7 @@ ERR_MISMATCH = -4
 
 EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm_upload", "da_pcm_upload_async", "da_host_alloc", "da_host_free",
            "da_features_resident", "da_features", "da_match", "da_match_begin", "da_match_finish", "da_match_fetch",
-           "da_match_corr", "da_match_dump_tile", "da_match_export_device", "da_match_import_device", "da_chain", "da_chain_begin", "da_chain_finish", "da_chain_resident", "da_chain_poll",
+           "da_match_corr", "da_trim", "da_match_dump_tile", "da_match_export_device", "da_match_import_device", "da_chain", "da_chain_begin", "da_chain_finish", "da_chain_resident", "da_chain_poll",
            "da_refine", "da_stats", "da_replace_segments", "da_stretch_resident", "da_stretch_schedule"]
 
 
@@ -90,6 +90,7 @@ def load():
     lib.da_match_finish.argtypes = [vp, P(i64)]
     lib.da_match_fetch.argtypes = [vp, vp, vp, vp, i64]
     lib.da_match_corr.argtypes = [vp, vp, vp, i64, vp]
+    lib.da_trim.argtypes = [vp]
     lib.da_match_export_device.argtypes = [vp, vp, vp, i64]
     lib.da_match_import_device.argtypes = [vp, vp, vp, i64]
     lib.da_match_dump_tile.argtypes = [vp, i64, i64, vp, vp, vp]
@@ -328,6 +329,11 @@ class Context:
     out = np.empty((len(i), 3), dtype=np.float32)
     self._check(self._lib.da_match_corr(self._h, _ptr(i), _ptr(v), len(i), _ptr(out)))
     return out
+
+  def trim(self):
+    """Give back the matching stage's scratch memory (tens of GB for a long pair); the resident match
+    list, PCM and feature rows stay."""
+    self._check(self._lib.da_trim(self._h))
 
   def match_export_device(self, d_keys: int, d_q: int, n: int):
     """Copy the n resident matches device-to-device into caller-owned device buffers (addresses):

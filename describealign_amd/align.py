@@ -421,19 +421,25 @@ def align(video_features, audio_desc_features, video_energy, audio_desc_energy, 
 
 
 def align_tiled(video_features, audio_desc_features, video_energy, audio_desc_energy, group, ctx=None,
-                timings=None, mode=_native.MATCH_HASHED):
+                timings=None, mode=_native.MATCH_HASHED, match_lock=None):
   """One long pair across all ranks of `group` (BASELINE config 5): the quadratic matching stage
   is split into contiguous audio-row blocks, one per GPU (each rank holds all video features);
   the verified match lists are gathered on rank 0 in ONE exchange (RCCL over xGMI, device to device:
   Group.gather_matches_to_root), rank 0 alone runs what is sequential -- chain DP on its GPU, the
-  host LP, pass 2 -- and broadcasts the result.  Returns the same tuple as align() on every rank."""
+  host LP, pass 2 -- and broadcasts the result.  Returns the same tuple as align() on every rank.
+  After matching every rank gives the stage's scratch memory back (da_trim: an 8 h pair's survivor buffer
+  is 23 GB per rank).  match_lock: optional context manager held during this rank's matching stage --
+  for ranks that SHARE a device (tests, one-GPU emulation of an 8-GPU run) and would not fit side by side."""
   from .distrib import row_blocks
   ctx = ctx or default_context()
   tm = timings if timings is not None else {}
   n_ve, n_ae = len(video_energy), len(audio_desc_energy)
   t0 = time.perf_counter()
   rb, re = row_blocks(max(0, n_ae - (2 * NODE_FRAMES - 1)), group.world)[group.rank]
-  n_local = _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm, rows=(rb, re))
+  import contextlib
+  with (match_lock if match_lock is not None else contextlib.nullcontext()):
+    n_local = _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm, rows=(rb, re))
+    ctx.trim()
   t1 = time.perf_counter()
   total = group.gather_matches_to_root(ctx, n_local)
   t2 = time.perf_counter()

@@ -489,7 +489,10 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
   }
   m.out_count = c->counters.as<unsigned long long>();
   c->pend_mode = mode; c->pend_nv = n_v;
-  rc = launch_gemm(c, m, (size_t)std::max(1e6, c->st.gemm_pairs * 4e-3));
+  // survivor records: observed 6e-4 .. 7e-4 per row pair (f32 threshold) and 1.6e-3 (bf16, threshold x2);
+  // an overflow is detected and the GEMM re-run with the exact size, so the margin is ~1.6-2x, not more:
+  // at 8 bytes per record this buffer is the largest of a long pair (8 h pair tiled over 8 GPUs: 23 GB per rank)
+  rc = launch_gemm(c, m, (size_t)std::max(1e6, c->st.gemm_pairs * (c->precision == DA_PREC_F32 ? 1.5e-3 : 2.5e-3)));
   if (rc) return rc;
   c->match_pending = true;                      // nothing has been waited for: the GEMM is in flight
   return DA_OK;
@@ -530,7 +533,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
   // exact verification + sort
   unsigned long long n_match = 0;
   if (n_surv > 0) {
-    size_t mcap = (size_t)n_surv + (size_t)n_surv / 2 + 1024;     // verified matches are a fraction of the expanded pairs
+    size_t mcap = (size_t)n_surv / 2 + 4096;      // verified matches: observed 0.14 .. 0.21 per survivor record; overflow -> retried with the exact count
     VerifyArgs v{};
     v.surv = c->surv.as<unsigned long long>(); v.capacity = cap;
     for (int j = 0; j < 3; ++j) {
@@ -664,6 +667,34 @@ extern "C" int da_match_import_device(da_ctx* c, const uint64_t* d_keys, const d
   c->n_match_resident = (unsigned long long)n;
   c->st.matches = (double)n;
   c->fetch_ready = true;
+  return DA_OK;
+}
+
+// Give back the scratch memory of the matching stage (survivor records, unsorted matches, sort and
+// pass-2 scratch, idle chain slots): after da_match_finish only the sorted match list is needed.  A long
+// pair's scratch runs to tens of GB; contexts that share a device (or a caller about to start the
+// chain DP of a 1e9-match list) call this between the stages.  Everything grows back on demand.
+extern "C" int da_trim(da_ctx* c) {
+  if (!c) return DA_ERR_ARG;
+  if (c->match_pending) return fail(c, DA_ERR_STATE, "da_trim: a da_match_begin is in flight");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+  for (DevBuf* b : {&c->surv, &c->q0, &c->sort_tmp, &c->rowscratch, &c->rankmap, &c->band_y, &c->band_q, &c->band_part, &c->band_cl,
+                    &c->band_keys, &c->band_ids, &c->band_head, &c->band_out, &c->band_tmp, &c->pair_i, &c->pair_v, &c->pair_c})
+    b->release();
+  // keys0 holds the unpacked (i, v) of the resident matches for da_match_fetch: shrink it to what they need
+  c->keys0.release();
+  if (c->fetch_ready && c->res_slot >= 0 && c->n_match_resident > 0) {
+    const int64_t n = (int64_t)c->n_match_resident;
+    HIP_TRY(c, c->keys0.ensure(sizeof(unsigned long long) * (size_t)n));
+    launch_unpack_keys(c->slots[c->res_slot]->keys.as<unsigned long long>(), n, c->keys0.as<int32_t>(), c->keys0.as<int32_t>() + n, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  for (ChainSlot* sl : c->slots)
+    if (sl->state == 0)
+      for (DevBuf* b : {&sl->keys, &sl->q, &sl->rank, &sl->flags, &sl->rows, &sl->pred, &sl->tree, &sl->ids, &sl->out_iv, &sl->temp}) b->release();
   return DA_OK;
 }
 

@@ -116,6 +116,11 @@ int da_match_fetch(da_ctx* ctx, int32_t* out_i, int32_t* out_v, double* out_q, i
 int da_match_export_device(da_ctx* ctx, uint64_t* d_keys, double* d_q, int64_t n);
 int da_match_import_device(da_ctx* ctx, const uint64_t* d_keys, const double* d_q, int64_t n);
 
+/* Release the scratch memory of the matching stage (survivor records, unsorted matches, sort / pass-2
+ * scratch, idle chain slots); the resident sorted match list, PCM and feature rows stay.  For long pairs
+ * (tens of GB of scratch) and for contexts sharing one device.  Buffers grow back on demand. */
+int da_trim(da_ctx* ctx);
+
 /* Correlation values of the similarity GEMM for explicit (i, v) pairs, as the selected
  * precision computes them (testing/diagnostics: "similarity values within 1e-3").
  * corr receives [n][3].  Uses the feature rows of the last da_match call. */

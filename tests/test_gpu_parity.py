@@ -624,6 +624,7 @@ def test_match_list_device_export_import(ctx, native):
   torch.cuda.synchronize()
   assert torch.equal(all_k, keys) and torch.equal(all_q, qual)
   ctx.match_import_device(all_k.data_ptr(), all_q.data_ptr(), int(all_k.numel()))
+  ctx.trim()                                            # scratch given back: the resident list must survive it
   fi, fv, fq = ctx.match_fetch(n)                      # the imported list is "the resident match" in every respect
   assert np.array_equal(fi, mi) and np.array_equal(fv, mv) and np.array_equal(fq, mq)
   gi, gv = ctx.chain_resident()                         # (collecting the DP releases the list)
