@@ -85,7 +85,7 @@ struct da_ctx {
   std::string err;
   Side side[2];
   DevBuf tables, hann41;
-  DevBuf vlist, alist, surv, counters, keys0, q0, sort_tmp, rankmap, rowscratch;
+  DevBuf vlist, alist, surv, counters, keys0, q0, sort_tmp, rankmap, rowscratch, bfv;
   std::vector<ChainSlot*> slots;  // sorted match lists live in slots (see ChainSlot)
   int res_slot = -1;              // slot holding the results of the last finished match
   unsigned long long next_ticket = 1;
@@ -225,7 +225,7 @@ void da_destroy(da_ctx* c) {
     for (int j = 0; j < 3; ++j) { s.ms32[j].release(); s.inv32[j].release(); s.nrm32[j].release(); s.nrmpk[j].release(); s.bfe[j].release(); s.bfo[j].release(); }
     s.prod32.release();
   }
-  DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->counters, &c->keys0,
+  DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->bfv, &c->counters, &c->keys0,
                    &c->q0, &c->sort_tmp, &c->rankmap, &c->rowscratch, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
                    &c->band_y, &c->band_q, &c->band_part, &c->band_tab, &c->band_cl, &c->band_keys, &c->band_ids, &c->band_head,
                    &c->band_out, &c->band_tmp};
@@ -403,6 +403,11 @@ int upload_and_prep(da_ctx* c, Side& s, const float* feat, int64_t stride, const
 static int launch_gemm(da_ctx* c, MatchArgs& m, size_t cap) {
   HIP_TRY(c, c->surv.ensure(sizeof(unsigned long long) * cap));
   m.out = c->surv.as<unsigned long long>(); m.capacity = cap;
+  if (c->precision != DA_PREC_F32) {            // the video operand in MFMA fragment order: 9 KiB per 32 rows, whole row groups
+    m.bfv_tiles = (((m.n_v + 31) / 32 + da::kBfVideoTileGroup - 1) / da::kBfVideoTileGroup) * da::kBfVideoTileGroup;
+    HIP_TRY(c, c->bfv.ensure((size_t)m.bfv_tiles * 9 * 1024));
+    m.bfv_frag = c->bfv.p;
+  }
   HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
   HIP_TRY(c, hipEventRecord(c->gemm_e0, c->stream));
   if (c->precision == DA_PREC_F32) launch_match_f32(m, c->stream); else launch_match_bf16(m, c->stream);
@@ -515,11 +520,6 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
     HIP_TRY(c, hipMemcpyAsync(&n_surv, d_cnt, sizeof n_surv, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float ms = 0.f; (void)hipEventElapsedTime(&ms, c->gemm_e0, c->gemm_e1); c->st.gemm_ms = ms;
-    if (std::getenv("DALIGN_DEBUG_STAMPS")) {               // diagnostic builds (-DDA_DBG_STAMPS) only
-      unsigned long long st[16]; debug_read_stamps(st);
-      if (st[3]) std::fprintf(stderr, "bf16 consumer wave 0 of every block: %.1f cycles per phase (9 MFMAs = 288), barrier wait %.1f, exposed fragment load %.1f per phase; %.2f ms\n",
-                              (double)st[0] / st[3], (double)st[1] / st[3], (double)st[2] / st[3], ms);
-    }
     if (n_surv <= cap) break;
     if (attempt == 2) return fail(c, DA_ERR_DEVICE, "da_match: survivor list kept overflowing");
     cap = (size_t)(n_surv + n_surv / 16 + 1024);          // rare: rerun with the exact size
@@ -680,7 +680,7 @@ extern "C" int da_trim(da_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-  for (DevBuf* b : {&c->surv, &c->q0, &c->sort_tmp, &c->rowscratch, &c->rankmap, &c->band_y, &c->band_q, &c->band_part, &c->band_cl,
+  for (DevBuf* b : {&c->surv, &c->bfv, &c->q0, &c->sort_tmp, &c->rowscratch, &c->rankmap, &c->band_y, &c->band_q, &c->band_part, &c->band_cl,
                     &c->band_keys, &c->band_ids, &c->band_head, &c->band_out, &c->band_tmp, &c->pair_i, &c->pair_v, &c->pair_c})
     b->release();
   // keys0 holds the unpacked (i, v) of the resident matches for da_match_fetch: shrink it to what they need

@@ -67,6 +67,7 @@ struct MatchArgs {
   const uint32_t* nrmpk_a[3];                                 // bf16 GEMM: audio norm as two bf16
   const uint16_t* bfa_even[3]; const uint16_t* bfa_odd[3];   // audio side bf16 copies
   const double* msd_v[3];                                     // for building bf16 A fragments
+  void* bfv_frag; int64_t bfv_tiles;                          // bf16 GEMM: the video operand in MFMA fragment order [tile][feature][step][lane] x 16 B (scratch, filled per launch)
   const int32_t* vlist; int64_t n_v;      // every 4th non-quiet video frame (:629-630)
   const int32_t* alist; int64_t n_a;      // non-quiet audio frames within the requested rows (:657-658)
   unsigned long long* out;                // staged survivor records (see pack_record)
@@ -75,9 +76,9 @@ struct MatchArgs {
   float thr;                              // (1e-8)^(1/2.9) times the precision's safety margin
   int audio_tiles_per_block;
 };
+constexpr int kBfVideoTileGroup = 96;   // bfv_tiles is a multiple of this: a workgroup of the bf16 GEMM owns 16, 24 or 32 row tiles
 void launch_match_f32(const MatchArgs& a, hipStream_t s);
 void launch_match_bf16(const MatchArgs& a, hipStream_t s);
-void debug_read_stamps(unsigned long long out[16]);   // diagnostic builds only (zeros otherwise)
 
 struct CorrArgs {   // diagnostics: GEMM-precision correlations for explicit pairs
   MatchArgs m; const int32_t* pi; const int32_t* pv; int64_t n; float* corr; int precision;

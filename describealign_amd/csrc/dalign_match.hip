@@ -385,51 +385,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 1) void k_match_f32(MatchArgs 
 // two bf16 (A holds 1 there): the accumulator ends as |A| (1 - corr) and the epilogue per video row
 // is three VALU instructions: p = a0 a1;  d = p a2 - thr |A|_0 |A|_1 |A|_2;  mask = (mask << 1) | sign(d).
 //
-// Workgroup = 8 waves, one per CU (152 KB of LDS), two waves per SIMD (256 VGPRs each):
-//   4 consumer waves, one per SIMD, 64 video rows each (two 32-row MFMA tiles, A operand resident in
-//     72 VGPRs).  A consumer is alone on its SIMD's matrix pipe and software-pipelines ITSELF: the
-//     threshold epilogue of the previous row tile (its own second accumulator set) and the LDS reads
-//     of the next column tile's fragments are interleaved between the 9 MFMAs of the current row tile;
-//   4 producer waves, one per SIMD, never touch the matrix pipe: they stage the streamed audio operand,
-//     shared by all consumers, in LDS in MFMA fragment order [buffer][tile][feature][step][lane]
-//     (1 KiB per fragment, conflict-free ds_read_b128) by direct global->LDS DMA (per-lane source =
-//     the unaligned run), patch the two norm slots and the per-column threshold, and publish a group
-//     of 8 column tiles per barrier; two LDS buffers: the DMA of group g+1 has all of group g's
-//     MFMA time (~4600 cycles) to land.
+// The kernel (k_match_bf16, further down) is organised like k_match_f32: one wave per SIMD, the resident
+// operand in AGPRs, the streamed operand loaded straight into fragment registers.
 // ------------------------------------------------------------------------------------------
-constexpr int kBfGroup = 8;                           // 32-column tiles per staged group
-constexpr int kBfTileBytes = 9 * 1024;                // 3 features x 3 steps x 64 lanes x 16 B
-constexpr int kBfBufBytes = kBfGroup * kBfTileBytes;  // one group
-constexpr int kBfBuffers = 2;
-constexpr int kBfSurv = 256;                          // survivor staging slots per consumer wave (flushed when the next column tile could overflow it)
-constexpr int kBfConsumers = 4;                       // consumer waves per workgroup
-constexpr int kBfRowTiles = 2;                        // 32-row MFMA tiles per consumer
-constexpr int kBfProducers = 4;                       // producer waves (two tiles of every group each)
-constexpr int kBfThreads = 64 * (kBfConsumers + kBfProducers);
-constexpr int kBfRowsPerBlock = 32 * kBfRowTiles * kBfConsumers;
-constexpr int kBfSurvStride = kBfSurv + 64;           // + one scrap slot per lane (lanes without a survivor write there)
-constexpr int kBfSmem = kBfBuffers * kBfBufBytes + kBfConsumers * kBfSurvStride * 8 + kBfBuffers * kBfGroup * 32 * (4 + 4);
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-__device__ __forceinline__ void stage_tile_bf16(const MatchArgs& a, unsigned char* tile_lds, int32_t ic, int h) {
-  const int32_t st = ic + 24 * h;                // first element of this lane's run
-  const int32_t odd = st & 1;
-  const int32_t ev = st - odd;                   // even element index into the chosen copy
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const uint16_t* base = (odd ? a.bfa_odd[j] : a.bfa_even[j]) + ev;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      unsigned char* dst = tile_lds + (3 * j + s) * 1024;        // + lane*16 added by the hardware
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + 8 * s), (lds_ptr_t)dst, 16, 0, 0);
-    }
-  }
-}
-
-#ifdef DA_DBG_STAMPS
-__device__ unsigned long long g_stamps[16];
-#endif
 
 // threshold epilogue of one accumulator row of a finished tile: three VALU instructions.
 // The three accumulator blocks of a tile are 16 registers apart, i.e. in the same VGPR bank for equal
@@ -446,10 +404,8 @@ __device__ __forceinline__ void bf_row(const f32x16 (&acc)[3], int g, float thr,
   mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(d), 31);   // (mask << 1) | sign(d): rows fed 15..0
 }
 
-// Survivors of one finished tile, straight-line (no branch: it sits between two runs of MFMAs and
-// is scheduled into them): every lane with a non-zero row mask stages one record at the next free
-// slot of its wave's LDS buffer; the others write to their own scrap slot behind it.  The caller flushes
-// the buffer before it can overflow (bf_flush_if_needed).
+// Survivors of one finished tile: every lane with a non-zero row mask stages one record at the next free
+// slot of its wave's LDS buffer.  The caller flushes the buffer before it can overflow.
 __device__ __forceinline__ void bf_emit(SurvSink& sk, int h, int64_t vtile, uint32_t mask, int32_t ic) {
   const unsigned long long m = __ballot(mask != 0u);
   if (m == 0ull) return;               // the wave is instruction-issue bound: ~4 in 10 tiles have no survivor at all
@@ -460,244 +416,215 @@ __device__ __forceinline__ void bf_emit(SurvSink& sk, int h, int64_t vtile, uint
   if (mask != 0u) reinterpret_cast<uint2*>(sk.s_buf)[pos] = uint2{lo, hi};
   sk.count += __popcll(m);
 }
-__device__ __forceinline__ void bf_flush_if_needed(SurvSink& sk, const MatchArgs& a, int lane) {
-  if (sk.count > kBfSurv - 128) sink_flush(sk, a, lane);          // a column tile (two row tiles) adds at most 128 records
+// ------------------------------------------------------------------------------------------
+// bf16 GEMM (v7).  One wave per SIMD with the whole 512-register budget, no LDS staging of operands, no
+// producer waves, no barriers (the round-1/2 kernel staged the streamed operand in LDS with four producer
+// waves per workgroup: v6, 11 % slower).  A wave keeps kBdRowTiles x 32 video
+// rows resident (216 AGPRs for six tiles) and streams 32-column tiles of the audio operand straight from
+// L2 into MFMA fragment registers -- nine 16-byte loads per lane and tile from the (even / odd) bf16 row
+// copies, issued one whole tile (54 MFMAs) ahead into a second register set -- so every fragment feeds
+// six MFMAs.  What this removes from the SIMD's instruction stream: the producers' LDS-DMA pieces
+// (measured: 17 % of the staged kernel's time), the group barriers and two thirds of the fragment reads.
+#ifndef DA_BD_ROWTILES
+#define DA_BD_ROWTILES 6
+#endif
+constexpr int kBdRowTiles = DA_BD_ROWTILES;       // even: the two accumulator sets alternate
+constexpr int kBdWaves = 4;
+constexpr int kBdRows = 32 * kBdRowTiles;
+constexpr int kBdRowsPerBlock = kBdRows * kBdWaves;
+static_assert(kBdRowTiles % 2 == 0 && kBdRowTiles >= 4 && kBfVideoTileGroup % (kBdRowTiles * kBdWaves) == 0, "row tiling");
+constexpr int kBdSurv = 128 * kBdRowTiles;        // a column tile adds at most 64 records per row tile
+typedef short bf16x8u __attribute__((ext_vector_type(8), aligned(4)));   // 16-byte load, 4-byte aligned
+
+struct BdTile {                  // streamed operand of one 32-column tile, as this lane's MFMAs take it
+  bf16x8 frag[3][3];
+  uint32_t nrm[3];               // audio window norms of the lane's column (hi + lo bf16)
+  float prod;                    // |A|_0 |A|_1 |A|_2 of the column
+  int32_t ic;                    // its frame number
+};
+
+// loads of feature j of the tile whose frame numbers are `ic`
+__device__ __forceinline__ void bd_issue_feature(const MatchArgs& a, int32_t ic, int h, int j, BdTile& t) {
+  const int32_t st = ic + 24 * h;                // first element of this lane's run (K permutation: k = 24 h + 8 s + e)
+  const int32_t odd = st & 1;
+  const int32_t ev = st - odd;                   // even element index into the chosen copy: 4-byte aligned
+  const uint16_t* base = (odd ? a.bfa_odd[j] : a.bfa_even[j]) + ev;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) t.frag[j][s] = *reinterpret_cast<const bf16x8u*>(base + 8 * s);
+}
+// what a tile needs besides its fragments: the column norms (they go into K slots 42 / 43) and their product (threshold)
+__device__ __forceinline__ void bd_issue_side(const MatchArgs& a, int32_t ic, BdTile& t) {
+  t.ic = ic;
+  t.prod = a.prod_a[ic];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) t.nrm[j] = a.nrmpk_a[j][ic];
 }
 
-// 9 MFMAs of one (32 video rows x 32 audio columns) tile into `acc`, with the epilogue of the
-// previously finished tile (`accp`, `thr_p`) -- and, when NEXT, the LDS reads of the next column
-// tile's fragments into the registers the MFMAs have just consumed -- interleaved between them.
-template <bool NEXT>
-__device__ __forceinline__ void bf_tile(const bf16x8 (&A)[3][3], bf16x8 (&frag)[3][3], f32x16 (&acc)[3],
-                                        const f32x16 (&accp)[3], float thr_p, uint32_t& mask_p,
-                                        const unsigned char* next_frags) {
+// names every register of a tile: the compiler retires its loads (vmcnt) here, before the next batch is issued
+__device__ __forceinline__ void bd_retire(const BdTile& t) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j) acc[j] = f32x16{0};
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) asm volatile("" ::"v"(t.frag[j][s]));
+    asm volatile("" ::"v"(t.nrm[j]));
+  }
+  asm volatile("" ::"v"(t.prod));
+}
+
+// 9 MFMAs of one (32 rows x 32 columns) phase into `acc`, the threshold epilogue of the previous phase
+// (`accp`, `thr_p`) between them.  The MFMAs are inline assembly so that the register files can be
+// chosen: the resident A operand lives in AGPRs (only MFMAs read it), accumulators and streamed
+// fragments in VGPRs (the epilogue reads accumulators with plain VALU: no v_accvgpr_read).  The
+// compiler does not know these statements are MFMAs, so
+//  (1) a scheduling barrier closes every MFMA slot -- nothing moves across;
+//  (2) the slot layout itself keeps the MFMA -> VALU read distance: the epilogue of the previous phase
+//      starts behind the SECOND MFMA of this one, i.e. more than two matrix-pipe slots (64 cycles) after
+//      the last MFMA that wrote `accp`;
+//  (3) nothing but loads and the norm patch (fenced, at the top of a tile) ever writes an MFMA source
+//      register, so no "VALU write -> MFMA read" wait states are owed in front of an MFMA.
+// profiles/tools/check_mfma_asm_hazards.py checks (2) and (3) on the generated ISA.
+// `extra(m)` is issued in slot m.
+template <class Extra>
+__device__ __forceinline__ void bd_phase(const bf16x8 (&A)[3][3], const bf16x8 (&frag)[3][3], f32x16 (&acc)[3],
+                                         const f32x16 (&accp)[3], float thr_p, uint32_t& mask_p, Extra extra) {
   int row = 15;
 #pragma unroll
   for (int m = 0; m < 9; ++m) {
-#ifdef DA_BF_CHAINED
-    const int j = m / 3, s = m % 3;                  // three dependent MFMAs per accumulator in a row
-#else
-    const int j = m % 3, s = m / 3;                  // accumulators interleaved: an MFMA never waits for the one before it
-#endif
-    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][s], frag[j][s], acc[j], 0, 0, 0);
-    if (NEXT) *reinterpret_cast<uint4*>(&frag[j][s]) = *reinterpret_cast<const uint4*>(next_frags + (3 * j + s) * 1024);
+    const int j = m % 3, s = m / 3;
+    if (s == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[j]) : "a"(A[j][s]), "v"(frag[j][s]));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[j]) : "a"(A[j][s]), "v"(frag[j][s]));
+    __builtin_amdgcn_sched_barrier(0);
 #ifndef DA_DBG_BF_NOEPI
-    const int nrows = m < 7 ? 2 : 1;                 // 16 rows over 9 MFMA slots
-#pragma unroll
-    for (int t = 0; t < nrows; ++t) { bf_row(accp, row, thr_p, mask_p); --row; }
+    if (m >= 1) {
+      bf_row(accp, row, thr_p, mask_p); --row;
+      bf_row(accp, row, thr_p, mask_p); --row;
+    }
 #endif
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
-    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);               // then up to six VALU
-    if (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // and one LDS read
+    extra(m);
+    __builtin_amdgcn_sched_barrier(0);
   }
-#ifdef DA_DBG_BF_NOEPI
-  asm volatile("" ::"v"(accp[0][0]), "v"(accp[1][7]), "v"(accp[2][15]), "v"(thr_p));
-#endif
 }
 
-__global__ __launch_bounds__(kBfThreads, 2) void k_match_bf16(MatchArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* s_b = smem;                                                        // [kBfBuffers][kBfGroup][9 KiB]
-  unsigned long long* s_surv = reinterpret_cast<unsigned long long*>(smem + kBfBuffers * kBfBufBytes);     // [consumers][kBfSurv]
-  float* s_thr = reinterpret_cast<float*>(smem + kBfBuffers * kBfBufBytes + kBfConsumers * kBfSurvStride * 8);   // [kBfBuffers][kBfGroup][32]
-  int32_t* s_ic = reinterpret_cast<int32_t*>(s_thr + kBfBuffers * kBfGroup * 32);                           // [kBfBuffers][kBfGroup][32]
+// The resident (video) operand in MFMA fragment order, one wavefront per 32-row tile: out[tile][feature][step][lane]
+// is the 16 bytes lane (r, h) feeds to step s of feature j -- the bf16 of -ms_v[v + k] / |V|_v for
+// k = 24 h + 8 s + e < 41, 1.0 in the two norm slots, 0 elsewhere; rows rotated per feature (bf_arow).
+// Tiles past the last row hold the "no row" operand (zeros and the norm ones): a wave may own up to
+// kBdRowTiles - 1 of them.  The GEMM waves load these straight into AGPRs.
+__global__ __launch_bounds__(64) void k_bf16_video_frags(MatchArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t tile = blockIdx.x;
+  uint4* out = reinterpret_cast<uint4*>(a.bfv_frag) + tile * 9 * 64 + lane;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int64_t vr = tile * 32 + bf_arow(r, j);
+    const bool vok = vr < a.n_v;
+    const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
+    const double sc = vok ? -(double)a.inv_v[j][v] : 0.0;
+    const double* p = a.msd_v[j] + v;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      uint32_t w[4];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 24 * h + 8 * s + e;
+        uint16_t x = 0;
+        if (k < kWin) x = f32_to_bf16((float)(p[k] * sc));
+        else if (k == 42 || k == 43) x = 0x3F80;            // 1.0: the norm slots
+        if (e & 1) w[e >> 1] |= (uint32_t)x << 16; else w[e >> 1] = x;
+      }
+      out[(3 * j + s) * 64] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
+  __shared__ unsigned long long s_surv[kBdWaves][kBdSurv + 64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const bool producer = wave >= kBfConsumers;
+  const int64_t vt0 = ((int64_t)blockIdx.x * kBdWaves + wave) * kBdRows;
   const int64_t a_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block * 32;
   int64_t a_end = a_begin + (int64_t)a.audio_tiles_per_block * 32;
   if (a_end > a.n_a) a_end = a.n_a;
-  if (a_begin >= a_end) return;                                           // uniform per block
-  const int64_t n_tiles = (a_end - a_begin + 31) / 32;
-  const int64_t n_groups = (n_tiles + kBfGroup - 1) / kBfGroup;
-  auto tile_pos = [&](int64_t g, int w) { return a_begin + (g * kBfGroup + w) * 32; };
-
-  if (producer) {
-    // ------------------------------------------------------------------ producer wave
-    // Stages tiles pw and pw + 4 of every group, one group ahead of the consumers.
-    const int pw = wave - kBfConsumers;
-    auto fetch_patch = [&](int32_t ic, uint32_t (&pv)[3]) {
-      if (h) { pv[0] = a.nrmpk_a[0][ic]; pv[1] = a.nrmpk_a[1][ic]; pv[2] = a.nrmpk_a[2][ic]; }
-      else { pv[0] = __float_as_uint(a.prod_a[ic]); pv[1] = 0; pv[2] = 0; }
-    };
-    int32_t ic_c[2], ic_n[2];                            // frame numbers: group being published / group in flight
-    uint32_t pv_c[2][3], pv_n[2][3];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      ic_c[u] = fetch_index(a, tile_pos(0, pw + 4 * u), a_end, r);
-      fetch_patch(ic_c[u], pv_c[u]);
-      stage_tile_bf16(a, s_b + (pw + 4 * u) * kBfTileBytes, ic_c[u], h);
-      ic_n[u] = fetch_index(a, tile_pos(1, pw + 4 * u), a_end, r);
-    }
-    for (int64_t g = 0; g < n_groups; ++g) {
-      const int cur = (int)(g & 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of group g has landed
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int w = pw + 4 * u;
-        unsigned char* tile = s_b + cur * kBfBufBytes + w * kBfTileBytes;
-        if (h) {
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            *reinterpret_cast<uint32_t*>(tile + (3 * j + 2) * 1024 + lane * 16 + 4) = pv_c[u][j];
-        } else {
-          s_thr[(cur * kBfGroup + w) * 32 + r] = ((tile_pos(g, w) + r) < a_end) ? a.thr * __uint_as_float(pv_c[u][0]) : -__builtin_inff();
-          s_ic[(cur * kBfGroup + w) * 32 + r] = ic_c[u];
-        }
-      }
-      __syncthreads();                           // group g published; the consumers have left buffer cur ^ 1
-      if (g + 1 < n_groups) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          fetch_patch(ic_n[u], pv_n[u]);
-          stage_tile_bf16(a, s_b + (cur ^ 1) * kBfBufBytes + (pw + 4 * u) * kBfTileBytes, ic_n[u], h);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        ic_c[u] = ic_n[u]; pv_c[u][0] = pv_n[u][0]; pv_c[u][1] = pv_n[u][1]; pv_c[u][2] = pv_n[u][2];
-        ic_n[u] = fetch_index(a, tile_pos(g + 2, pw + 4 * u), a_end, r);
-      }
-    }
-    return;
-  }
-
-  // -------------------------------------------------------------------- consumer wave
-  const int64_t vt0 = ((int64_t)blockIdx.x * kBfConsumers + wave) * (32 * kBfRowTiles);   // this wave's 64 video rows
-  SurvSink sk{s_surv + wave * kBfSurvStride, 0, kBfSurv};
-  bf16x8 A[kBfRowTiles][3][3];
-#pragma unroll
-  for (int rt = 0; rt < kBfRowTiles; ++rt) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int64_t vr = vt0 + 32 * rt + bf_arow(r, j);          // rows rotated per feature: see bf_row
-      const bool vok = vr < a.n_v;
-      const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
-      const double sc = vok ? -(double)a.inv_v[j][v] : 0.0;
-      const double* p = a.msd_v[j] + v;
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int k = 24 * h + 8 * s + e;
-          uint16_t x = 0;
-          if (k < kWin) x = f32_to_bf16((float)(p[k] * sc));
-          else if (k == 42 || k == 43) x = 0x3F80;            // 1.0: the norm slots
-          A[rt][j][s][e] = (short)x;
-        }
-    }
-  }
+  if (vt0 >= a.n_v || a_begin >= a_end) return;
+  SurvSink sk{s_surv[wave], 0, kBdSurv};
   const int64_t vtile0 = vt0 >> 5;
-  // Software pipeline over "phases" (one row tile x one column tile = 9 MFMAs).  Phase order:
-  //   rt0(0) | rt1(0) rt0(1) | rt1(1) rt0(2) | ...      ( | = loop back-edge )
-  // Each phase's MFMAs carry, interleaved: the threshold epilogue of the PREVIOUS phase's accumulators
-  // (two accumulator sets), and -- in rt1 phases -- the LDS reads of the next column tile's fragments
-  // into the registers the MFMAs have just consumed; the survivor records of the phase before that
-  // are written at the start of the phase.  The loop is rotated so that its back-edge sits behind an
-  // rt0 phase: every LDS operation in flight there is at least nine MFMAs old, and the
-  // s_waitcnt lgkmcnt(0) the compiler places at a loop header costs nothing.
-  f32x16 accX[3], accY[3];
+  // The resident operand goes from memory straight into AGPRs: only MFMAs read it, and the VGPR half of
+  // the register file belongs to the accumulators and the streamed fragments.  (Inline assembly: this
+  // is the one way to make the definition itself an AGPR; the compiler does not count these loads, hence
+  // the explicit wait.)
+  bf16x8 A[kBdRowTiles][3][3];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.bfv_frag) + vtile0 * 9 * 64 + lane;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) accY[j] = f32x16{0};
-  float thr_y = -__builtin_inff();                     // threshold row for accY's columns; -inf: nothing owed, no row passes
-  int32_t ic_y = 0;
-  uint32_t pend_mask = 0; int32_t pend_ic = 0; int pend_rt = 0;      // finished epilogue whose records are not staged yet
-  bf16x8 frag[3][3];
-#ifdef DA_DBG_STAMPS
-  unsigned long long st_acc[4] = {0, 0, 0, 0};
-  unsigned long long st_t = __builtin_amdgcn_s_memtime();
-#define BF_STAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t; st_t = t_; }
-#else
-#define BF_STAMP(k)
-#endif
-  for (int64_t g = 0; g < n_groups; ++g) {
-    const int cur = (int)(g & 1);
-    BF_STAMP(0)                                                    // phases of the previous group
-    __syncthreads();                                               // group g is in buffer cur
-    BF_STAMP(1)                                                    // barrier wait
-    const unsigned char* gbase = s_b + cur * kBfBufBytes + lane * 16;
+    for (int rt = 0; rt < kBdRowTiles; ++rt)
 #pragma unroll
-    for (int m = 0; m < 9; ++m) *reinterpret_cast<uint4*>(&frag[m / 3][m % 3]) = *reinterpret_cast<const uint4*>(gbase + m * 1024);
-#ifdef DA_DBG_STAMPS
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    BF_STAMP(2)                                                    // exposed fragment load
-#endif
-    int64_t left = n_tiles - g * kBfGroup;                         // column tiles of this group
-    if (left > kBfGroup) left = kBfGroup;
-    float thr_x = s_thr[(cur * kBfGroup) * 32 + r];                // -inf: column past the end
-    int32_t ic_x = s_ic[(cur * kBfGroup) * 32 + r];
-    auto stage_pending = [&]() {
-#ifndef DA_DBG_BF_NOEMIT
-      bf_emit(sk, h, vtile0 + pend_rt, pend_mask, pend_ic);
+      for (int m = 0; m < 9; ++m)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(A[rt][m / 3][m % 3]) : "v"(src + (rt * 9 + m) * 64) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  f32x16 acc0[3], acc1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) acc1[j] = f32x16{0};
+  float thr_prev = -__builtin_inff();                   // threshold row of acc1's columns; -inf: nothing owed
+  int32_t ic_prev = 0;
+  BdTile X, Y;
+  int64_t at = a_begin;
+  bd_issue_side(a, fetch_index(a, at, a_end, r), X);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bd_issue_feature(a, X.ic, h, j, X);
+  int32_t ic_next = fetch_index(a, at + 32, a_end, r);
+  // one column tile: kBdRowTiles phases on tile CUR while tile NXT streams in behind the MFMAs of the first
+  // three phases (frame numbers are fetched two tiles ahead, so no load waits for another)
+  auto run_tile = [&](BdTile& CUR, BdTile& NXT) {
+    bd_retire(CUR);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (h) reinterpret_cast<uint32_t*>(&CUR.frag[j][2])[1] = CUR.nrm[j];      // K slots 42 / 43 carry the audio norm
+    // the patched words are MFMA sources: keep the patch here (an MFMA may read a VALU result two wait states later at the earliest)
+    asm volatile("s_nop 1" : "+v"(CUR.frag[0][2]), "+v"(CUR.frag[1][2]), "+v"(CUR.frag[2][2]));
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef DA_DBG_BF_NOTHR
+    const float thr_cur = ((at + r) < a_end) ? -a.thr * CUR.prod : -__builtin_inff();
 #else
-      asm volatile("" ::"v"(pend_mask));
+    const float thr_cur = ((at + r) < a_end) ? a.thr * CUR.prod : -__builtin_inff();
 #endif
-    };
-    // rt0 of the group's first column tile; owed: rt1 of the previous group's last column tile
-    {
-      stage_pending();
+    asm volatile("" ::"v"(ic_next));
+    const int32_t icn = ic_next;
+#pragma unroll
+    for (int rt = 0; rt < kBdRowTiles; ++rt) {
       uint32_t mask = 0;
-      bf_tile<false>(A[0], frag, accX, accY, thr_y, mask, nullptr);
-      pend_mask = mask; pend_ic = ic_y; pend_rt = 1;
+      auto extra = [&](int m) {
+        if (rt == 0 && m == 2) { bd_issue_side(a, icn, NXT); ic_next = fetch_index(a, at + 64, a_end, r); }
+        if (rt == 0 && m == 5) bd_issue_feature(a, icn, h, 0, NXT);
+        if (rt == 1 && m == 4) bd_issue_feature(a, icn, h, 1, NXT);
+        if (rt == 2 && m == 4) bd_issue_feature(a, icn, h, 2, NXT);
+      };
+      const float thr_p = rt == 0 ? thr_prev : thr_cur;            // the epilogue in flight belongs to the phase before
+      if (rt & 1) bd_phase(A[rt], CUR.frag, acc1, acc0, thr_p, mask, extra);
+      else bd_phase(A[rt], CUR.frag, acc0, acc1, thr_p, mask, extra);
+      bf_emit(sk, h, vtile0 + (rt == 0 ? kBdRowTiles - 1 : rt - 1), mask, rt == 0 ? ic_prev : CUR.ic);
     }
-#pragma unroll 1
-    for (int w = 0; w + 1 < (int)left; ++w) {
-      // rt1(w): epilogue of rt0(w); fragments of column tile w + 1 stream in
-      stage_pending();
-      uint32_t mask = 0;
-      bf_tile<true>(A[1], frag, accY, accX, thr_x, mask, gbase + (w + 1) * kBfTileBytes);
-      pend_mask = mask; pend_ic = ic_x; pend_rt = 0;
-      thr_y = thr_x; ic_y = ic_x;
-      thr_x = s_thr[(cur * kBfGroup + w + 1) * 32 + r];
-      ic_x = s_ic[(cur * kBfGroup + w + 1) * 32 + r];
-      // rt0(w + 1): epilogue of rt1(w)
-      stage_pending();
-      mask = 0;
-      bf_tile<false>(A[0], frag, accX, accY, thr_y, mask, nullptr);
-      pend_mask = mask; pend_ic = ic_y; pend_rt = 1;
-#ifndef DA_DBG_BF_NOEMIT
-      bf_flush_if_needed(sk, a, lane);
-#endif
-    }
-    // rt1 of the group's last column tile (the next fragments come from the other buffer, after the barrier)
-    {
-      stage_pending();
-      uint32_t mask = 0;
-      bf_tile<false>(A[1], frag, accY, accX, thr_x, mask, nullptr);
-      pend_mask = mask; pend_ic = ic_x; pend_rt = 0;
-      thr_y = thr_x; ic_y = ic_x;
-#ifndef DA_DBG_BF_NOEMIT
-      bf_flush_if_needed(sk, a, lane);
-#endif
-    }
+    thr_prev = thr_cur; ic_prev = CUR.ic;
+    if (sk.count > kBdSurv - 64 * kBdRowTiles) sink_flush(sk, a, lane);
+    at += 32;
+  };
+  while (true) {
+    run_tile(X, Y);
+    if (at >= a_end) break;
+    run_tile(Y, X);
+    if (at >= a_end) break;
   }
-#ifdef DA_DBG_STAMPS
-  BF_STAMP(0)
-  if (wave == 0 && lane == 0) {
-    for (int t = 0; t < 3; ++t) atomicAdd(&g_stamps[t], st_acc[t]);
-    atomicAdd(&g_stamps[3], (unsigned long long)(n_tiles * 2));    // phases executed
-  }
-#endif
-  {                                                                // drain: staged record of rt0, epilogue + record of the last rt1
-    bf_emit(sk, h, vtile0 + pend_rt, pend_mask, pend_ic);
+  {                                                                // drain: the last tile's last row tile
+    // the last MFMAs have left the pipe before the accumulators are read (tied to them, so that the reads cannot be moved above the wait)
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]));
     uint32_t mask = 0;
 #pragma unroll
-    for (int g = 15; g >= 0; --g) bf_row(accY, g, thr_y, mask);
-    bf_emit(sk, h, vtile0 + 1, mask, ic_y);
+    for (int g = 15; g >= 0; --g) bf_row(acc1, g, thr_prev, mask);
+    bf_emit(sk, h, vtile0 + kBdRowTiles - 1, mask, ic_prev);
   }
   sink_flush(sk, a, lane);
-}
-
-void debug_read_stamps(unsigned long long out[16]) {
-  for (int k = 0; k < 16; ++k) out[k] = 0;
-#ifdef DA_DBG_STAMPS
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
-  unsigned long long z[16] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
-#endif
 }
 
 static dim3 match_grid(const MatchArgs& a) {
@@ -714,12 +641,17 @@ void launch_match_f32(const MatchArgs& a, hipStream_t s) {
 }
 void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   if (a.n_v <= 0 || a.n_a <= 0) return;
-  // per launch: the attribute is per device and contexts on several devices / threads share this code
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, kBfSmem);
-  const int64_t bx = (a.n_v + kBfRowsPerBlock - 1) / kBfRowsPerBlock;
+  MatchArgs b = a;
+  const int64_t bx = (a.n_v + kBdRowsPerBlock - 1) / kBdRowsPerBlock;
   const int64_t atiles = (a.n_a + 31) / 32;
-  const int64_t by = (atiles + a.audio_tiles_per_block - 1) / a.audio_tiles_per_block;
-  hipLaunchKernelGGL(k_match_bf16, dim3((unsigned)bx, (unsigned)by), dim3(kBfThreads), kBfSmem, s, a);
+  int64_t want_y = (256 * 12 + bx - 1) / bx;                      // one workgroup per CU at a time: >= 12 rounds of them
+  if (want_y < 1) want_y = 1;
+  int64_t tpb = (atiles + want_y - 1) / want_y;
+  if (tpb < 1) tpb = 1;
+  if ((atiles + tpb - 1) / tpb > 65535) tpb = (atiles + 65534) / 65535;
+  b.audio_tiles_per_block = (int)tpb;
+  hipLaunchKernelGGL(k_bf16_video_frags, dim3((unsigned)b.bfv_tiles), dim3(64), 0, s, b);
+  hipLaunchKernelGGL(k_match_bf16, dim3((unsigned)bx, (unsigned)((atiles + tpb - 1) / tpb)), dim3(64 * kBdWaves), 0, s, b);
 }
 
 // diagnostics: the raw MFMA accumulators of ONE (32 video rows x 32 audio columns) tile, formed with
