@@ -404,6 +404,14 @@ __device__ __forceinline__ void bf_row(const f32x16 (&acc)[3], int g, float thr,
   mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(d), 31);   // (mask << 1) | sign(d): rows fed 15..0
 }
 
+// the same in two steps, for kernels that spread the epilogue over MFMA slots: the product of the first two
+// features may be formed one matrix-pipe slot earlier than the third accumulator may be read
+__device__ __forceinline__ void bf_row_mul(f32x16 (&acc)[3], int g) { acc[0][g] = acc[0][g] * acc[1][bf_rot(g, 1)]; }
+__device__ __forceinline__ void bf_row_cmp(const f32x16 (&acc)[3], int g, float thr, uint32_t& mask) {
+  const float d = __builtin_fmaf(acc[0][g], acc[2][bf_rot(g, 2)], -thr);
+  mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(d), 31);
+}
+
 // Survivors of one finished tile: every lane with a non-zero row mask stages one record at the next free
 // slot of its wave's LDS buffer.  The caller flushes the buffer before it can overflow.
 __device__ __forceinline__ void bf_emit(SurvSink& sk, int h, int64_t vtile, uint32_t mask, int32_t ic) {
@@ -430,6 +438,7 @@ __device__ __forceinline__ void bf_emit(SurvSink& sk, int h, int64_t vtile, uint
 #endif
 constexpr int kBdRowTiles = DA_BD_ROWTILES;       // even: the two accumulator sets alternate
 constexpr int kBdWaves = 4;
+constexpr int kBdLoadSlot = 7;                    // MFMA slot of a phase that carries the next tile's loads (it has two epilogue instructions; with the loads in slots 2 / 4 / 5 the kernel was 5 % slower)
 constexpr int kBdRows = 32 * kBdRowTiles;
 constexpr int kBdRowsPerBlock = kBdRows * kBdWaves;
 static_assert(kBdRowTiles % 2 == 0 && kBdRowTiles >= 4 && kBfVideoTileGroup % (kBdRowTiles * kBdWaves) == 0, "row tiling");
@@ -477,17 +486,22 @@ __device__ __forceinline__ void bd_retire(const BdTile& t) {
 // fragments in VGPRs (the epilogue reads accumulators with plain VALU: no v_accvgpr_read).  The
 // compiler does not know these statements are MFMAs, so
 //  (1) a scheduling barrier closes every MFMA slot -- nothing moves across;
-//  (2) the slot layout itself keeps the MFMA -> VALU read distance: the epilogue of the previous phase
-//      starts behind the SECOND MFMA of this one, i.e. more than two matrix-pipe slots (64 cycles) after
-//      the last MFMA that wrote `accp`;
+//  (2) the slot layout itself keeps the MFMA -> VALU read distance (a result may be read 11 wait states =
+//      44 cycles after its MFMA was issued; the matrix pipe takes one MFMA per 32 cycles): slot 0 only
+//      multiplies the first two accumulators, whose last MFMAs are two and three pipe slots old there,
+//      and the third accumulator is first read in slot 1, two pipe slots behind its last MFMA;
 //  (3) nothing but loads and the norm patch (fenced, at the top of a tile) ever writes an MFMA source
 //      register, so no "VALU write -> MFMA read" wait states are owed in front of an MFMA.
 // profiles/tools/check_mfma_asm_hazards.py checks (2) and (3) on the generated ISA.
 // `extra(m)` is issued in slot m.
 template <class Extra>
 __device__ __forceinline__ void bd_phase(const bf16x8 (&A)[3][3], const bf16x8 (&frag)[3][3], f32x16 (&acc)[3],
-                                         const f32x16 (&accp)[3], float thr_p, uint32_t& mask_p, Extra extra) {
-  int row = 15;
+                                         f32x16 (&accp)[3], float thr_p, uint32_t& mask_p, Extra extra) {
+  // epilogue of the previous phase, 48 VALU over the nine slots: products a0 a1 (in place) first -- they
+  // only read accumulators whose last MFMA is at least two slots old even in slot 0 -- then, from slot 1
+  // on, the fused multiply-add with the third accumulator and the sign collection, rows 15 .. 0
+  constexpr int kMulFrom[10] = {16, 10, 6, 2, 0, 0, 0, 0, 0, 0};   // slot m multiplies rows kMulFrom[m+1] .. kMulFrom[m]-1
+  constexpr int kCmpFrom[10] = {16, 16, 15, 14, 12, 9, 6, 3, 1, 0};  // slot m finishes rows kCmpFrom[m+1] .. kCmpFrom[m]-1
 #pragma unroll
   for (int m = 0; m < 9; ++m) {
     const int j = m % 3, s = m / 3;
@@ -495,10 +509,10 @@ __device__ __forceinline__ void bd_phase(const bf16x8 (&A)[3][3], const bf16x8 (
     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[j]) : "a"(A[j][s]), "v"(frag[j][s]));
     __builtin_amdgcn_sched_barrier(0);
 #ifndef DA_DBG_BF_NOEPI
-    if (m >= 1) {
-      bf_row(accp, row, thr_p, mask_p); --row;
-      bf_row(accp, row, thr_p, mask_p); --row;
-    }
+#pragma unroll
+    for (int g = kMulFrom[m] - 1; g >= kMulFrom[m + 1]; --g) bf_row_mul(accp, g);
+#pragma unroll
+    for (int g = kCmpFrom[m] - 1; g >= kCmpFrom[m + 1]; --g) bf_row_cmp(accp, g, thr_p, mask_p);
 #endif
     extra(m);
     __builtin_amdgcn_sched_barrier(0);
@@ -596,10 +610,11 @@ __global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
     for (int rt = 0; rt < kBdRowTiles; ++rt) {
       uint32_t mask = 0;
       auto extra = [&](int m) {
-        if (rt == 0 && m == 2) { bd_issue_side(a, icn, NXT); ic_next = fetch_index(a, at + 64, a_end, r); }
-        if (rt == 0 && m == 5) bd_issue_feature(a, icn, h, 0, NXT);
-        if (rt == 1 && m == 4) bd_issue_feature(a, icn, h, 1, NXT);
-        if (rt == 2 && m == 4) bd_issue_feature(a, icn, h, 2, NXT);
+        // the next tile's loads go into the lightest slot (two epilogue instructions) of the first four phases
+        if (rt == 0 && m == kBdLoadSlot) { bd_issue_side(a, icn, NXT); ic_next = fetch_index(a, at + 64, a_end, r); }
+        if (rt == 1 && m == kBdLoadSlot) bd_issue_feature(a, icn, h, 0, NXT);
+        if (rt == 2 && m == kBdLoadSlot) bd_issue_feature(a, icn, h, 1, NXT);
+        if (rt == 3 && m == kBdLoadSlot) bd_issue_feature(a, icn, h, 2, NXT);
       };
       const float thr_p = rt == 0 ? thr_prev : thr_cur;            // the epilogue in flight belongs to the phase before
       if (rt & 1) bd_phase(A[rt], CUR.frag, acc1, acc0, thr_p, mask, extra);
@@ -644,7 +659,7 @@ void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   MatchArgs b = a;
   const int64_t bx = (a.n_v + kBdRowsPerBlock - 1) / kBdRowsPerBlock;
   const int64_t atiles = (a.n_a + 31) / 32;
-  int64_t want_y = (256 * 12 + bx - 1) / bx;                      // one workgroup per CU at a time: >= 12 rounds of them
+  int64_t want_y = (256 * 12 + bx - 1) / bx;                      // one workgroup per CU at a time: 12 rounds of them (6: 143 ms, 24: 140 ms, 12: 137 ms on the 2 h pair)
   if (want_y < 1) want_y = 1;
   int64_t tpb = (atiles + want_y - 1) / want_y;
   if (tpb < 1) tpb = 1;
