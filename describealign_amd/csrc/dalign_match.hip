@@ -783,20 +783,22 @@ void launch_corr(const CorrArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // exact verification of survivors (float64), hash vote, quality (:649-673)
 // ------------------------------------------------------------------------------------------
-// exact float64 re-evaluation of one pair; returns true and the quality when it is a match
-__device__ inline bool verify_pair(const VerifyArgs& a, int32_t i, int32_t v, double& q_out) {
-  if (a.mode == 0) {
-    // (feature 3 or 4 hits) and (at least two of features 0-2 hit), cheapest rejection first: a
-    // hash hit of one feature is a ~1e-3 event for an unrelated pair, so testing the two-feature
-    // alternative first rejects almost every survivor after 3-6 gathers instead of 9-15
-    const bool h3 = digit_hit(a.dig_a[3][i], a.dig_v[3][v], a.flg_v[3][v]);
-    const bool h34 = h3 ? true : digit_hit(a.dig_a[4][i], a.dig_v[4][v], a.flg_v[4][v]);
-    if (!h34) return false;
-    const int h0 = digit_hit(a.dig_a[0][i], a.dig_v[0][v], a.flg_v[0][v]) ? 1 : 0;
-    const int h1 = digit_hit(a.dig_a[1][i], a.dig_v[1][v], a.flg_v[1][v]) ? 1 : 0;
-    if (h0 + h1 == 0) return false;
-    if (h0 + h1 < 2 && !digit_hit(a.dig_a[2][i], a.dig_v[2][v], a.flg_v[2][v])) return false;
-  }
+// hash vote of one pair (:649-660): (feature 3 or 4 hits) and (at least two of features 0-2 hit),
+// cheapest rejection first: a hash hit of one feature is a ~1e-3 event for an unrelated pair, so testing
+// the two-feature alternative first rejects almost every survivor after 3-6 gathers instead of 9-15
+__device__ inline bool vote_pair(const VerifyArgs& a, int32_t i, int32_t v) {
+  if (a.mode != 0) return true;
+  const bool h3 = digit_hit(a.dig_a[3][i], a.dig_v[3][v], a.flg_v[3][v]);
+  const bool h34 = h3 ? true : digit_hit(a.dig_a[4][i], a.dig_v[4][v], a.flg_v[4][v]);
+  if (!h34) return false;
+  const int h0 = digit_hit(a.dig_a[0][i], a.dig_v[0][v], a.flg_v[0][v]) ? 1 : 0;
+  const int h1 = digit_hit(a.dig_a[1][i], a.dig_v[1][v], a.flg_v[1][v]) ? 1 : 0;
+  if (h0 + h1 == 0) return false;
+  if (h0 + h1 < 2 && !digit_hit(a.dig_a[2][i], a.dig_v[2][v], a.flg_v[2][v])) return false;
+  return true;
+}
+// exact float64 re-evaluation of one pair (:662-672); returns true and the quality when it is a match
+__device__ inline bool correlate_pair(const VerifyArgs& a, int32_t i, int32_t v, double& q_out) {
   double prob = 1.0;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -816,18 +818,24 @@ __device__ inline bool verify_pair(const VerifyArgs& a, int32_t i, int32_t v, do
   return true;
 }
 
-// Grid-stride over the staged records: expand each row mask into (i, v) pairs, verify, and stage
-// the matches of the whole block in LDS; output space is reserved with ONE global atomic per
-// flush (a single hot counter sustains only ~90 atomics/us, and there are up to 1e9 pairs).
+// Grid-stride over the staged records, two steps per round so that the expensive step runs on full
+// wavefronts: (1) every thread expands its record's row mask into (i, v) pairs and takes the hash vote
+// (a few gathers; ~1 pair in 8 passes) -- the passing pairs are collected in LDS; (2) the workgroup
+// re-evaluates the collected pairs in float64, 256 at a time, one per thread (3 x 41 FMAs on unaligned
+// doubles; done per record this ran with one lane in eight busy).  Matches are staged per workgroup in
+// LDS and output space is reserved with ONE global atomic per flush (a single hot counter sustains only
+// ~90 atomics/us, and there are up to 1e9 pairs).
 constexpr int kVerifyThreads = 256;
 constexpr int kVerifyStage = 1024;
+constexpr int kVerifyCand = kVerifyThreads * 16 + kVerifyThreads;     // a round adds at most 16 pairs per thread to fewer than 256 left over
 
 __global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyArgs a, unsigned long long n_rec) {
   __shared__ unsigned long long s_key[kVerifyStage];
   __shared__ double s_q[kVerifyStage];
-  __shared__ unsigned int s_n;
+  __shared__ unsigned long long s_cand[kVerifyCand];
+  __shared__ unsigned int s_n, s_nc;
   __shared__ unsigned long long s_base;
-  if (threadIdx.x == 0) s_n = 0;
+  if (threadIdx.x == 0) { s_n = 0; s_nc = 0; }
   __syncthreads();
   const unsigned long long stride = (unsigned long long)gridDim.x * kVerifyThreads;
   const unsigned long long rounds = (n_rec + stride - 1) / stride;
@@ -838,40 +846,54 @@ __global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyArgs a, unsigne
     const int64_t vtile = (int64_t)((rec >> 17) & 0xFFFFFFull);
     const int h = (int)((rec >> 16) & 1ull);
     uint32_t mask = (uint32_t)(rec & 0xFFFFull);
-    while (mask != 0u) {
+    while (mask != 0u) {                                              // step 1: expand + vote
       const int g = __ffs(mask) - 1;
       mask &= mask - 1u;
       const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
       const int64_t vr = vtile * 32 + row;
-      double q;
       if (vr < a.n_v) {
         const int32_t v = a.vlist[vr];
-        if (verify_pair(a, i, v, q)) {
-          const unsigned int pos = atomicAdd(&s_n, 1u);
-          if (pos < (unsigned)kVerifyStage) {
-            s_key[pos] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v;
-            s_q[pos] = q;
-          } else {                                   // stage full: rare, go straight to global
-            const unsigned long long gp = atomicAdd(a.n_out, 1ull);
-            if (gp < a.out_capacity) { a.keys[gp] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v; a.quals[gp] = q; }
-          }
-        }
+        if (vote_pair(a, i, v)) s_cand[atomicAdd(&s_nc, 1u)] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v;
       }
     }
     __syncthreads();
-    // flush when the stage could overflow in the next round (each thread adds at most 16)
-    const unsigned int n = s_n < (unsigned)kVerifyStage ? s_n : (unsigned)kVerifyStage;
     const bool last = (rnd + 1 == rounds);
-    if (n > (unsigned)(kVerifyStage / 2) || (last && n > 0)) {
-      if (threadIdx.x == 0) s_base = atomicAdd(a.n_out, (unsigned long long)n);
-      __syncthreads();
-      for (unsigned int t = threadIdx.x; t < n; t += kVerifyThreads) {
-        const unsigned long long gp = s_base + t;
-        if (gp < a.out_capacity) { a.keys[gp] = s_key[t]; a.quals[gp] = s_q[t]; }
+    while (true) {                                                    // step 2: full batches (any remainder in the last round)
+      const unsigned int nc = s_nc;                                   // uniform: read behind a barrier
+      if (nc < (unsigned)kVerifyThreads && !(last && nc > 0)) break;
+      const unsigned int take = nc < (unsigned)kVerifyThreads ? nc : (unsigned)kVerifyThreads;
+      const unsigned int base = nc - take;
+      if (threadIdx.x < take) {
+        const unsigned long long key = s_cand[base + threadIdx.x];
+        double q;
+        if (correlate_pair(a, (int32_t)(key >> 32), (int32_t)(key & 0xffffffffu), q)) {
+          const unsigned int pos = atomicAdd(&s_n, 1u);               // at most 512 + 256 <= kVerifyStage
+          s_key[pos] = key; s_q[pos] = q;
+        }
       }
       __syncthreads();
-      if (threadIdx.x == 0) s_n = 0;
+      if (threadIdx.x == 0) s_nc = base;
+      const unsigned int n = s_n;
+      if (n > (unsigned)(kVerifyStage / 2)) {                         // the next batch could overflow the stage
+        if (threadIdx.x == 0) s_base = atomicAdd(a.n_out, (unsigned long long)n);
+        __syncthreads();
+        for (unsigned int t = threadIdx.x; t < n; t += kVerifyThreads) {
+          const unsigned long long gp = s_base + t;
+          if (gp < a.out_capacity) { a.keys[gp] = s_key[t]; a.quals[gp] = s_q[t]; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+      }
       __syncthreads();
+    }
+  }
+  const unsigned int n = s_n;                                         // what is left in the stage
+  if (n > 0) {
+    if (threadIdx.x == 0) s_base = atomicAdd(a.n_out, (unsigned long long)n);
+    __syncthreads();
+    for (unsigned int t = threadIdx.x; t < n; t += kVerifyThreads) {
+      const unsigned long long gp = s_base + t;
+      if (gp < a.out_capacity) { a.keys[gp] = s_key[t]; a.quals[gp] = s_q[t]; }
     }
   }
 }

@@ -411,6 +411,28 @@ def test_bf16_prefilter_loses_no_match_at_size(ctx, ctx_bf16, seconds):
   assert np.array_equal(k32, k16) and np.array_equal(q32, q16)
 
 
+@pytest.mark.parametrize("seed,seconds", [(41, 150.0), (7, 333.3), (13, 61.7)])
+def test_bf16_prefilter_equals_f32_with_gaps_in_the_row_lists(ctx, ctx_bf16, seed, seconds):
+  """The bf16 GEMM streams 32-column tiles of NON-QUIET audio frames and keeps 192 video rows per
+  wavefront: silences make the column frames non-consecutive (per-lane operand runs far apart) and odd
+  durations leave partial tiles / partly empty row groups at every edge.  Verified set and qualities
+  must equal the f32 path's."""
+  from describealign_amd import synth
+  pair = synth.make_pair(seed, seconds, n_jumps=3, first_gap=8.0)
+  v = pair.video.copy(); a = pair.audio.copy()
+  sr = synth.SAMPLE_RATE
+  rng = np.random.default_rng(seed)
+  for _ in range(6):                                      # silences of 0.2 .. 6 s on both sides
+    for arr in (v, a):
+      t0 = float(rng.uniform(1.0, seconds - 8.0)); d = float(rng.uniform(0.2, 6.0))
+      arr[..., int(t0 * sr):int((t0 + d) * sr)] = 0
+  vf = ctx.features(v, 0); af = ctx.features(a, 1)
+  k32, q32 = _match_keys(ctx, vf, af)
+  k16, q16 = _match_keys(ctx_bf16, [f.copy() for f in vf], [f.copy() for f in af])
+  assert len(k32) > 1000
+  assert np.array_equal(k32, k16) and np.array_equal(q32, q16)
+
+
 def test_silence_heavy_pair_vs_oracle(ctx):
   """Long stretches of digital silence on both sides (quiet frames are excluded from matching,
   :629-630, :657-658): GPU path vs the oracle, end to end."""
