@@ -475,12 +475,10 @@ def _lp_worker(args):
   return lp, time.perf_counter() - t0
 
 
-def cpu_order(cpus=None):
-  """The CPUs this process may use, ordered so that the first K are the best K places for K
-  single-threaded solver processes: one hardware thread per physical core first (a HiGHS solve runs
-  2x slower next to a busy SMT sibling), dealt round-robin over the L3 domains (CCDs) so that
-  neighbours share as little cache as possible; the second hardware threads come last.  Read from
-  sysfs; without it, the usual Linux numbering (second half = siblings) is assumed."""
+def _cpu_topology(cpus=None):
+  """(primary, secondary, domain): one hardware thread per physical core, their SMT siblings, and the L3
+  domain (CCD) of every CPU this process may use.  Read from sysfs; without it, the usual Linux numbering
+  (second half = siblings, eight cores to an L3) is assumed."""
   import os
   cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
   allowed = set(cpus)
@@ -507,6 +505,15 @@ def cpu_order(cpus=None):
     half = max(1, len(cpus) // 2)
     primary, secondary = cpus[:half], cpus[half:]
     domain = {c: (c % half) // 8 for c in cpus}
+  return primary, secondary, domain
+
+
+def cpu_order(cpus=None):
+  """The CPUs this process may use, ordered so that the first K are the best K places for K
+  single-threaded solver processes: one hardware thread per physical core first (a HiGHS solve runs
+  2x slower next to a busy SMT sibling), dealt round-robin over the L3 domains (CCDs) so that
+  neighbours share as little cache as possible; the second hardware threads come last."""
+  primary, secondary, domain = _cpu_topology(cpus)
 
   def deal(group):
     buckets = {}
@@ -540,15 +547,17 @@ def _pin_worker(slot_counter, lock, first_slot, order):
 
 
 def default_worker_count(local_world: int = 1) -> int:
-  """LP worker processes per rank.  One HiGHS solve wants a whole L3 slice: on the GPU box's host
-  (2 x 64 cores, 16 CCDs) 16 pinned solves run at full speed (0.43-0.46 s each, 24 solves/s), 32-48
-  give the best aggregate (30-31 solves/s at 0.9-1.3 s each) and 128 only 26 -- so a rank on its own
-  takes 24 workers and ranks sharing a host split 48 between them."""
-  import os
-  ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+  """LP worker processes per rank, from the host's cache topology.  One HiGHS solve of a long pair
+  wants a whole L3 slice: on the GPU box's host (2 x 64 cores, 16 L3 domains) the 2 h pairs' LP runs
+  at 2.4 solves/s whether 16, 24 or 32 workers share the domains (time per solve grows in proportion),
+  and the 22 min pairs' LP peaks between 32 and 48 workers (30-31 solves/s; 128 workers: 26).  So: 1.5
+  workers per L3 domain for a rank on its own (24 there), 3 per domain split between ranks that share
+  a host (48 there), never more than one per physical core."""
+  primary, _, domain = _cpu_topology()
+  n_l3 = max(1, len({domain[c] for c in primary}))
   local_world = max(1, int(local_world))
-  want = 24 if local_world == 1 else max(2, 48 // local_world)
-  return int(max(2, min(want, (ncpu // 2) // local_world)))
+  want = (3 * n_l3 + 1) // 2 if local_world == 1 else max(2, (3 * n_l3) // local_world)
+  return int(max(2, min(want, max(1, len(primary) // local_world))))
 
 
 # ---- worker-process side of the batch pipeline ---------------------------------------------------

@@ -408,6 +408,21 @@ def test_cli_accepts_the_reference_flags():
   assert "v.mp4" in flat and "a.mp3" in flat and "x_" in flat and True in flat
 
 
+def test_worker_count_follows_the_l3_topology(monkeypatch):
+  """1.5 LP workers per L3 domain for a rank on its own, 3 per domain split between ranks sharing the host,
+  never more than one per physical core: the GPU box's host (2 x 64 cores, 16 CCDs, SMT) gives 24 / 6."""
+  from describealign_amd import align as A
+  primary = list(range(128)); secondary = list(range(128, 256))
+  domain = {c: (c % 128) // 8 for c in range(256)}
+  monkeypatch.setattr(A, "_cpu_topology", lambda cpus=None: (primary, secondary, domain))
+  assert A.default_worker_count(1) == 24
+  assert A.default_worker_count(8) == 6
+  assert A.default_worker_count(2) == 24
+  small = ([0, 1, 2, 3], [4, 5, 6, 7], {c: 0 for c in range(8)})
+  monkeypatch.setattr(A, "_cpu_topology", lambda cpus=None: small)
+  assert A.default_worker_count(1) == 2 and A.default_worker_count(4) == 2
+
+
 def test_cpu_order_is_a_permutation_with_physical_cores_first():
   from describealign_amd import align as A
   cpus = sorted(os.sched_getaffinity(0))
