@@ -433,6 +433,28 @@ def test_bf16_prefilter_equals_f32_with_gaps_in_the_row_lists(ctx, ctx_bf16, see
   assert np.array_equal(k32, k16) and np.array_equal(q32, q16)
 
 
+def test_bf16_prefilter_repeats_itself_on_random_pairs(ctx, ctx_bf16):
+  """k_match_bf16 places its MFMAs by hand (inline assembly), outside the compiler's hazard recogniser:
+  a timing hazard would show as matches that come and go.  Random durations, jump counts and silences;
+  every pair is matched three times and must equal the f32 path's set and qualities each time."""
+  from describealign_amd import synth
+  rng = np.random.default_rng(2024)
+  sr = synth.SAMPLE_RATE
+  for trial in range(10):
+    secs = float(rng.uniform(40, 600)); seed = int(rng.integers(1, 10000))
+    pair = synth.make_pair(seed, secs, n_jumps=int(rng.integers(1, 6)), first_gap=float(rng.uniform(2, 20)))
+    v = pair.video.copy(); a = pair.audio.copy()
+    for _ in range(int(rng.integers(0, 5))):
+      for arr in (v, a):
+        t0 = float(rng.uniform(1.0, max(2.0, secs - 8.0))); d = float(rng.uniform(0.1, 5.0))
+        arr[..., int(t0 * sr):int((t0 + d) * sr)] = 0
+    vf = ctx.features(v, 0); af = ctx.features(a, 1)
+    k32, q32 = _match_keys(ctx, vf, af)
+    for rep in range(3):
+      k16, q16 = _match_keys(ctx_bf16, [f.copy() for f in vf], [f.copy() for f in af])
+      assert np.array_equal(k32, k16) and np.array_equal(q32, q16), (trial, rep, secs, seed, len(k32), len(k16))
+
+
 def test_silence_heavy_pair_vs_oracle(ctx):
   """Long stretches of digital silence on both sides (quiet frames are excluded from matching,
   :629-630, :657-658): GPU path vs the oracle, end to end."""
