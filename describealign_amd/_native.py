@@ -15,7 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DALIGN_LIB") or os.path.join(_HERE, "libdalign.so")   # DALIGN_LIB: diagnostic builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 PREC_F32, PREC_BF16 = 0, 1
 SIDE_VIDEO, SIDE_AUDIO = 0, 1
@@ -36,7 +36,7 @@ class Stats(C.Structure):
       "features_ms", "features_bytes", "prep_ms", "gemm_ms", "gemm_pairs", "gemm_flops", "verify_ms",
       "survivors", "matches", "chain_ms", "refine_kernel_ms", "refine_dp_ms", "refine_points", "h2d_ms",
       "resample_ms", "resample_points", "resample_bytes", "correlate_ms", "correlate_windows", "viterbi_ms",
-      "splice_ms", "splice_points", "stretch_prepare_ms", "stretch_finish_ms")]
+      "splice_ms", "splice_points", "stretch_prepare_ms", "stretch_finish_ms", "chain_columns", "chain_column_width")]
 
   def as_dict(self):
     return {n: getattr(self, n) for n, _ in self._fields_}

@@ -437,14 +437,23 @@ def align_tiled(video_features, audio_desc_features, video_energy, audio_desc_en
   t0 = time.perf_counter()
   rb, re = row_blocks(max(0, n_ae - (2 * NODE_FRAMES - 1)), group.world)[group.rank]
   import contextlib
-  with (match_lock if match_lock is not None else contextlib.nullcontext()):
-    n_local = _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm, rows=(rb, re))
-    ctx.trim()
+  n_local, match_err = 0, None
+  try:
+    with (match_lock if match_lock is not None else contextlib.nullcontext()):
+      n_local = _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm, rows=(rb, re))
+      ctx.trim()
+  except BaseException as e:                                 # e.g. out of memory on this rank's survivor buffer
+    match_err = e
+  # a rank that failed must not leave the others blocked in the gather
+  if not group.all_ok(match_err is None):
+    if match_err is not None:
+      raise match_err
+    raise RuntimeError("align_tiled: the matching stage failed on another rank")
   t1 = time.perf_counter()
   total = group.gather_matches_to_root(ctx, n_local)
   t2 = time.perf_counter()
   tm.update(match_s=t1 - t0, gather_s=t2 - t1, n_matches=total if total is not None else n_local, rows=(rb, re))
-  out, err = None, None
+  out, err, root_exc = None, None, None
   if group.rank == 0:
     try:
       gathered = getattr(ctx, "_gathered", None)
@@ -460,9 +469,16 @@ def align_tiled(video_features, audio_desc_features, video_energy, audio_desc_en
       lp = solve_trend_lp(fx, fy)
       tm["lp_s"] = time.perf_counter() - t3
       out = _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm)
-    except RuntimeError as e:
-      err = str(e)
-  out = group.broadcast_result(out, err)
+    except BaseException as e:                               # whatever it is, the other ranks are waiting in the broadcast
+      err = f"{type(e).__name__}: {e}" if not isinstance(e, RuntimeError) else str(e)
+      err = err or type(e).__name__
+      root_exc = e
+  try:
+    out = group.broadcast_result(out, err)
+  except RuntimeError:
+    if root_exc is not None and not isinstance(root_exc, RuntimeError):
+      raise root_exc                                         # rank 0: the original exception, now that everyone has been told
+    raise
   tm["total_s"] = time.perf_counter() - t0
   return out
 

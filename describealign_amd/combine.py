@@ -214,7 +214,13 @@ def _finish_pair(outputs, video_file, audio_desc_file, has_audio_extension, ctx,
   elif ffmpeg is not None and not has_audio_extension:
     print("  processing output file...                   \r", end='')
     # to make ffmpeg cut at the last key frame before the audio starts, use a timestamp after it (:1162-1164)
-    after_start_key_frame = get_closest_key_frame_time(video_file, video_offset)
+    try:
+      after_start_key_frame = get_closest_key_frame_time(video_file, video_offset)
+    except (RuntimeError, OSError, ValueError) as e:
+      # no ffprobe next to ffmpeg, or it could not read the file: cut at the offset itself instead of
+      # losing the pair after all the alignment work is done
+      print(f"  WARNING: key frame lookup failed ({e}); cutting at the audio start instead")
+      after_start_key_frame = max(0., video_offset)
     argv = _mux_command(ffmpeg, video_file, audio_desc_file, output_filename, setts_cmd, video_offset,
                         after_start_key_frame, median_slope)
     res = subprocess.run(argv, capture_output=True)

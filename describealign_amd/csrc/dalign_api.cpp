@@ -54,6 +54,10 @@ struct Side {
 struct ChainSlot {
   DevBuf keys, q;                 // matches sorted by (i, v): packed keys and qualities
   DevBuf rank, flags, rows, pred, tree, ids, out_iv, small, temp;
+  // column-pipelined DP: row ordinals, partition keys / ids, column-major matches, per-row records, control words
+  DevBuf rowid, ckey, cval, c_row, c_lr, c_q, c_gid, col_start, msg, ctl;
+  int64_t rows_hint = 0;          // audio rows of the match that filled this slot (upper bound on the rows with matches), 0 = unknown
+  int mode = 0;                   // how the DP in flight was launched: 0 = columns, 1 / 4 = one workgroup of 1 / 4 wavefronts
   hipStream_t stream = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr, ready = nullptr;
   int64_t n = 0, n_ranks = 0;
@@ -61,7 +65,8 @@ struct ChainSlot {
   unsigned long long ticket = 0;
   long long* h_small = nullptr;   // pinned copy of `small`: [0] rows | err << 32, [1] best id, [2] path length
   void release() {
-    for (DevBuf* b : {&keys, &q, &rank, &flags, &rows, &pred, &tree, &ids, &out_iv, &small, &temp}) b->release();
+    for (DevBuf* b : {&keys, &q, &rank, &flags, &rows, &pred, &tree, &ids, &out_iv, &small, &temp,
+                      &rowid, &ckey, &cval, &c_row, &c_lr, &c_q, &c_gid, &col_start, &msg, &ctl}) b->release();
     if (stream) (void)hipStreamDestroy(stream);
     for (hipEvent_t e : {e0, e1, ready}) if (e) (void)hipEventDestroy(e);
     if (h_small) (void)hipHostFree(h_small);
@@ -97,6 +102,7 @@ struct da_ctx {
   // state carried from da_match_begin to da_match_finish
   bool match_pending = false;
   bool fetch_ready = false;       // results of the last finished match are resident (keys0 / the result slot)
+  bool rows_of_resident = false;  // vlist / res_lv / pend_nv still describe the RESIDENT match (no da_match_begin since its finish)
   int pend_mode = 0; int64_t pend_nv = 0; size_t pend_cap = 0;
   hipEvent_t gemm_e0 = nullptr, gemm_e1 = nullptr, prep_e0 = nullptr, prep_e1 = nullptr;
   hipStream_t copy_stream = nullptr;
@@ -178,7 +184,7 @@ void build_tables(FeatTables& T) {
 
 extern "C" {
 
-int da_abi_version(void) { return 3; }
+int da_abi_version(void) { return 4; }
 
 const char* da_last_error(const da_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -430,6 +436,7 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
     return fail(c, DA_ERR_ARG, "da_match: inconsistent lengths");
   HIP_TRY(c, hipSetDevice(c->device));
   c->match_ready = false; c->match_pending = false;       // fetch_ready is untouched: the previous results stay fetchable
+  c->rows_of_resident = false;                            // ... but the video row list is about to become the next pair's
   c->res_lv = v_lengths[0];
   Side& V = c->side[0]; Side& A = c->side[1];
   HIP_TRY(c, hipEventRecord(c->prep_e0, c->stream));
@@ -566,6 +573,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
     HIP_TRY(c, sl.keys.ensure(sizeof(unsigned long long) * std::max<size_t>(1, n_match)));
     HIP_TRY(c, sl.q.ensure(sizeof(double) * std::max<size_t>(1, n_match)));
     sl.n = (int64_t)n_match; sl.n_ranks = n_v; sl.state = 1;
+    sl.rows_hint = c->last_match.n_a;
     c->res_slot = si;
     if (n_match > 0) {
       size_t tmp_bytes = 0;
@@ -587,6 +595,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
   c->st.matches = (double)n_match;
   c->n_match_resident = n_match;
   c->fetch_ready = true;
+  c->rows_of_resident = true;
   *n_out = (int64_t)n_match;
   return DA_OK;
 }
@@ -644,7 +653,8 @@ extern "C" int da_match_export_device(da_ctx* c, uint64_t* d_keys, double* d_q, 
 
 extern "C" int da_match_import_device(da_ctx* c, const uint64_t* d_keys, const double* d_q, int64_t n) {
   if (!c) return DA_ERR_ARG;
-  if (!c->match_ready) return fail(c, DA_ERR_STATE, "da_match_import_device: call da_match on this context first (its video row list ranks the matches)");
+  if (!c->match_ready || !c->rows_of_resident)
+    return fail(c, DA_ERR_STATE, "da_match_import_device: call da_match on this context first (its video row list ranks the matches)");
   if (n < 0 || (n > 0 && (!d_keys || !d_q))) return fail(c, DA_ERR_ARG, "da_match_import_device: bad argument");
   HIP_TRY(c, hipSetDevice(c->device));
   if (c->res_slot >= 0 && c->slots[c->res_slot]->state == 1) c->slots[c->res_slot]->state = 0;
@@ -663,6 +673,7 @@ extern "C" int da_match_import_device(da_ctx* c, const uint64_t* d_keys, const d
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   sl.n = n; sl.n_ranks = c->pend_nv; sl.state = 1;
+  sl.rows_hint = c->side[1].lmax;                       // the imported list may cover every audio row of the pair
   c->res_slot = si;
   c->n_match_resident = (unsigned long long)n;
   c->st.matches = (double)n;
@@ -694,7 +705,8 @@ extern "C" int da_trim(da_ctx* c) {
   }
   for (ChainSlot* sl : c->slots)
     if (sl->state == 0)
-      for (DevBuf* b : {&sl->keys, &sl->q, &sl->rank, &sl->flags, &sl->rows, &sl->pred, &sl->tree, &sl->ids, &sl->out_iv, &sl->temp}) b->release();
+      for (DevBuf* b : {&sl->keys, &sl->q, &sl->rank, &sl->flags, &sl->rows, &sl->pred, &sl->tree, &sl->ids, &sl->out_iv, &sl->temp,
+                        &sl->rowid, &sl->ckey, &sl->cval, &sl->c_row, &sl->c_lr, &sl->c_q, &sl->c_gid, &sl->col_start, &sl->msg, &sl->ctl}) b->release();
   return DA_OK;
 }
 
@@ -804,7 +816,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
   HIP_TRY(c, sl.rank.ensure(sizeof(int32_t) * nn)); HIP_TRY(c, sl.flags.ensure(nn));
   HIP_TRY(c, sl.rows.ensure(sizeof(int32_t) * (nn + 1))); HIP_TRY(c, sl.pred.ensure(sizeof(int32_t) * nn));
   HIP_TRY(c, sl.ids.ensure(sizeof(int32_t) * nn)); HIP_TRY(c, sl.out_iv.ensure(sizeof(int32_t) * 2 * nn));
-  HIP_TRY(c, sl.tree.ensure(16 * ((size_t)sl.n_ranks + 2 + 256)));       // + one scrap record per thread
+  HIP_TRY(c, sl.tree.ensure(16 * ((size_t)sl.n_ranks + 2 + 256)));       // rows kernels: + one scrap record per thread
   HIP_TRY(c, sl.small.ensure(128));
   const size_t tb = da::chain_rows_temp_bytes(n);
   HIP_TRY(c, sl.temp.ensure(tb + 256));
@@ -827,23 +839,55 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     L.rankmap = c->rankmap.as<int32_t>(); L.rankmap_len = c->res_lv;
   }
   HIP_TRY(c, hipMemsetAsync(sl.small.p, 0, 128, c->stream));
-  HIP_TRY(c, hipMemsetAsync(sl.tree.p, 0, 16 * ((size_t)sl.n_ranks + 2), c->stream));
+  // Which kernel: the column pipeline (default), or ONE workgroup of one / four wavefronts walking the rows
+  // (DALIGN_CHAIN_KERNEL=rows, then DALIGN_CHAIN_WAVES=1|4: the round-2 kernels, kept as a cross-check).
   {
-    // four wavefronts per row super-step (256 matches at a time) unless the input is tiny or
-    // DALIGN_CHAIN_WAVES=1 asks for the one-wavefront kernel: 1.76 s instead of 3.0 s per 2 h pair
-    // (255 matches per row), 157 instead of 192 ms per 22 min pair (55 per row)
+    const char* kern = std::getenv("DALIGN_CHAIN_KERNEL");
     const char* force = std::getenv("DALIGN_CHAIN_WAVES");
-    L.wide = force ? (std::atoi(force) >= 4) : (n >= 4096);
+    sl.mode = 0;
+    if (kern && std::strcmp(kern, "rows") == 0) sl.mode = force ? (std::atoi(force) >= 4 ? 4 : 1) : (n >= 4096 ? 4 : 1);
+    L.wide = sl.mode == 4;
   }
-  if (da::launch_chain_prep(L, c->stream) != 0) return fail(c, DA_ERR_ARG, "da_chain: %lld matches / %lld video rows exceed the kernel's range", (long long)n, (long long)sl.n_ranks);
+  da::ChainColumns K{};
+  if (sl.mode == 0 && n > 0) {
+    const int64_t rows_bound = std::min<int64_t>(n, sl.rows_hint > 0 ? sl.rows_hint : n);
+    const da::ChainColumnPlan plan = da::chain_columns_plan(n, sl.n_ranks, rows_bound);
+    K.n_cols = plan.n_cols; K.width = plan.width;
+    K.msg_stride = (rows_bound + 63) / 64 * 64;
+    const size_t ctb = da::chain_columns_temp_bytes(n);
+    HIP_TRY(c, sl.rowid.ensure(sizeof(int32_t) * nn));
+    HIP_TRY(c, sl.ckey.ensure(sizeof(uint16_t) * 2 * nn)); HIP_TRY(c, sl.cval.ensure(sizeof(uint32_t) * 2 * nn));
+    HIP_TRY(c, sl.c_row.ensure(sizeof(uint32_t) * nn)); HIP_TRY(c, sl.c_lr.ensure(sizeof(uint16_t) * nn));
+    HIP_TRY(c, sl.c_q.ensure(sizeof(double) * nn)); HIP_TRY(c, sl.c_gid.ensure(sizeof(uint32_t) * nn));
+    HIP_TRY(c, sl.col_start.ensure(sizeof(int32_t) * ((size_t)K.n_cols + 1)));
+    HIP_TRY(c, sl.msg.ensure(16 * (size_t)K.msg_stride * (size_t)K.n_cols));
+    HIP_TRY(c, sl.ctl.ensure(sizeof(uint32_t) * ((size_t)da::kChainCtlHead + (size_t)K.n_cols)));
+    HIP_TRY(c, sl.temp.ensure(std::max(tb, ctb) + 256));
+    K.rowid1 = sl.rowid.as<int32_t>();
+    K.key_in = sl.ckey.as<uint16_t>(); K.key_out = sl.ckey.as<uint16_t>() + nn;
+    K.val_in = sl.cval.as<uint32_t>(); K.val_out = sl.cval.as<uint32_t>() + nn;
+    K.c_row = sl.c_row.as<uint32_t>(); K.c_lr = sl.c_lr.as<uint16_t>(); K.c_q = sl.c_q.as<double>(); K.c_gid = sl.c_gid.as<uint32_t>();
+    K.col_start = sl.col_start.as<int32_t>(); K.msg = reinterpret_cast<uint4*>(sl.msg.p); K.ctl = sl.ctl.as<uint32_t>();
+    K.temp = sl.temp.p; K.temp_bytes = ctb;
+    L.temp = sl.temp.p;
+    c->st.chain_columns = (double)K.n_cols; c->st.chain_column_width = (double)K.width;
+  } else {
+    HIP_TRY(c, hipMemsetAsync(sl.tree.p, 0, 16 * ((size_t)sl.n_ranks + 2), c->stream));
+    c->st.chain_columns = 0; c->st.chain_column_width = 0;
+  }
+  if (da::launch_chain_prep(L, c->stream, sl.mode == 0) != 0) return fail(c, DA_ERR_ARG, "da_chain: %lld matches / %lld video rows exceed the kernel's range", (long long)n, (long long)sl.n_ranks);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipEventRecord(sl.ready, c->stream));
   HIP_TRY(c, hipStreamWaitEvent(st, sl.ready, 0));
   HIP_TRY(c, hipEventRecord(sl.e0, st));
-  if (da::launch_chain_dp(L, st) != 0) return fail(c, DA_ERR_DEVICE, "da_chain: launch failed");
+  if (sl.mode == 0) {
+    if (da::launch_chain_columns(L, K, st) != 0) return fail(c, DA_ERR_DEVICE, "da_chain: launch failed");
+  } else if (da::launch_chain_dp(L, st) != 0) return fail(c, DA_ERR_DEVICE, "da_chain: launch failed");
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipEventRecord(sl.e1, st));
   HIP_TRY(c, hipMemcpyAsync(sl.h_small, sl.small.p, 32, hipMemcpyDeviceToHost, st));
+  sl.h_small[4] = 0;
+  if (sl.mode == 0 && n > 0) HIP_TRY(c, hipMemcpyAsync(sl.h_small + 4, sl.ctl.p, 8, hipMemcpyDeviceToHost, st));   // [1] = abort flag
   sl.state = 2;
   sl.ticket = c->next_ticket++;
   return DA_OK;
@@ -863,6 +907,10 @@ int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int
   }
   const int err = (int)((unsigned long long)sl.h_small[0] >> 32);
   const int64_t L = sl.n > 0 ? (int64_t)sl.h_small[2] : 0;
+  if (sl.mode == 0 && ((unsigned long long)sl.h_small[4] >> 32) != 0) {
+    sl.state = 0;
+    return fail(c, DA_ERR_DEVICE, "da_chain: a column of the chain DP waited more than 20 s for its neighbour (device oversubscribed?)");
+  }
   if (err) {
     sl.state = 0;
     return fail(c, DA_ERR_ARG, err & 1 ? "da_chain: qualities must be finite and positive (describealign.py:672 yields (0, 50])"
@@ -912,6 +960,7 @@ extern "C" int da_chain(da_ctx* c, const int32_t* pi, const int32_t* pv, const d
     HIP_TRY(c, hipMemcpyAsync(sl.rank.p, ranks.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
   }
   sl.n = n; sl.n_ranks = nr;
+  { int64_t rows = 0; for (int64_t k = 0; k < n; ++k) rows += (k == 0 || pi[k] != pi[k - 1]); sl.rows_hint = rows; }
   int rc = chain_enqueue(c, sl, false);
   if (rc) { (void)hipStreamSynchronize(c->stream); sl.state = 0; return rc; }
   HIP_TRY(c, hipStreamSynchronize(c->stream));          // the host staging vectors go out of scope
@@ -924,12 +973,15 @@ extern "C" int da_chain_begin(da_ctx* c, uint64_t* ticket) {
   if (!c) return DA_ERR_ARG;
   if (!ticket) return fail(c, DA_ERR_ARG, "da_chain_begin: null ticket");
   if (!c->fetch_ready) return fail(c, DA_ERR_STATE, "da_chain_begin: no finished match is resident");
+  if (!c->rows_of_resident)
+    return fail(c, DA_ERR_STATE, "da_chain_begin: da_match_begin has been called since the resident match finished; its video row list "
+                                 "(the ranks of the matches) is gone -- call da_chain_begin before the next da_match_begin");
   HIP_TRY(c, hipSetDevice(c->device));
   int si = c->res_slot;
   if (si < 0) {                                         // the match produced nothing: an empty DP
     si = acquire_slot(c);
     if (si < 0) return fail(c, DA_ERR_STATE, "da_chain_begin: all chain slots are in flight");
-    c->slots[si]->n = 0; c->slots[si]->n_ranks = 0;
+    c->slots[si]->n = 0; c->slots[si]->n_ranks = 0; c->slots[si]->rows_hint = 0;
   }
   ChainSlot& sl = *c->slots[si];
   if (sl.state == 2) return fail(c, DA_ERR_STATE, "da_chain_begin: the chain DP of this match is already in flight");

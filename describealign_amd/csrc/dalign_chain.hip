@@ -28,6 +28,8 @@
 // later pairs; nothing of the match list ever goes to the host, only the path does.
 #include "dalign_common.h"
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cstdlib>
 
 namespace da {
 
@@ -490,6 +492,324 @@ __global__ __launch_bounds__(256) void k_chain_gather(const unsigned long long* 
   }
 }
 
+// =====================================================================================================
+// Column-pipelined DP (the default).  For a match k of rank column C in audio row i
+//     {k' < k, v' <= v} = {matches of columns < C in rows <= i}  u  {matches k' < k of column C with rank' <= rank}
+// so a column needs from the columns to its left ONE (sum, id) record per audio row -- B_i(C), the
+// lexicographic maximum over their matches in rows <= i -- and hands B_i(C + 1) = max(B_i(C), its own matches
+// in rows <= i) to the right.  One single-wavefront workgroup per column; its Fenwick tree covers only the
+// column's `width` ranks and lives entirely in LDS; the columns form a pipeline over the rows (64-row
+// batches of records through global memory: write-through stores, a counter per column, polled with
+// L1-bypassing loads).  Inside a column the matches are taken 64 at a time, one per lane ("window"):
+//   * prefix maxima from the tree as it stood before the window (all lanes at once, LDS only);
+//   * dominance among the window's own matches by a sequential sweep -- match j's final sum is broadcast
+//     (v_readlane) and taken by the later lanes with rank >= rank_j whose best is not larger; later ids win
+//     ties, which is what the reference's frontier does (:679-680);
+//   * the window's matches enter the tree in two LDS-atomic phases: max on the sums (ds_max_u64: the sums
+//     are non-negative doubles, ordered like their bit patterns), then max on the ids where the sum is the
+//     lane's own (newer matches have larger ids, so a stale id of a smaller sum always loses).
+// Every sum is still "predecessor's sum + q", one IEEE addition, so sums, comparisons and ties are those
+// of the reference whatever the column width.  Column numbers are taken from a ticket counter, so a
+// workgroup only ever waits for workgroups that are already running, and every column writes its records
+// to a buffer of its own (no back-pressure): the pipeline cannot deadlock however many columns are resident.
+// tests/chain_col_model.cpp is the CPU model of exactly this decomposition.
+
+struct ColArgs {
+  const uint32_t* c_row; const uint16_t* c_lr; const double* c_q; const uint32_t* c_gid;
+  const int32_t* col_start; const int32_t* d_nrows;   // *d_nrows = number of audio rows (device)
+  int n_cols, width;
+  uint4* msg; int64_t msg_stride;
+  uint32_t* ctl;
+  int32_t* pred; int64_t* meta;
+  unsigned long long spin_limit;           // wall-clock ticks (100 MHz) a column may wait for its neighbour
+};
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_sc1_b128(const uint4* p) {        // L1-bypassing load, waited for
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return uint4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void store_sc1_b128(uint4* p, const uint4& n) {   // write-through store
+  const u32x4 v = {n.x, n.y, n.z, n.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ double shfl_f64(double x, int src) {
+  return __hiloint2double(__shfl(__double2hiint(x), src), __shfl(__double2loint(x), src));
+}
+__device__ __forceinline__ double shfl_up_f64(double x, int d) {
+  return __hiloint2double(__shfl_up(__double2hiint(x), d), __shfl_up(__double2loint(x), d));
+}
+// inclusive prefix maximum over the lanes, lexicographic on (sum, id)
+__device__ __forceinline__ void scan_lexmax(double& f, uint32_t& id, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double of = shfl_up_f64(f, d);
+    const uint32_t oi = (uint32_t)__shfl_up((int)id, d);
+    if (lane >= d && beats(of, oi, f, id)) { f = of; id = oi; }
+  }
+}
+
+}  // namespace
+
+template <int LV>      // LV = longest Fenwick path: width < 2^LV
+__global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
+  extern __shared__ uint4 s_tree[];                  // [0] empty record, [1 .. width] nodes, [width + 1] overflow dummy, then 64 per-row records
+  const int lane = threadIdx.x;
+  const int w = a.width;
+  uint4* s_rowmax = s_tree + (w + 2);
+  for (int h = lane; h < w + 2 + 64; h += 64) s_tree[h] = uint4{0u, 0u, 0u, 0u};
+  uint32_t col = 0;
+  if (lane == 0) col = __hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int C = (int)__builtin_amdgcn_readfirstlane(col);
+  __syncthreads();
+  if (C >= a.n_cols) return;
+  const int32_t n_rows = *a.d_nrows;
+  const int32_t n_batches = (n_rows + 63) >> 6;
+  int64_t cursor = a.col_start[C];
+  const int64_t end = a.col_start[C + 1];
+  const uint4* __restrict__ in = C > 0 ? a.msg + (int64_t)(C - 1) * a.msg_stride : nullptr;
+  uint4* __restrict__ out = a.msg + (int64_t)C * a.msg_stride;
+  uint32_t* done_in = a.ctl + kChainCtlHead + (C > 0 ? C - 1 : 0);
+  uint32_t* done_out = a.ctl + kChainCtlHead + C;
+  double Mf = 0.0; uint32_t Mid = 0u;               // running maximum over this column's matches (uniform)
+  uint32_t seen = 0u;                               // batches the left neighbour is known to have published
+  double Of = 0.0; uint32_t Oid = 0u;               // this lane's outgoing record of the current batch
+  const unsigned long long t_start = wall_clock64();
+
+  // the window at `cursor`, prefetched: one match per lane
+  uint32_t n_row = 0xFFFFFFFFu, n_gid = 0u; uint32_t n_lr = 0u; double n_q = 0.0;
+  auto fetch = [&](int64_t at) {
+    const int64_t k = at + lane;
+    n_row = 0xFFFFFFFFu; n_lr = 0u; n_q = 0.0; n_gid = 0u;
+    if (k < end) { n_row = a.c_row[k]; n_lr = a.c_lr[k]; n_q = a.c_q[k]; n_gid = a.c_gid[k]; }
+  };
+  fetch(cursor);
+
+  for (int32_t b = 0; b < n_batches; ++b) {
+    // ---- the records of this batch's rows from the left neighbour (lane = row)
+    double Bf = 0.0; uint32_t Bid = 0u;
+    if (C > 0) {
+      if (seen <= (uint32_t)b) {
+        unsigned spins = 0;
+        while (true) {
+          seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(done_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (seen > (uint32_t)b) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((++spins & 255u) == 0u) {
+            const uint32_t ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (ab != 0u) return;
+            if (wall_clock64() - t_start > a.spin_limit) {
+              if (lane == 0) __hip_atomic_store(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              return;
+            }
+          }
+        }
+      }
+      const uint4 m = load_sc1_b128(in + (int64_t)64 * b + lane);
+      Bf = node_cum(m); Bid = m.z;
+    }
+    s_rowmax[lane] = uint4{0u, 0u, 0u, 0u};
+    const double Mstart_f = Mf; const uint32_t Mstart_id = Mid;
+    const uint32_t row_end = (uint32_t)(64 * (b + 1));
+
+    while (true) {
+      // ---- this window: the matches at `cursor` that belong to the batch (a prefix of the lanes)
+      const uint32_t row = n_row; const uint32_t gid = n_gid; const double qv0 = n_q; const uint32_t lr0 = n_lr;
+      const bool inb = row < row_end;                 // lanes past the column's end carry row = 0xFFFFFFFF
+      const int cnt = __popcll(__ballot(inb));
+      if (cnt == 0) break;
+      cursor += cnt;
+      fetch(cursor);                                  // the next window, behind this one's work
+      const uint32_t lr = inb ? lr0 : 0u;             // rank 0: the empty record, on every path
+      const double qv = inb ? qv0 : 0.0;
+      const uint32_t id1 = inb ? gid + 1u : 0u;
+      const int rl = inb ? (int)(row - (uint32_t)(64 * b)) : 0;
+      const double Bpf = shfl_f64(Bf, rl);
+      const uint32_t Bpid = (uint32_t)__shfl((int)Bid, rl);
+
+      // ---- prefix maximum over the column's earlier windows: Fenwick query, all lanes at once
+      double tf = 0.0; uint32_t tid = 0u;
+      {
+        uint4 nd[LV];
+        uint32_t x = lr;
+#pragma unroll
+        for (int l = 0; l < LV; ++l) { nd[l] = s_tree[x]; x &= x - 1u; }
+#pragma unroll
+        for (int l = 0; l < LV; ++l) tf = max_f64(tf, node_cum(nd[l]));
+#pragma unroll
+        for (int l = 0; l < LV; ++l) tid = (node_cum(nd[l]) == tf && nd[l].z > tid) ? nd[l].z : tid;
+      }
+      // ---- dominance inside the window: match j's final sum goes to the later lanes it precedes
+      double gcol = tf; int winj = -1;
+      for (int j = 0; j < cnt; ++j) {
+        const double fcur = qv + max_f64(gcol, Bpf);
+        const double fj = read_lane(fcur, j);
+        const uint32_t lrj = (uint32_t)__builtin_amdgcn_readlane((int)lr, j);
+        const bool take = lane > j && lr >= lrj && fj >= gcol;
+        gcol = take ? fj : gcol; winj = take ? j : winj;
+      }
+      const double F = inb ? qv + max_f64(gcol, Bpf) : 0.0;      // idle lanes: the identity record, on the empty path
+      {
+        const uint32_t wid = (uint32_t)__shfl((int)id1, winj < 0 ? 0 : winj);
+        const uint32_t cid = winj >= 0 ? wid : tid;   // the column's own candidate (sum gcol)
+        const uint32_t pid = beats(Bpf, Bpid, gcol, cid) ? Bpid : cid;
+        if (inb) a.pred[gid] = (int32_t)pid - 1;
+      }
+      // ---- the window's matches enter the tree: sums first, then ids where the sum is this lane's
+      {
+        const unsigned long long Fb = (unsigned long long)__double_as_longlong(F);
+        uint32_t x = lr;
+        uint32_t path[LV];
+#pragma unroll
+        for (int l = 0; l < LV; ++l) {
+          path[l] = x <= (uint32_t)w ? x : (uint32_t)w + 1u;
+          atomicMax(reinterpret_cast<unsigned long long*>(&s_tree[path[l]]), Fb);
+          x += x & (0u - x);
+        }
+#pragma unroll
+        for (int l = 0; l < LV; ++l) {
+          const unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&s_tree[path[l]]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (cur == Fb) atomicMax(reinterpret_cast<unsigned int*>(&s_tree[path[l]]) + 2, id1);
+        }
+      }
+      // ---- running maximum of the column after every row of the window
+      double rf = F; uint32_t rid = id1;
+      scan_lexmax(rf, rid, lane);
+      if (beats(Mf, Mid, rf, rid)) { rf = Mf; rid = Mid; }
+      const uint32_t nrow = (uint32_t)__shfl_down((int)row, 1);
+      if (inb && (lane == cnt - 1 || nrow != row)) s_rowmax[rl] = make_node(rf, rid);
+      Mf = read_lane(rf, cnt - 1); Mid = (uint32_t)__builtin_amdgcn_readlane((int)rid, cnt - 1);
+      if (cnt < 64) break;
+    }
+    // ---- records for the right neighbour: max(incoming, the column's maximum over rows <= this one)
+    {
+      const uint4 rm = s_rowmax[lane];
+      double ff = node_cum(rm); uint32_t fi = rm.z;
+      scan_lexmax(ff, fi, lane);
+      if (beats(Mstart_f, Mstart_id, ff, fi)) { ff = Mstart_f; fi = Mstart_id; }
+      Of = Bf; Oid = Bid;
+      if (beats(ff, fi, Of, Oid)) { Of = ff; Oid = fi; }
+      if (C + 1 < a.n_cols) {
+        store_sc1_b128(out + (int64_t)64 * b + lane, make_node(Of, Oid));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(done_out, (uint32_t)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  // the last column's record of the last row is the heaviest match overall
+  if (C + 1 == a.n_cols && lane == 63) { a.meta[0] = (int64_t)Oid - 1; a.meta[1] = 0; }
+}
+
+// ---- preparation of the column-major arrays
+struct U8ToI32 { __device__ int32_t operator()(const uint8_t& x) const { return (int32_t)x; } };
+
+__global__ __launch_bounds__(256) void k_col_keys(const int32_t* __restrict__ rank, int64_t n, int width, uint16_t* __restrict__ key,
+                                                  uint32_t* __restrict__ val) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  key[k] = (uint16_t)((uint32_t)(rank[k] - 1) / (uint32_t)width);
+  val[k] = (uint32_t)k;
+}
+
+__global__ __launch_bounds__(256) void k_col_gather(const uint16_t* __restrict__ key, const uint32_t* __restrict__ val, int64_t n, int width,
+                                                    int n_cols, const int32_t* __restrict__ rank, const double* __restrict__ q,
+                                                    const int32_t* __restrict__ rowid1, uint32_t* __restrict__ c_row, uint16_t* __restrict__ c_lr,
+                                                    double* __restrict__ c_q, uint32_t* __restrict__ c_gid, int32_t* __restrict__ col_start) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > n) return;
+  const int prev = j > 0 ? (int)key[j - 1] : -1;
+  const int cur = j < n ? (int)key[j] : n_cols;
+  for (int c = prev + 1; c <= cur; ++c) col_start[c] = (int32_t)j;      // first match of every column (empty ones included)
+  if (j == n) return;
+  const uint32_t g = val[j];
+  c_row[j] = (uint32_t)(rowid1[g] - 1);
+  c_lr[j] = (uint16_t)((uint32_t)(rank[g] - 1) % (uint32_t)width + 1u);
+  c_q[j] = q[g];
+  c_gid[j] = g;
+}
+
+namespace {
+int bit_length(int64_t x) { int b = 0; while (((int64_t)1 << b) <= x) ++b; return b; }
+int col_bits(int n_cols) { return std::max(1, bit_length((int64_t)n_cols - 1)); }
+constexpr int kColMaxWidth = 8191;      // LV 13: 128 KiB of tree
+constexpr int kColMaxCols = 4096;
+}  // namespace
+
+ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint) {
+  // More columns = more wavefronts working, down to windows that are mostly empty: keep about half a
+  // window (32 matches) per column and 64-row batch; a column is at least 64 ranks wide and must fit LDS.
+  if (n_ranks < 1) n_ranks = 1;
+  if (rows_hint < 1) rows_hint = std::max<int64_t>(1, n / 64);
+  int64_t nc = 2 * n / rows_hint;
+  if (const char* e = std::getenv("DALIGN_CHAIN_COLS")) nc = std::atoll(e);
+  else nc = std::min<int64_t>(nc, 512);
+  nc = std::min<int64_t>(nc, (n_ranks + 63) / 64);
+  nc = std::max<int64_t>(nc, (n_ranks + kColMaxWidth - 1) / kColMaxWidth);
+  nc = std::max<int64_t>(1, std::min<int64_t>(nc, kColMaxCols));
+  int64_t width = (n_ranks + nc - 1) / nc;
+  nc = (n_ranks + width - 1) / width;
+  return ChainColumnPlan{(int)nc, (int)width};
+}
+
+size_t chain_columns_lds_bytes(int width) { return (size_t)(width + 2 + 64) * 16; }
+
+size_t chain_columns_temp_bytes(int64_t n) {
+  size_t b1 = 0, b2 = 0;
+  const int m = (int)std::max<int64_t>(1, n);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b1, (const uint16_t*)nullptr, (uint16_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, m, 0, 16);
+  hipcub::TransformInputIterator<int32_t, U8ToI32, const uint8_t*> it((const uint8_t*)nullptr, U8ToI32{});
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, b2, it, (int32_t*)nullptr, m);
+  return std::max(b1, b2);
+}
+
+int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream_t s) {
+  if (c.n <= 0) return 0;
+  if (c.n > 0x7fffffffLL || cc.n_cols < 1 || cc.n_cols > kColMaxCols || cc.width < 1 || cc.width > kColMaxWidth ||
+      (int64_t)cc.n_cols * cc.width < c.n_ranks) return -1;
+  const int n = (int)c.n;
+  const unsigned blocks = (unsigned)((c.n + 256) / 256);               // covers j = n as well
+  // dense row ordinals: inclusive scan of the row-head flags
+  {
+    size_t bytes = cc.temp_bytes;
+    hipcub::TransformInputIterator<int32_t, U8ToI32, const uint8_t*> it(c.flags, U8ToI32{});
+    if (hipcub::DeviceScan::InclusiveSum(cc.temp, bytes, it, cc.rowid1, n, s) != hipSuccess) return -1;
+  }
+  // stable partition of the match ids by column
+  hipLaunchKernelGGL(k_col_keys, dim3(blocks), dim3(256), 0, s, c.rank, c.n, cc.width, cc.key_in, cc.val_in);
+  {
+    size_t bytes = cc.temp_bytes;
+    if (hipcub::DeviceRadixSort::SortPairs(cc.temp, bytes, (const uint16_t*)cc.key_in, cc.key_out, (const uint32_t*)cc.val_in, cc.val_out, n, 0,
+                                           col_bits(cc.n_cols), s) != hipSuccess) return -1;
+  }
+  hipLaunchKernelGGL(k_col_gather, dim3(blocks), dim3(256), 0, s, cc.key_out, cc.val_out, c.n, cc.width, cc.n_cols, c.rank, c.q, cc.rowid1,
+                     cc.c_row, cc.c_lr, cc.c_q, cc.c_gid, cc.col_start);
+  if (hipMemsetAsync(cc.ctl, 0, sizeof(uint32_t) * (size_t)(kChainCtlHead + cc.n_cols), s) != hipSuccess) return -1;
+  ColArgs a{};
+  a.c_row = cc.c_row; a.c_lr = cc.c_lr; a.c_q = cc.c_q; a.c_gid = cc.c_gid; a.col_start = cc.col_start;
+  a.d_nrows = cc.rowid1 + (c.n - 1);
+  a.n_cols = cc.n_cols; a.width = cc.width; a.msg = cc.msg; a.msg_stride = cc.msg_stride; a.ctl = cc.ctl;
+  a.pred = c.pred; a.meta = c.meta;
+  a.spin_limit = 100000000ull * 20ull;                                 // 20 s
+  const size_t lds = chain_columns_lds_bytes(cc.width);
+  const int lv = bit_length(cc.width);
+  auto go = [&](auto kernel) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)cc.n_cols), dim3(64), lds, s, a);
+  };
+  if (lv <= 7) go(k_chain_columns<7>);
+  else if (lv <= 9) go(k_chain_columns<9>);
+  else if (lv <= 10) go(k_chain_columns<10>);
+  else if (lv <= 11) go(k_chain_columns<11>);
+  else if (lv <= 12) go(k_chain_columns<12>);
+  else go(k_chain_columns<13>);
+  hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(256), 0, s, c.pred, c.n, c.path_ids, c.meta);
+  hipLaunchKernelGGL(k_chain_gather, dim3(256), dim3(256), 0, s, c.keys, c.path_ids, c.meta, c.out_i, c.out_v);
+  return 0;
+}
+
 int chain_tree_shift(int64_t n_ranks) {
   // LDS holds the levels with span >= 2^S: (n_ranks >> S) + 1 nodes of 16 B within 128 KiB
   int S = 6;
@@ -505,10 +825,10 @@ size_t chain_rows_temp_bytes(int64_t n) {
 }
 
 // per-match ranks, row-head flags, validation (reads the rank map: runs where that is built)
-int launch_chain_prep(const ChainLaunch& c, hipStream_t s) {
+int launch_chain_prep(const ChainLaunch& c, hipStream_t s, bool columns) {
   if (c.n > 0x7fffffffLL || c.n_ranks >= (1LL << 24)) return -1;
   const int S = chain_tree_shift(c.n_ranks);
-  if (((c.n_ranks >> S) + 2 + kScrap) * 16 > 150 * 1024) return -1;
+  if (!columns && ((c.n_ranks >> S) + 2 + kScrap) * 16 > 150 * 1024) return -1;    // the one-workgroup kernels keep the upper tree levels in LDS
   if (c.n <= 0) return 0;
   const unsigned blocks = (unsigned)((c.n + 255) / 256);
   hipLaunchKernelGGL(k_chain_prep, dim3(blocks), dim3(256), 0, s, c.keys, c.q, c.n, c.rankmap, c.rankmap_len, c.rank, c.flags, c.err);

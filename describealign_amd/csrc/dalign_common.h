@@ -170,11 +170,34 @@ struct ChainLaunch {
   int xcd;                                                      // XCD the persistent DP workgroup should sit on (-1: any)
   int wide;                                                     // 1: four wavefronts per row super-step (rows of > ~100 matches)
 };
+// Column-pipelined form of the same DP (k_chain_columns): the video ranks are cut into `n_cols` columns of
+// `width` ranks, one single-wavefront workgroup per column with its Fenwick tree in LDS; the columns form a
+// pipeline over the audio rows, handing one (sum, id) record per row to the right through global memory.
+struct ChainColumns {
+  int n_cols, width;                       // ranks [c * width + 1, (c + 1) * width] belong to column c
+  int32_t* rowid1;                         // [n] 1-based dense row ordinal of every match (inclusive scan of the row heads)
+  uint16_t* key_in; uint16_t* key_out;     // [n] column of every match, before / after the stable partition
+  uint32_t* val_in; uint32_t* val_out;     // [n] match ids, before / after
+  uint32_t* c_row; uint16_t* c_lr; double* c_q; uint32_t* c_gid;   // [n + 64] matches in column-major order: row ordinal, local rank, quality, id
+  int32_t* col_start;                      // [n_cols + 1]
+  uint4* msg; int64_t msg_stride;          // [n_cols][msg_stride] records handed to the right, one per row (stride = rows rounded up to 64)
+  uint32_t* ctl;                           // [0] column tickets, [1] abort flag, [16 + c] batches published by column c; zeroed per launch
+  void* temp; size_t temp_bytes;           // hipCUB scratch (chain_columns_temp_bytes)
+};
+constexpr int kChainCtlHead = 16;
+struct ChainColumnPlan { int n_cols, width; };
+// rows_hint: (an estimate of) the number of distinct audio rows, 0 if unknown
+ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint);
+size_t chain_columns_temp_bytes(int64_t n);
+size_t chain_columns_lds_bytes(int width);
+// partition + forward DP + back-track + gather, all on stream s (prep has run); -1 = out of range
+int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream_t s);
+
 int chain_tree_shift(int64_t n_ranks);
 size_t chain_rows_temp_bytes(int64_t n);
 // prep = per-match ranks / row-head flags / validation; dp = row starts, forward DP, back-track, gather.
 // Both return -1 when the input is out of the kernels' range.
-int launch_chain_prep(const ChainLaunch& c, hipStream_t s);
+int launch_chain_prep(const ChainLaunch& c, hipStream_t s, bool columns);
 int launch_chain_dp(const ChainLaunch& c, hipStream_t s);
 void launch_rankmap(const int32_t* vlist, int64_t n_v, int32_t* rankmap, hipStream_t s);
 

@@ -9,14 +9,16 @@ import os
 
 
 class Group:
-  def __init__(self, backend=None):
+  def __init__(self, backend=None, init_single=False):
+    """init_single: create the process group even for one rank (RANK / WORLD_SIZE / MASTER_* as usual), so
+    that the collective code paths -- RCCL included -- run on a one-GPU box."""
     self.rank = int(os.environ.get("RANK", "0"))
     self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     self.world = int(os.environ.get("WORLD_SIZE", "1"))
     self.backend = backend
     self.dist = None
     self.device = None
-    if self.world > 1:
+    if self.world > 1 or init_single:
       import torch
       import torch.distributed as dist
       backend = backend or "nccl"
@@ -33,6 +35,16 @@ class Group:
   def barrier(self):
     if self.dist is not None:
       self.dist.barrier()
+
+  def all_ok(self, ok: bool) -> bool:
+    """True when `ok` holds on every rank (one MIN all-reduce): lets one failing rank abort a collective
+    step everywhere instead of leaving the others blocked in it."""
+    if self.dist is None:
+      return bool(ok)
+    import torch
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=self.device)
+    self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
 
   def max_over_ranks(self, value: float) -> float:
     if self.dist is None:
@@ -71,9 +83,13 @@ class Group:
     counts = [int(c.item()) for c in counts]
     cap = max(1, max(counts))
     on_gpu = self.backend == "nccl"
-    keys = torch.zeros(cap, dtype=torch.int64, device=dev)
-    qual = torch.zeros(cap, dtype=torch.float64, device=dev)
+    keys = torch.empty(cap, dtype=torch.int64, device=dev)
+    qual = torch.empty(cap, dtype=torch.float64, device=dev)
+    keys[n_local:] = 0; qual[n_local:] = 0                 # only the padding; the list itself is written below
     if on_gpu:
+      # the context copies on ITS stream (non-blocking, no implicit order with torch's): the tensors'
+      # allocation and the tail fill above must have completed before it writes into them
+      torch.cuda.current_stream(dev).synchronize()
       if n_local:
         ctx.match_export_device(keys.data_ptr(), qual.data_ptr(), n_local)
     else:

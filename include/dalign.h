@@ -140,8 +140,9 @@ int da_match_dump_tile(da_ctx* ctx, int64_t video_tile, int64_t audio_tile, floa
  * describealign.py:654-656, :674-698: heaviest chain non-decreasing in both coordinates over
  * matches sorted by (i, v).  *n_path in: capacity, out: length.  min_len = the reference's
  * failure bound max(min(Lv,La)/500, 1050) (:698); shorter -> DA_ERR_MISMATCH.
- * With a context the DP runs on the device (one persistent wavefront walking the audio rows:
- * Fenwick prefix maxima in LDS / L2, exact in-order double sums; qualities must be > 0 as the
+ * With a context the DP runs on the device (the video rows cut into rank columns, one wavefront per
+ * column with its Fenwick tree in LDS, the columns pipelined over the audio rows; every sum is the
+ * predecessor's sum plus q, one double addition, as in the reference; qualities must be > 0 as the
  * reference's are, :672).  ctx may be NULL: a host-only utility with the same result for CPU
  * tools and tests (then only the return code reports errors). */
 int da_chain(da_ctx* ctx, const int32_t* i, const int32_t* v, const double* q, int64_t n,
@@ -154,7 +155,11 @@ int da_chain(da_ctx* ctx, const int32_t* i, const int32_t* v, const double* q, i
  * the similarity GEMMs of later pairs -- and returns a ticket; the context is immediately free for
  * the next da_match_begin.  da_chain_finish(ticket) waits for that DP and returns its path
  * (*n_path in: capacity, out: length; DA_ERR_CAPACITY keeps the result collectable).  At most 16
- * tickets may be outstanding per context.  da_chain_resident == begin + finish. */
+ * tickets may be outstanding per context.  da_chain_resident == begin + finish.
+ * ORDER: da_chain_begin ranks the matches with the video row list of the match that produced them, and
+ * the next da_match_begin overwrites that list -- so call da_chain_begin (or da_match_import_device +
+ * da_chain_begin) BEFORE the next da_match_begin on the context; afterwards it fails with DA_ERR_STATE.
+ * Limits: fewer than 2^31 matches and 2^24 distinct video rows. */
 int da_chain_begin(da_ctx* ctx, uint64_t* ticket);
 int da_chain_finish(da_ctx* ctx, uint64_t ticket, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path);
 int da_chain_resident(da_ctx* ctx, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path);
@@ -227,6 +232,9 @@ typedef struct da_stats_t {
   double splice_points;
   double stretch_prepare_ms; /* int16 -> float16 + loudness matching (da_stretch_resident) */
   double stretch_finish_ms;  /* peak normalisation + int16 interleave */
+  /* chain DP geometry of the last enqueued DP (ABI v4): rank columns and their width; 0 = one-workgroup kernel */
+  double chain_columns;
+  double chain_column_width;
 } da_stats_t;
 
 int da_stats(const da_ctx* ctx, da_stats_t* out);

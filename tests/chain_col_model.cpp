@@ -1,0 +1,120 @@
+// CPU model of the column-pipelined chain DP (describealign_amd/csrc/dalign_chain.hip, k_chain_columns).
+// Test infrastructure: tests/test_host_cpu.py compiles this file with g++ and checks the model against the
+// host utility (da_chain with a NULL context) on random, tie-heavy instances, so the DECOMPOSITION the
+// kernel uses -- rank columns, 64-row message batches, 64-point windows, two-phase tree update -- is
+// pinned on the CPU; the GPU tests then pin the kernel itself.
+//
+// Recurrence (describealign.py:654-656, :674-697): over matches sorted by (audio frame i, video frame v)
+//     f[k] = q[k] + max{ f[k'] : k' < k, v[k'] <= v[k] },  ties on f resolved to the larger k'.
+// Decomposition: video ranks are cut into columns of `w` ranks.  For a point k of column C in row i
+//     {k' < k, v' <= v} = {points of columns < C in rows <= i}  u  {points k' < k of column C with rank' <= rank}
+// so column C needs from the columns to its left ONE (sum, id) record per audio row -- B_i(C), the
+// lexicographic maximum over their points in rows <= i -- and hands B_i(C+1) = max(B_i(C), its own points
+// in rows <= i) to the right.  Columns therefore form a pipeline over the rows; inside a column, points are
+// taken 64 at a time (a "window"): prefix maxima from a Fenwick tree over the column's ranks as it stood
+// before the window, dominance among the window's own points by a 64-step sequential sweep, then the
+// window's points enter the tree.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct Rec { double f; uint32_t id1; };                      // id1 = id + 1, 0 = none
+inline bool beats(const Rec& a, const Rec& b) { return a.f > b.f || (a.f == b.f && a.id1 > b.id1); }
+inline Rec lexmax(const Rec& a, const Rec& b) { return beats(b, a) ? b : a; }
+
+}  // namespace
+
+extern "C" int chain_col_model(const int32_t* pi, const int32_t* pv, const double* pq, int64_t n, int w,
+                               int32_t* pred, int64_t* best) {
+  *best = -1;
+  if (n <= 0) return 0;
+  // dense 1-based video ranks, dense row ordinals
+  int32_t vmax = 0;
+  for (int64_t k = 0; k < n; ++k) vmax = std::max(vmax, pv[k]);
+  std::vector<int32_t> rk((size_t)vmax + 2, 0);
+  for (int64_t k = 0; k < n; ++k) rk[pv[k]] = 1;
+  int32_t n_ranks = 0;
+  for (size_t x = 0; x < rk.size(); ++x) if (rk[x]) rk[x] = ++n_ranks;
+  std::vector<int32_t> rowid((size_t)n);
+  int32_t n_rows = 0;
+  for (int64_t k = 0; k < n; ++k) { if (k == 0 || pi[k] != pi[k - 1]) ++n_rows; rowid[k] = n_rows - 1; }
+  const int NC = (n_ranks + w - 1) / w;
+  const int n_batches = (n_rows + 63) / 64;
+  // stable partition by column
+  std::vector<std::vector<int32_t>> cols((size_t)NC);
+  for (int64_t k = 0; k < n; ++k) cols[(rk[pv[k]] - 1) / w].push_back((int32_t)k);
+  std::vector<Rec> Bin((size_t)n_batches * 64, Rec{0.0, 0u}), Bout((size_t)n_batches * 64);
+  int LV = 1; while ((1 << LV) <= w) ++LV;                     // longest Fenwick path
+  for (int C = 0; C < NC; ++C) {
+    const std::vector<int32_t>& P = cols[C];
+    std::vector<Rec> tree((size_t)w + 2, Rec{0.0, 0u});        // [0] empty record, [w + 1] overflow dummy
+    Rec M{0.0, 0u};
+    size_t cursor = 0;
+    for (int b = 0; b < n_batches; ++b) {
+      Rec rowmax[64];
+      for (int r = 0; r < 64; ++r) rowmax[r] = Rec{0.0, 0u};
+      const Rec Mstart = M;
+      while (true) {
+        int cnt = 0;
+        while (cnt < 64 && cursor + cnt < P.size() && rowid[P[cursor + cnt]] < 64 * (b + 1)) ++cnt;
+        if (cnt == 0) break;
+        int32_t row[64], lr[64], gid[64]; double q[64]; Rec B[64];
+        for (int p = 0; p < cnt; ++p) {
+          gid[p] = P[cursor + p]; row[p] = rowid[gid[p]] - 64 * b; lr[p] = (rk[pv[gid[p]]] - 1) % w + 1; q[p] = pq[gid[p]];
+          B[p] = Bin[(size_t)64 * b + row[p]];
+        }
+        // tree query (state before the window)
+        Rec t[64]; double gcol[64]; int winj[64];
+        for (int p = 0; p < cnt; ++p) {
+          Rec best_t{0.0, 0u};
+          int x = lr[p];
+          for (int l = 0; l < LV; ++l) { best_t = lexmax(best_t, tree[x]); x &= x - 1; }
+          t[p] = best_t; gcol[p] = best_t.f; winj[p] = -1;
+        }
+        // dominance among the window's own points: sequential sweep
+        for (int j = 0; j < cnt; ++j) {
+          const double fj = q[j] + std::max(gcol[j], B[j].f);
+          for (int p = j + 1; p < cnt; ++p)
+            if (lr[p] >= lr[j] && fj >= gcol[p]) { gcol[p] = fj; winj[p] = j; }
+        }
+        Rec me[64];
+        for (int p = 0; p < cnt; ++p) {
+          const double F = q[p] + std::max(gcol[p], B[p].f);
+          const Rec colc{gcol[p], winj[p] >= 0 ? (uint32_t)gid[winj[p]] + 1u : t[p].id1};
+          const Rec c = lexmax(colc, B[p]);
+          pred[gid[p]] = (int32_t)c.id1 - 1;
+          me[p] = Rec{F, (uint32_t)gid[p] + 1u};
+        }
+        // two-phase tree update: max on the sums, then the ids where the sum is ours
+        for (int p = 0; p < cnt; ++p) {
+          int x = lr[p];
+          for (int l = 0; l < LV; ++l) { const int idx = std::min(x, w + 1); if (me[p].f > tree[idx].f) tree[idx].f = me[p].f; x += x & -x; }
+        }
+        for (int p = 0; p < cnt; ++p) {
+          int x = lr[p];
+          for (int l = 0; l < LV; ++l) { const int idx = std::min(x, w + 1); if (tree[idx].f == me[p].f && me[p].id1 > tree[idx].id1) tree[idx].id1 = me[p].id1; x += x & -x; }
+        }
+        // running maximum per row
+        Rec run = M;
+        for (int p = 0; p < cnt; ++p) {
+          run = lexmax(run, me[p]);
+          if (p == cnt - 1 || row[p + 1] != row[p]) rowmax[row[p]] = lexmax(rowmax[row[p]], run);
+        }
+        M = run;
+        cursor += (size_t)cnt;
+        if (cnt < 64) break;
+      }
+      Rec fill = Mstart;
+      for (int r = 0; r < 64; ++r) {
+        fill = lexmax(fill, rowmax[r]);
+        Bout[(size_t)64 * b + r] = lexmax(Bin[(size_t)64 * b + r], fill);
+      }
+    }
+    Bin.swap(Bout);
+  }
+  *best = (int64_t)Bin[(size_t)n_batches * 64 - 1].id1 - 1;
+  return 0;
+}

@@ -196,14 +196,19 @@ def _random_chain_instance(rng, n, rows, cols, step=4, quals=(50.0, 50.0, 12.5, 
   return i, v, rng.choice(quals, len(i))
 
 
-@pytest.mark.parametrize("waves", ["1", "4"])
+@pytest.mark.parametrize("kernel", ["columns", "columns:1", "columns:37", "columns:700", "rows:1", "rows:4"])
 @pytest.mark.parametrize("shape", ["wide_rows", "many_ranks", "sparse"])
-def test_chain_kernel_equals_host_utility(ctx, native, shape, waves, monkeypatch):
+def test_chain_kernel_equals_host_utility(ctx, native, shape, kernel, monkeypatch):
   """The device DP (da_chain with a context) against the host utility (NULL context) on instances
-  that exercise what the goldens do not: rows with more than 64 / 256 points (several steps per
-  row, sums carried between wavefronts and steps), more than 2^19 distinct video ranks (another LDS / L2 split of the tree) and
-  rows of one or two points.  Qualities are drawn from a few values, so equal sums abound."""
-  monkeypatch.setenv("DALIGN_CHAIN_WAVES", waves)        # both forward kernels: one wavefront / four per row super-step
+  that exercise what the goldens do not: rows with more than 64 / 256 points (several windows per
+  row and column), more than 2^19 distinct video ranks and rows of one or two points.  Qualities are
+  drawn from a few values, so equal sums abound.  The column pipeline runs with its own choice of
+  columns and with 1, 37 and 700 forced (one workgroup; windows that straddle rows; far more columns
+  than matches per row); the round-2 one-workgroup kernels (one / four wavefronts) stay as a cross-check."""
+  kind, _, arg = kernel.partition(":")
+  monkeypatch.setenv("DALIGN_CHAIN_KERNEL", kind)
+  if kind == "rows": monkeypatch.setenv("DALIGN_CHAIN_WAVES", arg)
+  elif arg: monkeypatch.setenv("DALIGN_CHAIN_COLS", arg)
   rng = np.random.default_rng({"wide_rows": 1, "many_ranks": 2, "sparse": 3}[shape])
   if shape == "wide_rows":
     i, v, q = _random_chain_instance(rng, 120000, 300, 5000)             # ~400 points per row: more than one 256-match super-step
