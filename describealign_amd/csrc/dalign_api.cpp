@@ -56,6 +56,7 @@ struct ChainSlot {
   DevBuf rank, flags, rows, pred, tree, ids, out_iv, small, temp;
   // column-pipelined DP: row ordinals, partition keys / ids, column-major matches, per-row records, control words
   DevBuf rowid, ckey, cval, c_row, c_lr, c_q, c_gid, col_start, msg, ctl;
+  unsigned launches = 0;          // column DPs that have written `msg` since it was last zeroed (tag salt)
   int64_t rows_hint = 0;          // audio rows of the match that filled this slot (upper bound on the rows with matches), 0 = unknown
   int mode = 0;                   // how the DP in flight was launched: 0 = columns, 1 / 4 = one workgroup of 1 / 4 wavefronts
   hipStream_t stream = nullptr;
@@ -853,21 +854,32 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     const int64_t rows_bound = std::min<int64_t>(n, sl.rows_hint > 0 ? sl.rows_hint : n);
     const da::ChainColumnPlan plan = da::chain_columns_plan(n, sl.n_ranks, rows_bound);
     K.n_cols = plan.n_cols; K.width = plan.width;
-    K.msg_stride = (rows_bound + 63) / 64 * 64;
+    const int64_t br = da::chain_columns_batch_rows();
+    K.msg_stride = (rows_bound + br - 1) / br * br;
     const size_t ctb = da::chain_columns_temp_bytes(n);
     HIP_TRY(c, sl.rowid.ensure(sizeof(int32_t) * nn));
     HIP_TRY(c, sl.ckey.ensure(sizeof(uint16_t) * 2 * nn)); HIP_TRY(c, sl.cval.ensure(sizeof(uint32_t) * 2 * nn));
     HIP_TRY(c, sl.c_row.ensure(sizeof(uint32_t) * nn)); HIP_TRY(c, sl.c_lr.ensure(sizeof(uint16_t) * nn));
     HIP_TRY(c, sl.c_q.ensure(sizeof(double) * nn)); HIP_TRY(c, sl.c_gid.ensure(sizeof(uint32_t) * nn));
     HIP_TRY(c, sl.col_start.ensure(sizeof(int32_t) * ((size_t)K.n_cols + 1)));
-    HIP_TRY(c, sl.msg.ensure(16 * (size_t)K.msg_stride * (size_t)K.n_cols));
-    HIP_TRY(c, sl.ctl.ensure(sizeof(uint32_t) * ((size_t)da::kChainCtlHead + (size_t)K.n_cols)));
+    {
+      // granule tags must never match what an earlier launch left behind: fresh memory and every 4095th
+      // launch are zeroed, in between the salt distinguishes the launches
+      const size_t cap_before = sl.msg.cap;
+      HIP_TRY(c, sl.msg.ensure(24 * (size_t)K.msg_stride * (size_t)K.n_cols));
+      if (sl.msg.cap != cap_before || sl.launches >= 4095) {
+        HIP_TRY(c, hipMemsetAsync(sl.msg.p, 0, sl.msg.cap, c->stream));
+        sl.launches = 0;
+      }
+      K.salt = ++sl.launches;
+    }
+    HIP_TRY(c, sl.ctl.ensure(sizeof(uint32_t) * ((size_t)da::kChainCtlHead + (size_t)K.n_cols + 2) + 64 * (size_t)K.n_cols));   // + diagnostic stamps
     HIP_TRY(c, sl.temp.ensure(std::max(tb, ctb) + 256));
     K.rowid1 = sl.rowid.as<int32_t>();
     K.key_in = sl.ckey.as<uint16_t>(); K.key_out = sl.ckey.as<uint16_t>() + nn;
     K.val_in = sl.cval.as<uint32_t>(); K.val_out = sl.cval.as<uint32_t>() + nn;
     K.c_row = sl.c_row.as<uint32_t>(); K.c_lr = sl.c_lr.as<uint16_t>(); K.c_q = sl.c_q.as<double>(); K.c_gid = sl.c_gid.as<uint32_t>();
-    K.col_start = sl.col_start.as<int32_t>(); K.msg = reinterpret_cast<uint4*>(sl.msg.p); K.ctl = sl.ctl.as<uint32_t>();
+    K.col_start = sl.col_start.as<int32_t>(); K.msg = sl.msg.as<unsigned long long>(); K.ctl = sl.ctl.as<uint32_t>();
     K.temp = sl.temp.p; K.temp_bytes = ctb;
     L.temp = sl.temp.p;
     c->st.chain_columns = (double)K.n_cols; c->st.chain_column_width = (double)K.width;
@@ -897,7 +909,19 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
 int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
   HIP_TRY(c, hipStreamSynchronize(sl.stream));
   float ms = 0.f; (void)hipEventElapsedTime(&ms, sl.e0, sl.e1); c->st.chain_ms = ms;
-  if (std::getenv("DALIGN_DEBUG_STAMPS")) {               // diagnostic builds (-DDA_CHAIN_STAMPS) only
+  if (std::getenv("DALIGN_DEBUG_STAMPS") && sl.mode == 0 && sl.n > 0) {   // diagnostic builds (-DDA_CHAIN_STAMPS) only
+    const int nc = (int)c->st.chain_columns;
+    std::vector<unsigned long long> st((size_t)nc * 8);
+    const uint32_t* base = sl.ctl.as<uint32_t>() + da::kChainCtlHead + ((nc + 1) & ~1);
+    if (hipMemcpy(st.data(), base, st.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = 0; k < nc; ++k) for (int j = 0; j < 8; ++j) sum[j] += (double)st[(size_t)k * 8 + j];
+      const char* names[7] = {"publish-drain", "input-wait", "window-pre+query", "sweep", "finals+update", "window-scan", "batch-end"};
+      std::fprintf(stderr, "chain column stamps (mean per column, ms; %d columns, %.0f windows per column, kernel+rest %.2f ms):", nc, sum[7] / nc, ms);
+      for (int j = 0; j < 7; ++j) std::fprintf(stderr, " %s %.2f", names[j], sum[j] / nc * 1e-5);
+      std::fprintf(stderr, "\n");
+    }
+  } else if (std::getenv("DALIGN_DEBUG_STAMPS")) {        // one-workgroup kernels
     long long st[6];
     if (hipMemcpy(st, sl.small.as<int64_t>() + 3, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
       double tot = 0; for (long long v : st) tot += (double)v;

@@ -442,42 +442,65 @@ __global__ __launch_bounds__(64 * kW4) void k_chain_forward_w4(ChainArgs a) {
   if (tid == 0) { a.meta[0] = (int64_t)s_best_i - 1; a.meta[1] = 0; }
 }
 
-// Back-track from the heaviest point through pred[] (:690-697).  The chain's ids decrease, and a
-// predecessor is rarely more than a few rows back, so pred[] is pulled through LDS in windows of
-// kBackWindow ids and chased there by one lane; ids are staged and written out coalesced.
-constexpr int kBackWindow = 12288;
+// Back-track from the heaviest point through pred[] (:690-697).  The chain's ids decrease and a
+// predecessor is rarely more than a few rows back, so pred[] is pulled through LDS in fixed blocks of
+// kBackBlock ids (16-byte loads, 1024 threads) and chased there by one lane; the block below is
+// requested into registers before the chase starts, so its trip from HBM hides behind the chase;
+// ids are staged and written out coalesced.
+constexpr int kBackBlock = 16384;
 constexpr int kBackStage = 2048;
+constexpr int kBackThreads = 1024;
 
-__global__ __launch_bounds__(256) void k_chain_backtrack(const int32_t* __restrict__ pred, int64_t n, int32_t* __restrict__ path_ids,
-                                                         int64_t* __restrict__ meta) {
-  __shared__ int32_t s_pred[kBackWindow];
+__global__ __launch_bounds__(kBackThreads) void k_chain_backtrack(const int32_t* __restrict__ pred, int64_t n, int32_t* __restrict__ path_ids,
+                                                                  int64_t* __restrict__ meta) {
+  __shared__ int32_t s_pred[2][kBackBlock];
   __shared__ int32_t s_out[kBackStage];
   __shared__ int32_t s_cur, s_nout;
+  constexpr int kPer = kBackBlock / kBackThreads;            // ids per thread and block (16): four 16-byte loads
+  const int tid = threadIdx.x;
   int64_t total = 0;
   int32_t cur = (int32_t)meta[0];
+  int sel = 0;
+  bool have = false;                                         // s_pred[sel] already holds the block of `cur`
+  int4 pre[kPer / 4];
+  auto request = [&](int32_t kb) {                           // block kb -> registers (ids past n read as -1)
+    const int64_t base = (int64_t)kb * kBackBlock + (int64_t)tid * 4;
+#pragma unroll
+    for (int u = 0; u < kPer / 4; ++u) {
+      const int64_t at = base + (int64_t)u * kBackThreads * 4;
+      if (at + 3 < n) pre[u] = *reinterpret_cast<const int4*>(pred + at);
+      else pre[u] = int4{at < n ? pred[at] : -1, at + 1 < n ? pred[at + 1] : -1, at + 2 < n ? pred[at + 2] : -1, -1};
+    }
+  };
+  auto deposit = [&](int into) {
+#pragma unroll
+    for (int u = 0; u < kPer / 4; ++u) *reinterpret_cast<int4*>(&s_pred[into][tid * 4 + u * kBackThreads * 4]) = pre[u];
+  };
   while (cur >= 0) {
-    const int32_t whi = cur + 1;
-    const int32_t wlo = whi > kBackWindow ? whi - kBackWindow : 0;
-    for (int32_t t = wlo + (int32_t)threadIdx.x; t < whi; t += 256) s_pred[t - wlo] = pred[t];
+    const int32_t kb = cur / kBackBlock;
+    const int32_t lo = kb * kBackBlock;
+    if (!have) { request(kb); deposit(sel); }
     __syncthreads();
-    // chase inside the window, flushing the stage when it fills
-    while (true) {
-      if (threadIdx.x == 0) {
+    if (kb > 0) request(kb - 1);                             // in flight during the chase
+    while (true) {                                           // chase inside the block, flushing the stage when it fills
+      if (tid == 0) {
         int32_t m = 0, p = cur;
-        while (p >= wlo && m < kBackStage) { s_out[m++] = p; p = s_pred[p - wlo]; }
+        while (p >= lo && m < kBackStage) { s_out[m++] = p; p = s_pred[sel][p - lo]; }
         s_cur = p; s_nout = m;
       }
       __syncthreads();
       const int32_t m = s_nout;
       cur = s_cur;
-      for (int32_t t = threadIdx.x; t < m; t += 256) path_ids[total + t] = s_out[t];
+      for (int32_t t = tid; t < m; t += kBackThreads) path_ids[total + t] = s_out[t];
       total += m;
       __syncthreads();
-      if (cur < wlo || m < kBackStage) break;
+      if (cur < lo || m < kBackStage) break;
     }
-    // cur < wlo here (or the chain ended); pred ids are < their own id, so the next window starts at cur
+    // cur < lo here (or the chain ended).  Usually it lies in the block just below: the one in the registers.
+    have = false;
+    if (cur >= 0 && kb > 0 && cur / kBackBlock == kb - 1) { sel ^= 1; deposit(sel); have = true; }
   }
-  if (threadIdx.x == 0) meta[1] = total;
+  if (tid == 0) meta[1] = total;
 }
 
 // ascending (audio frame, video frame) arrays from the descending id list
@@ -498,9 +521,8 @@ __global__ __launch_bounds__(256) void k_chain_gather(const unsigned long long* 
 // so a column needs from the columns to its left ONE (sum, id) record per audio row -- B_i(C), the
 // lexicographic maximum over their matches in rows <= i -- and hands B_i(C + 1) = max(B_i(C), its own matches
 // in rows <= i) to the right.  One single-wavefront workgroup per column; its Fenwick tree covers only the
-// column's `width` ranks and lives entirely in LDS; the columns form a pipeline over the rows (64-row
-// batches of records through global memory: write-through stores, a counter per column, polled with
-// L1-bypassing loads).  Inside a column the matches are taken 64 at a time, one per lane ("window"):
+// column's `width` ranks and lives entirely in LDS; the columns form a pipeline over the rows, 256 rows
+// ("batch") at a time.  Inside a column the matches are taken 64 at a time, one per lane ("window"):
 //   * prefix maxima from the tree as it stood before the window (all lanes at once, LDS only);
 //   * dominance among the window's own matches by a sequential sweep -- match j's final sum is broadcast
 //     (v_readlane) and taken by the later lanes with rank >= rank_j whose best is not larger; later ids win
@@ -509,75 +531,92 @@ __global__ __launch_bounds__(256) void k_chain_gather(const unsigned long long* 
 //     are non-negative doubles, ordered like their bit patterns), then max on the ids where the sum is the
 //     lane's own (newer matches have larger ids, so a stale id of a smaller sum always loses).
 // Every sum is still "predecessor's sum + q", one IEEE addition, so sums, comparisons and ties are those
-// of the reference whatever the column width.  Column numbers are taken from a ticket counter, so a
-// workgroup only ever waits for workgroups that are already running, and every column writes its records
-// to a buffer of its own (no back-pressure): the pipeline cannot deadlock however many columns are resident.
-// tests/chain_col_model.cpp is the CPU model of exactly this decomposition.
+// of the reference whatever the column width.
+// Hand-over (MI355X: per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores): a
+// row's record travels as three 8-byte granules {tag, value} -- sum low word, sum high word, id -- each
+// written by ONE write-through (sc1) store and read by L1-bypassing (sc1) loads, as relaxed agent-scope
+// atomics; the tag (launch salt | batch + 1) IS the ready flag, so there is no counter to poll, no release
+// fence and no store drain: the right neighbour re-reads a batch until every tag matches.  The next
+// batch's granules are requested while the current batch is processed.  Column numbers are taken from a
+// ticket counter, so a workgroup only ever waits for workgroups that are already running, and every column
+// writes to a buffer of its own (no back-pressure): the pipeline cannot deadlock however many columns are
+// resident.  tests/chain_col_model.cpp is the CPU model of exactly this decomposition.
+
+constexpr int kRowsPerLane = 4;                      // a batch = 64 lanes x 4 rows
+constexpr int kBatchRows = 64 * kRowsPerLane;
+constexpr int kGranules = 3 * kRowsPerLane;          // per lane and batch
 
 struct ColArgs {
   const uint32_t* c_row; const uint16_t* c_lr; const double* c_q; const uint32_t* c_gid;
   const int32_t* col_start; const int32_t* d_nrows;   // *d_nrows = number of audio rows (device)
   int n_cols, width;
-  uint4* msg; int64_t msg_stride;
+  unsigned long long* msg; int64_t msg_stride;        // [n_cols][msg_stride rows][3] granules
   uint32_t* ctl;
   int32_t* pred; int64_t* meta;
   unsigned long long spin_limit;           // wall-clock ticks (100 MHz) a column may wait for its neighbour
+  uint32_t salt;                           // tag = salt << 20 | batch + 1: never equal to what an earlier launch left in the buffer
+  unsigned long long* stamps;              // diagnostic build (-DDA_CHAIN_STAMPS): 8 tick counters per column
 };
+#ifdef DA_CHAIN_STAMPS
+#define DA_CSTAMP(k) { const unsigned long long t_ = wall_clock64(); cst[k] += t_ - cst_t; cst_t = t_; }
+#else
+#define DA_CSTAMP(k)
+#endif
 
 namespace {
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 load_sc1_b128(const uint4* p) {        // L1-bypassing load, waited for
-  u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return uint4{v.x, v.y, v.z, v.w};
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_fetch(double f, uint32_t id, double& of, uint32_t& oi) {   // lanes outside the pattern read (0, 0)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(f), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(f), CTRL, ROW_MASK, 0xf, true);
+  oi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)id, CTRL, ROW_MASK, 0xf, true);
+  of = __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ void store_sc1_b128(uint4* p, const uint4& n) {   // write-through store
-  const u32x4 v = {n.x, n.y, n.z, n.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+// inclusive prefix maximum over the 64 lanes, lexicographic on (sum, id); (0, 0) is the identity
+__device__ __forceinline__ void scan_lexmax(double& f, uint32_t& id) {
+  double of; uint32_t oi;
+#define DA_SCAN_STEP(CTRL, MASK) dpp_fetch<CTRL, MASK>(f, id, of, oi); if (beats(of, oi, f, id)) { f = of; id = oi; }
+  DA_SCAN_STEP(0x111, 0xf)      // row_shr:1
+  DA_SCAN_STEP(0x112, 0xf)      // row_shr:2
+  DA_SCAN_STEP(0x114, 0xf)      // row_shr:4
+  DA_SCAN_STEP(0x118, 0xf)      // row_shr:8   -> prefix within each row of 16 lanes
+  DA_SCAN_STEP(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+  DA_SCAN_STEP(0x143, 0xc)      // row_bcast:31 into rows 2 and 3
+#undef DA_SCAN_STEP
 }
-__device__ __forceinline__ double shfl_f64(double x, int src) {
-  return __hiloint2double(__shfl(__double2hiint(x), src), __shfl(__double2loint(x), src));
-}
-__device__ __forceinline__ double shfl_up_f64(double x, int d) {
-  return __hiloint2double(__shfl_up(__double2hiint(x), d), __shfl_up(__double2loint(x), d));
-}
-// inclusive prefix maximum over the lanes, lexicographic on (sum, id)
-__device__ __forceinline__ void scan_lexmax(double& f, uint32_t& id, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const double of = shfl_up_f64(f, d);
-    const uint32_t oi = (uint32_t)__shfl_up((int)id, d);
-    if (lane >= d && beats(of, oi, f, id)) { f = of; id = oi; }
-  }
+__device__ __forceinline__ void lexmax_into(double& f, uint32_t& id, double of, uint32_t oi) {
+  if (beats(of, oi, f, id)) { f = of; id = oi; }
 }
 
 }  // namespace
 
 template <int LV>      // LV = longest Fenwick path: width < 2^LV
 __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
-  extern __shared__ uint4 s_tree[];                  // [0] empty record, [1 .. width] nodes, [width + 1] overflow dummy, then 64 per-row records
+  extern __shared__ uint4 s_tree[];                  // [0] empty record, [1 .. width] nodes, [width + 1] overflow dummy; then the batch's incoming records and its per-row maxima
   const int lane = threadIdx.x;
   const int w = a.width;
-  uint4* s_rowmax = s_tree + (w + 2);
-  for (int h = lane; h < w + 2 + 64; h += 64) s_tree[h] = uint4{0u, 0u, 0u, 0u};
+  uint4* s_in = s_tree + (w + 2);                    // [256] records from the left, by row of the batch
+  uint4* s_rowmax = s_in + kBatchRows;               // [256] the column's running maximum after each row
+  for (int h = lane; h < w + 2 + 2 * kBatchRows; h += 64) s_tree[h] = uint4{0u, 0u, 0u, 0u};
   uint32_t col = 0;
   if (lane == 0) col = __hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int C = (int)__builtin_amdgcn_readfirstlane(col);
   __syncthreads();
   if (C >= a.n_cols) return;
   const int32_t n_rows = *a.d_nrows;
-  const int32_t n_batches = (n_rows + 63) >> 6;
+  const int32_t n_batches = (n_rows + kBatchRows - 1) / kBatchRows;
   int64_t cursor = a.col_start[C];
   const int64_t end = a.col_start[C + 1];
-  const uint4* __restrict__ in = C > 0 ? a.msg + (int64_t)(C - 1) * a.msg_stride : nullptr;
-  uint4* __restrict__ out = a.msg + (int64_t)C * a.msg_stride;
-  uint32_t* done_in = a.ctl + kChainCtlHead + (C > 0 ? C - 1 : 0);
-  uint32_t* done_out = a.ctl + kChainCtlHead + C;
+  const unsigned long long* in8 = C > 0 ? a.msg + (int64_t)(C - 1) * a.msg_stride * 3 : nullptr;
+  unsigned long long* out8 = a.msg + (int64_t)C * a.msg_stride * 3;
+  const bool has_right = C + 1 < a.n_cols;
   double Mf = 0.0; uint32_t Mid = 0u;               // running maximum over this column's matches (uniform)
-  uint32_t seen = 0u;                               // batches the left neighbour is known to have published
-  double Of = 0.0; uint32_t Oid = 0u;               // this lane's outgoing record of the current batch
+  uint32_t last_id = 0u;                            // id of the record of the batch's last row (lane 63)
   const unsigned long long t_start = wall_clock64();
+#ifdef DA_CHAIN_STAMPS
+  unsigned long long cst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long cst_t = t_start;
+#endif
 
   // the window at `cursor`, prefetched: one match per lane
   uint32_t n_row = 0xFFFFFFFFu, n_gid = 0u; uint32_t n_lr = 0u; double n_q = 0.0;
@@ -588,32 +627,56 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
   };
   fetch(cursor);
 
+  // this lane's granules of a batch: rows 4 * lane .. 4 * lane + 3, three granules each, contiguous
+  unsigned long long gr[kGranules];
+  auto request = [&](int32_t b) {
+    const unsigned long long* p = in8 + ((int64_t)kBatchRows * b + kRowsPerLane * lane) * 3;
+#pragma unroll
+    for (int g = 0; g < kGranules; ++g) gr[g] = __hip_atomic_load(p + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto complete = [&](uint32_t tag) -> bool {
+    bool ok = true;
+#pragma unroll
+    for (int g = 0; g < kGranules; ++g) ok &= (uint32_t)(gr[g] >> 32) == tag;
+    return __all(ok);
+  };
+  if (C > 0 && n_batches > 0) request(0);
+
   for (int32_t b = 0; b < n_batches; ++b) {
-    // ---- the records of this batch's rows from the left neighbour (lane = row)
-    double Bf = 0.0; uint32_t Bid = 0u;
+    DA_CSTAMP(6)
+    const uint32_t tag = (a.salt << 20) | (uint32_t)(b + 1);
+    // ---- the records of this batch's rows from the left neighbour: wait until every granule carries the tag
     if (C > 0) {
-      if (seen <= (uint32_t)b) {
-        unsigned spins = 0;
-        while (true) {
-          seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(done_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          if (seen > (uint32_t)b) break;
-          __builtin_amdgcn_s_sleep(1);
-          if ((++spins & 255u) == 0u) {
-            const uint32_t ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (ab != 0u) return;
-            if (wall_clock64() - t_start > a.spin_limit) {
-              if (lane == 0) __hip_atomic_store(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              return;
-            }
+      unsigned spins = 0;
+      while (!complete(tag)) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0u) {
+          const uint32_t ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (ab != 0u) return;
+          if (wall_clock64() - t_start > a.spin_limit) {
+            if (lane == 0) __hip_atomic_store(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
           }
         }
+        request(b);
       }
-      const uint4 m = load_sc1_b128(in + (int64_t)64 * b + lane);
-      Bf = node_cum(m); Bid = m.z;
     }
-    s_rowmax[lane] = uint4{0u, 0u, 0u, 0u};
+    double Bf[kRowsPerLane]; uint32_t Bid[kRowsPerLane];
+#pragma unroll
+    for (int r = 0; r < kRowsPerLane; ++r) {
+      Bf[r] = 0.0; Bid[r] = 0u;
+      if (C > 0) {
+        Bf[r] = __hiloint2double((int)(uint32_t)gr[3 * r + 1], (int)(uint32_t)gr[3 * r]);
+        Bid[r] = (uint32_t)gr[3 * r + 2];
+      }
+      s_in[kRowsPerLane * lane + r] = make_node(Bf[r], Bid[r]);
+      s_rowmax[kRowsPerLane * lane + r] = uint4{0u, 0u, 0u, 0u};
+    }
+    if (C > 0 && b + 1 < n_batches) request(b + 1);       // the next batch, behind this one's work
+    DA_CSTAMP(1)
     const double Mstart_f = Mf; const uint32_t Mstart_id = Mid;
-    const uint32_t row_end = (uint32_t)(64 * (b + 1));
+    const uint32_t row_base = (uint32_t)(kBatchRows * b);
+    const uint32_t row_end = row_base + (uint32_t)kBatchRows;
 
     while (true) {
       // ---- this window: the matches at `cursor` that belong to the batch (a prefix of the lanes)
@@ -626,9 +689,10 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
       const uint32_t lr = inb ? lr0 : 0u;             // rank 0: the empty record, on every path
       const double qv = inb ? qv0 : 0.0;
       const uint32_t id1 = inb ? gid + 1u : 0u;
-      const int rl = inb ? (int)(row - (uint32_t)(64 * b)) : 0;
-      const double Bpf = shfl_f64(Bf, rl);
-      const uint32_t Bpid = (uint32_t)__shfl((int)Bid, rl);
+      const int rl = inb ? (int)(row - row_base) : 0;
+      const uint4 bp = s_in[rl];
+      const double Bpf = node_cum(bp);
+      const uint32_t Bpid = bp.z;
 
       // ---- prefix maximum over the column's earlier windows: Fenwick query, all lanes at once
       double tf = 0.0; uint32_t tid = 0u;
@@ -642,9 +706,16 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
 #pragma unroll
         for (int l = 0; l < LV; ++l) tid = (node_cum(nd[l]) == tf && nd[l].z > tid) ? nd[l].z : tid;
       }
+#ifdef DA_CHAIN_STAMPS
+      if (tf < 0.0) return;
+#endif
+      DA_CSTAMP(2)
       // ---- dominance inside the window: match j's final sum goes to the later lanes it precedes
       double gcol = tf; int winj = -1;
-      for (int j = 0; j < cnt; ++j) {
+      // (A hand-scheduled version of this loop -- exec-masked v_max_f64, ten vector instructions per match --
+      // measured 115 cycles per match against 103 for the compiler's: the step is bound by the dependent
+      // chain add -> v_readlane -> SGPR -> max, 83 cycles by itself, not by instruction count.)
+      for (int j = 0; j + 1 < cnt; ++j) {
         const double fcur = qv + max_f64(gcol, Bpf);
         const double fj = read_lane(fcur, j);
         const uint32_t lrj = (uint32_t)__builtin_amdgcn_readlane((int)lr, j);
@@ -652,6 +723,7 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
         gcol = take ? fj : gcol; winj = take ? j : winj;
       }
       const double F = inb ? qv + max_f64(gcol, Bpf) : 0.0;      // idle lanes: the identity record, on the empty path
+      DA_CSTAMP(3)
       {
         const uint32_t wid = (uint32_t)__shfl((int)id1, winj < 0 ? 0 : winj);
         const uint32_t cid = winj >= 0 ? wid : tid;   // the column's own candidate (sum gcol)
@@ -675,32 +747,58 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
           if (cur == Fb) atomicMax(reinterpret_cast<unsigned int*>(&s_tree[path[l]]) + 2, id1);
         }
       }
+      DA_CSTAMP(4)
       // ---- running maximum of the column after every row of the window
       double rf = F; uint32_t rid = id1;
-      scan_lexmax(rf, rid, lane);
-      if (beats(Mf, Mid, rf, rid)) { rf = Mf; rid = Mid; }
+      scan_lexmax(rf, rid);
+      lexmax_into(rf, rid, Mf, Mid);
       const uint32_t nrow = (uint32_t)__shfl_down((int)row, 1);
       if (inb && (lane == cnt - 1 || nrow != row)) s_rowmax[rl] = make_node(rf, rid);
       Mf = read_lane(rf, cnt - 1); Mid = (uint32_t)__builtin_amdgcn_readlane((int)rid, cnt - 1);
+      DA_CSTAMP(5)
+#ifdef DA_CHAIN_STAMPS
+      cst[7] += 1;
+#endif
       if (cnt < 64) break;
     }
-    // ---- records for the right neighbour: max(incoming, the column's maximum over rows <= this one)
+    // ---- records for the right neighbour: max(incoming, the column's maximum over rows <= this one).
+    // Rows without a match of this column inherit the previous row's maximum: a prefix maximum over the
+    // rows (serial over the lane's four, then across the lanes).
     {
-      const uint4 rm = s_rowmax[lane];
-      double ff = node_cum(rm); uint32_t fi = rm.z;
-      scan_lexmax(ff, fi, lane);
-      if (beats(Mstart_f, Mstart_id, ff, fi)) { ff = Mstart_f; fi = Mstart_id; }
-      Of = Bf; Oid = Bid;
-      if (beats(ff, fi, Of, Oid)) { Of = ff; Oid = fi; }
-      if (C + 1 < a.n_cols) {
-        store_sc1_b128(out + (int64_t)64 * b + lane, make_node(Of, Oid));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(done_out, (uint32_t)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      double rf[kRowsPerLane]; uint32_t ri[kRowsPerLane];
+#pragma unroll
+      for (int r = 0; r < kRowsPerLane; ++r) {
+        const uint4 rm = s_rowmax[kRowsPerLane * lane + r];
+        rf[r] = node_cum(rm); ri[r] = rm.z;
+        if (r > 0) lexmax_into(rf[r], ri[r], rf[r - 1], ri[r - 1]);
       }
+      double tf = rf[kRowsPerLane - 1]; uint32_t ti = ri[kRowsPerLane - 1];
+      scan_lexmax(tf, ti);                            // inclusive over the lanes' totals
+      double ef; uint32_t ei;
+      dpp_fetch<0x138, 0xf>(tf, ti, ef, ei);          // wave_shr:1 -> exclusive (lane 0 reads the identity)
+      lexmax_into(ef, ei, Mstart_f, Mstart_id);
+      const uint32_t tagw = tag;
+      unsigned long long* p = out8 + ((int64_t)kBatchRows * b + kRowsPerLane * lane) * 3;
+#pragma unroll
+      for (int r = 0; r < kRowsPerLane; ++r) {
+        lexmax_into(rf[r], ri[r], ef, ei);
+        lexmax_into(rf[r], ri[r], Bf[r], Bid[r]);
+        if (has_right) {
+          const unsigned long long hi = (unsigned long long)tagw << 32;
+          __hip_atomic_store(p + 3 * r, hi | (uint32_t)__double2loint(rf[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p + 3 * r + 1, hi | (uint32_t)__double2hiint(rf[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p + 3 * r + 2, hi | ri[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      last_id = ri[kRowsPerLane - 1];
     }
   }
-  // the last column's record of the last row is the heaviest match overall
-  if (C + 1 == a.n_cols && lane == 63) { a.meta[0] = (int64_t)Oid - 1; a.meta[1] = 0; }
+#ifdef DA_CHAIN_STAMPS
+  DA_CSTAMP(6)
+  if (lane == 0) for (int k = 0; k < 8; ++k) a.stamps[(size_t)C * 8 + k] = cst[k];
+#endif
+  // the last column's record of the last row is the heaviest match overall (rows past the end repeat it)
+  if (C + 1 == a.n_cols && lane == 63) { a.meta[0] = (int64_t)last_id - 1; a.meta[1] = 0; }
 }
 
 // ---- preparation of the column-major arrays
@@ -739,13 +837,17 @@ constexpr int kColMaxCols = 4096;
 }  // namespace
 
 ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint) {
-  // More columns = more wavefronts working, down to windows that are mostly empty: keep about half a
-  // window (32 matches) per column and 64-row batch; a column is at least 64 ranks wide and must fit LDS.
+  // More columns = more wavefronts working, but every column walks all the batches, the pipeline takes
+  // n_cols batch times to fill, and the matches along the true alignment -- a few per audio row, all in
+  // the one column the diagonal is crossing -- are a serial chain that no column count shortens.
+  // Measured (MI355X): 2 h pair, 7.2e7 matches: 64 columns 156 ms, 128: 97, 256: 74, 512: 72, 1024: 93;
+  // 22 min pair, 3.1e6 matches: 32: 15.5, 64: 11.1, 128: 9.6, 256: 10.9, 512: 14.2.  About 25 k matches
+  // per column, at most 384 columns; a column is at least 64 ranks wide and must fit LDS.
+  (void)rows_hint;
   if (n_ranks < 1) n_ranks = 1;
-  if (rows_hint < 1) rows_hint = std::max<int64_t>(1, n / 64);
-  int64_t nc = 2 * n / rows_hint;
+  int64_t nc = n / 24576;
   if (const char* e = std::getenv("DALIGN_CHAIN_COLS")) nc = std::atoll(e);
-  else nc = std::min<int64_t>(nc, 512);
+  else nc = std::min<int64_t>(nc, 384);
   nc = std::min<int64_t>(nc, (n_ranks + 63) / 64);
   nc = std::max<int64_t>(nc, (n_ranks + kColMaxWidth - 1) / kColMaxWidth);
   nc = std::max<int64_t>(1, std::min<int64_t>(nc, kColMaxCols));
@@ -754,7 +856,8 @@ ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint
   return ChainColumnPlan{(int)nc, (int)width};
 }
 
-size_t chain_columns_lds_bytes(int width) { return (size_t)(width + 2 + 64) * 16; }
+size_t chain_columns_lds_bytes(int width) { return (size_t)(width + 2 + 2 * kBatchRows) * 16; }
+int chain_columns_batch_rows() { return kBatchRows; }
 
 size_t chain_columns_temp_bytes(int64_t n) {
   size_t b1 = 0, b2 = 0;
@@ -790,9 +893,10 @@ int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream
   ColArgs a{};
   a.c_row = cc.c_row; a.c_lr = cc.c_lr; a.c_q = cc.c_q; a.c_gid = cc.c_gid; a.col_start = cc.col_start;
   a.d_nrows = cc.rowid1 + (c.n - 1);
-  a.n_cols = cc.n_cols; a.width = cc.width; a.msg = cc.msg; a.msg_stride = cc.msg_stride; a.ctl = cc.ctl;
+  a.n_cols = cc.n_cols; a.width = cc.width; a.msg = cc.msg; a.msg_stride = cc.msg_stride; a.ctl = cc.ctl; a.salt = cc.salt;
   a.pred = c.pred; a.meta = c.meta;
   a.spin_limit = 100000000ull * 20ull;                                 // 20 s
+  a.stamps = reinterpret_cast<unsigned long long*>(cc.ctl + kChainCtlHead + ((cc.n_cols + 1) & ~1));
   const size_t lds = chain_columns_lds_bytes(cc.width);
   const int lv = bit_length(cc.width);
   auto go = [&](auto kernel) {
@@ -805,7 +909,7 @@ int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream
   else if (lv <= 11) go(k_chain_columns<11>);
   else if (lv <= 12) go(k_chain_columns<12>);
   else go(k_chain_columns<13>);
-  hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(256), 0, s, c.pred, c.n, c.path_ids, c.meta);
+  hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(kBackThreads), 0, s, c.pred, c.n, c.path_ids, c.meta);
   hipLaunchKernelGGL(k_chain_gather, dim3(256), dim3(256), 0, s, c.keys, c.path_ids, c.meta, c.out_i, c.out_v);
   return 0;
 }
@@ -871,7 +975,7 @@ int launch_chain_dp(const ChainLaunch& c, hipStream_t s) {
   DA_CHAIN_CASE(8, 10) DA_CHAIN_CASE(8, 13) DA_CHAIN_CASE(8, 16)
 #undef DA_CHAIN_CASE
   }
-  hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(256), 0, s, c.pred, c.n, c.path_ids, c.meta);
+  hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(kBackThreads), 0, s, c.pred, c.n, c.path_ids, c.meta);
   hipLaunchKernelGGL(k_chain_gather, dim3(256), dim3(256), 0, s, c.keys, c.path_ids, c.meta, c.out_i, c.out_v);
   return 0;
 }

@@ -180,8 +180,9 @@ struct ChainColumns {
   uint32_t* val_in; uint32_t* val_out;     // [n] match ids, before / after
   uint32_t* c_row; uint16_t* c_lr; double* c_q; uint32_t* c_gid;   // [n + 64] matches in column-major order: row ordinal, local rank, quality, id
   int32_t* col_start;                      // [n_cols + 1]
-  uint4* msg; int64_t msg_stride;          // [n_cols][msg_stride] records handed to the right, one per row (stride = rows rounded up to 64)
-  uint32_t* ctl;                           // [0] column tickets, [1] abort flag, [16 + c] batches published by column c; zeroed per launch
+  unsigned long long* msg; int64_t msg_stride;   // [n_cols][msg_stride rows][3] tagged 8-byte granules handed to the right (stride = rows rounded up to a batch)
+  uint32_t salt;                           // 1 .. 4095, distinct from every launch that has written `msg` since it was last zeroed
+  uint32_t* ctl;                           // [0] column tickets, [1] abort flag; zeroed per launch
   void* temp; size_t temp_bytes;           // hipCUB scratch (chain_columns_temp_bytes)
 };
 constexpr int kChainCtlHead = 16;
@@ -190,6 +191,7 @@ struct ChainColumnPlan { int n_cols, width; };
 ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint);
 size_t chain_columns_temp_bytes(int64_t n);
 size_t chain_columns_lds_bytes(int width);
+int chain_columns_batch_rows();
 // partition + forward DP + back-track + gather, all on stream s (prep has run); -1 = out of range
 int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream_t s);
 

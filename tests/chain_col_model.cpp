@@ -1,7 +1,7 @@
 // CPU model of the column-pipelined chain DP (describealign_amd/csrc/dalign_chain.hip, k_chain_columns).
 // Test infrastructure: tests/test_host_cpu.py compiles this file with g++ and checks the model against the
 // host utility (da_chain with a NULL context) on random, tie-heavy instances, so the DECOMPOSITION the
-// kernel uses -- rank columns, 64-row message batches, 64-point windows, two-phase tree update -- is
+// kernel uses -- rank columns, 256-row record batches, 64-point windows, two-phase tree update -- is
 // pinned on the CPU; the GPU tests then pin the kernel itself.
 //
 // Recurrence (describealign.py:654-656, :674-697): over matches sorted by (audio frame i, video frame v)
@@ -24,6 +24,7 @@ namespace {
 struct Rec { double f; uint32_t id1; };                      // id1 = id + 1, 0 = none
 inline bool beats(const Rec& a, const Rec& b) { return a.f > b.f || (a.f == b.f && a.id1 > b.id1); }
 inline Rec lexmax(const Rec& a, const Rec& b) { return beats(b, a) ? b : a; }
+constexpr int kBatchRows = 256;                               // rows per hand-over batch (64 lanes x 4 rows in the kernel)
 
 }  // namespace
 
@@ -42,11 +43,11 @@ extern "C" int chain_col_model(const int32_t* pi, const int32_t* pv, const doubl
   int32_t n_rows = 0;
   for (int64_t k = 0; k < n; ++k) { if (k == 0 || pi[k] != pi[k - 1]) ++n_rows; rowid[k] = n_rows - 1; }
   const int NC = (n_ranks + w - 1) / w;
-  const int n_batches = (n_rows + 63) / 64;
+  const int n_batches = (n_rows + kBatchRows - 1) / kBatchRows;
   // stable partition by column
   std::vector<std::vector<int32_t>> cols((size_t)NC);
   for (int64_t k = 0; k < n; ++k) cols[(rk[pv[k]] - 1) / w].push_back((int32_t)k);
-  std::vector<Rec> Bin((size_t)n_batches * 64, Rec{0.0, 0u}), Bout((size_t)n_batches * 64);
+  std::vector<Rec> Bin((size_t)n_batches * kBatchRows, Rec{0.0, 0u}), Bout((size_t)n_batches * kBatchRows);
   int LV = 1; while ((1 << LV) <= w) ++LV;                     // longest Fenwick path
   for (int C = 0; C < NC; ++C) {
     const std::vector<int32_t>& P = cols[C];
@@ -54,17 +55,17 @@ extern "C" int chain_col_model(const int32_t* pi, const int32_t* pv, const doubl
     Rec M{0.0, 0u};
     size_t cursor = 0;
     for (int b = 0; b < n_batches; ++b) {
-      Rec rowmax[64];
-      for (int r = 0; r < 64; ++r) rowmax[r] = Rec{0.0, 0u};
+      Rec rowmax[kBatchRows];
+      for (int r = 0; r < kBatchRows; ++r) rowmax[r] = Rec{0.0, 0u};
       const Rec Mstart = M;
       while (true) {
         int cnt = 0;
-        while (cnt < 64 && cursor + cnt < P.size() && rowid[P[cursor + cnt]] < 64 * (b + 1)) ++cnt;
+        while (cnt < 64 && cursor + cnt < P.size() && rowid[P[cursor + cnt]] < kBatchRows * (b + 1)) ++cnt;
         if (cnt == 0) break;
         int32_t row[64], lr[64], gid[64]; double q[64]; Rec B[64];
         for (int p = 0; p < cnt; ++p) {
-          gid[p] = P[cursor + p]; row[p] = rowid[gid[p]] - 64 * b; lr[p] = (rk[pv[gid[p]]] - 1) % w + 1; q[p] = pq[gid[p]];
-          B[p] = Bin[(size_t)64 * b + row[p]];
+          gid[p] = P[cursor + p]; row[p] = rowid[gid[p]] - kBatchRows * b; lr[p] = (rk[pv[gid[p]]] - 1) % w + 1; q[p] = pq[gid[p]];
+          B[p] = Bin[(size_t)kBatchRows * b + row[p]];
         }
         // tree query (state before the window)
         Rec t[64]; double gcol[64]; int winj[64];
@@ -108,13 +109,13 @@ extern "C" int chain_col_model(const int32_t* pi, const int32_t* pv, const doubl
         if (cnt < 64) break;
       }
       Rec fill = Mstart;
-      for (int r = 0; r < 64; ++r) {
+      for (int r = 0; r < kBatchRows; ++r) {
         fill = lexmax(fill, rowmax[r]);
-        Bout[(size_t)64 * b + r] = lexmax(Bin[(size_t)64 * b + r], fill);
+        Bout[(size_t)kBatchRows * b + r] = lexmax(Bin[(size_t)kBatchRows * b + r], fill);
       }
     }
     Bin.swap(Bout);
   }
-  *best = (int64_t)Bin[(size_t)n_batches * 64 - 1].id1 - 1;
+  *best = (int64_t)Bin[(size_t)n_batches * kBatchRows - 1].id1 - 1;
   return 0;
 }

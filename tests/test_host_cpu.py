@@ -58,6 +58,41 @@ def test_chain_dp_host_only_matches_reference_and_oracle(lib):
     _native.chain_host(np.array([3, 1], dtype=np.int32), np.array([0, 0], dtype=np.int32), np.ones(2))
 
 
+def test_column_decomposition_of_the_chain_dp_equals_the_recurrence(lib, tmp_path):
+  """The device chain DP (k_chain_columns) cuts the video ranks into columns that hand one record per
+  audio row to the right, takes matches 64 at a time and updates its tree in two phases.
+  tests/chain_col_model.cpp restates exactly that decomposition on the CPU; here it is compiled and
+  checked against the host utility (plain Fenwick recurrence) on random instances with many equal sums,
+  for column widths from 1 rank to wider than the input, rows wider than a window and more than one
+  256-row batch.  (The kernel itself is checked against the same utility in the GPU tests.)"""
+  import ctypes as C
+  from describealign_amd import _native
+  so = str(tmp_path / "chain_col_model.so")
+  subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(os.path.dirname(__file__), "chain_col_model.cpp")], check=True)
+  model = C.CDLL(so)
+  vp = C.c_void_p
+
+  def run(i, v, q, w):
+    n = len(i); pred = np.empty(n, np.int32); best = C.c_int64(-1)
+    model.chain_col_model(vp(i.ctypes.data), vp(v.ctypes.data), vp(q.ctypes.data), C.c_int64(n), C.c_int(w), vp(pred.ctypes.data), C.byref(best))
+    ids, p = [], best.value
+    while p >= 0:
+      ids.append(p); p = int(pred[p])
+    ids = np.array(ids[::-1], np.int64)
+    return i[ids], v[ids]
+
+  rng = np.random.default_rng(21)
+  for trial in range(24):
+    n = int(rng.integers(1, 30000)); rows = int(rng.integers(1, 3000)); cols = int(rng.integers(1, 4000))
+    w = int(rng.choice([1, 2, 3, 7, 64, 100, 256, 1000, 4096]))
+    key = np.unique(rng.integers(0, rows, n).astype(np.int64) << 32 | rng.integers(0, cols, n) * 4)
+    i = (key >> 32).astype(np.int32); v = (key & 0xffffffff).astype(np.int32)
+    q = rng.choice([50.0, 50.0, 12.5, 3.25, 0.75], len(i)) if trial % 3 else rng.uniform(0.001, 50, len(i))
+    wi, wv = _native.chain_host(i, v, q)
+    gi, gv = run(i, v, np.ascontiguousarray(q, dtype=np.float64), w)
+    assert len(gi) == len(wi) and np.array_equal(gi, wi) and np.array_equal(gv, wv), (trial, n, rows, cols, w)
+
+
 def test_no_cpu_fallback_context_fails_loudly():
   import torch
   if torch.cuda.is_available():
