@@ -15,7 +15,8 @@ Workloads (BASELINE.json configs):
         configuration and the north_star target                                      (default)
   cfg1  configs[1] stand-in: 1320 s video / ~1558 s AD, 10 jumps + 200 s intro, mono, fp32 GEMM
         (reported as the `secondary` object of the same JSON line at N = 1)
-  cfg3  configs[3], one GPU's share: 1800 s mono pairs, fp32 GEMM (--gpus 8 runs the whole config)
+  cfg3  configs[3], one GPU's share: 1800 s mono pairs, bf16 prefilter GEMM (--gpus 8 runs the whole
+        config; reported as the `secondary_cfg3` object of the same JSON line at N = 1)
 
 Timed region (steady state of a directory batch).  The pairs go through ONE primed pipeline: an
 untimed lead-in of max(W, two LP solves per host worker) pairs, K timed pairs and a tail that keeps
@@ -48,7 +49,7 @@ WORKLOADS = {
                seconds=7200.0, n_jumps=10, first_gap=200.0, channels=2, precision="bf16"),
   "cfg3": dict(desc="configs[3] per-GPU share: synthetic 1800 s (30 min) mono pairs, 10 jumps + 120 s intro (the batch of 32 shards "
                     "embarrassingly: every rank streams its own pairs)",
-               seconds=1800.0, n_jumps=10, first_gap=120.0, channels=1, precision="f32"),
+               seconds=1800.0, n_jumps=10, first_gap=120.0, channels=1, precision="bf16"),
   "cfg-small": dict(desc="600 s mono pair, 5 jumps (CI-sized)",
                     seconds=600.0, n_jumps=5, first_gap=60.0, channels=1, precision="f32"),
 }
@@ -82,6 +83,9 @@ def cpu_baseline(channels, workload_seconds, sample_seconds=None):
     model = "unknown"
   return pair, (x, y), dict(
       value=(sample_seconds / 3600.0) / dt, unit="audio-hours/s", cores=1, kind="port",
+      note="the numpy restatement of the reference algorithm (oracle/dalign_oracle.py), about 7x faster than the reference's own "
+           "Python (describealign.py measured in the survey container: 65.6 s for a 1320 s pair, 0.0056 audio-hours/s); one core, "
+           "as the reference is single-threaded",
       sample=f"{sample_seconds:.0f} s video / {pair.audio_seconds:.0f} s AD synthetic {'stereo' if channels == 2 else 'mono'} pair, "
              f"{n_jumps} jumps; features {t1 - t0:.1f} s + align {t2 - t1:.1f} s through oracle/dalign_oracle.py on one core",
       seconds=round(dt, 2), host_cpu=model, host_cores=os.cpu_count(),
@@ -257,9 +261,14 @@ class Bench:
                    "video_seconds": wl["seconds"], "audio_seconds": round(pair.audio_seconds, 1),
                    "channels": wl["channels"], "parallelism": f"pairs sharded over {world} GPU(s), no collectives"},
         "realtime_factor": wl["seconds"] * world * steps / elapsed,
+        "lead_in_pairs_actual": warmup,
+        "whole_stream_value": hours * world * total / (t_end - t_start),
         "timed_region": {"kind": "steady state of one primed pipeline" if pipe is not None else "sequential align() calls",
                          "pairs_streamed": total, "untimed_lead_in_pairs": warmup, "tail_pairs": tail,
-                         "whole_stream_s": round(t_end - t_start, 2), "timed_s": round(elapsed, 3)},
+                         "whole_stream_s": round(t_end - t_start, 2), "timed_s": round(elapsed, 3),
+                         "note": "`warmup` echoes the command line; the untimed lead-in actually streamed is `lead_in_pairs_actual` "
+                                 "(at least two LP solves per host worker), `whole_stream_value` is the rate over every pair streamed, "
+                                 "lead-in and tail included"},
         "single_pair_latency_s": round(acc["align_s"] / k, 3),
         "single_pair_realtime_factor": round(wl["seconds"] / (acc["align_s"] / k), 1),
         "roofline": {"bound": "mfma", "kernel": "k_match_" + prec_name, "achieved": gemm_tf, "peak": peak, "unit": "TFLOP/s",
@@ -284,9 +293,23 @@ class Bench:
         "pcm_h2d_ms_audio_side": round(h2d_ms, 2),
         "pcm_h2d_ms_per_step": round(sum(h2d_acc) / max(1, len(h2d_acc)), 2) if include_h2d else None,
       }
+      # Which stage limits the stream: the GPU stage (one thread feeds features + prep + GEMM + verify of pair
+      # k+1 while the chain DP of pair k runs on its own stream) or the host LP (scipy.optimize.linprog,
+      # host-side by contract, one solve per worker process at a time).
+      gpu_stage_ms = sum(acc[n] for n in ("feat_ms", "prep_ms", "gemm_ms", "verify_ms")) / k
+      gpu_rate = 1e3 / gpu_stage_ms if gpu_stage_ms > 0 else float("inf")
+      gpu_rate_wall = k / acc["match_s"] if acc.get("match_s") else float("inf")
+      lp_rate = workers * k / acc["lp_s"] if workers > 0 and acc.get("lp_s") else (k / acc["lp_s"] if acc.get("lp_s") else float("inf"))
+      res["gpu_stage_pairs_per_s"] = round(min(gpu_rate, gpu_rate_wall), 3)
+      res["lp_solves_per_s_host"] = round(lp_rate, 3)
+      res["measured_pairs_per_s"] = round(world * steps / elapsed, 3)
+      res["bound"] = "host_lp" if lp_rate < 0.9 * min(gpu_rate, gpu_rate_wall) else "gpu"
+      res["bound_note"] = (f"GPU stage {gpu_stage_ms:.1f} ms of kernels per pair ({gpu_rate:.2f} pairs/s; {gpu_rate_wall:.2f} pairs/s by the feeding "
+                           f"thread's wall clock); host LP {acc['lp_s'] / k:.2f} s per solve x {max(1, workers)} worker processes = {lp_rate:.2f} solves/s on "
+                           f"this host ({os.cpu_count()} logical CPUs, shared by every rank of the node)")
       # HBM traffic of the dominant kernel from the committed PMC profile of this workload (PMC
       # collection needs its own rocprofv3 passes; bench.py itself only times with HIP events)
-      for prof_name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+      for prof_name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
           prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
           key = workload + "_" + prec_name
@@ -333,6 +356,12 @@ class Bench:
     return res
 
 
+SECONDARY_KEYS = ("value", "unit", "steps", "warmup", "lead_in_pairs_actual", "whole_stream_value", "ms_per_step", "dtype", "config",
+                  "realtime_factor", "roofline", "feature_stage", "stage_ms_per_step", "host_s_per_step", "counts", "bound",
+                  "gpu_stage_pairs_per_s", "lp_solves_per_s_host", "measured_pairs_per_s", "single_pair_latency_s",
+                  "max_offset_err_vs_injected_ms")
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -346,7 +375,8 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-sample-seconds", type=float, default=None)
   ap.add_argument("--no-pcie", action="store_true", help="skip the short PCIe-inclusive measurement reported as `pcie_inclusive`")
-  ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] measurement reported as `secondary`")
+  ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[3] measurements reported as `secondary` / `secondary_cfg3`")
+  ap.add_argument("--no-cfg3", action="store_true", help="skip only the configs[3] measurement")
   ap.add_argument("--include-h2d", action="store_true",
                   help="diagnostic: re-upload the PCM over PCIe inside every step (the PCIe-inclusive rate; never the headline value)")
   ap.add_argument("--gpu-streams", type=int, default=1,
@@ -377,9 +407,11 @@ def main():
   if single and args.workload == "cfg2" and not args.no_secondary and args.precision is None:
     sec = b.run("cfg1", max(args.steps, 64), max(args.warmup, 8), with_cpu_baseline=False, with_stretch=False)
     if res is not None and sec is not None:
-      res["secondary"] = {k: sec[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "realtime_factor",
-                                              "roofline", "feature_stage", "stage_ms_per_step", "host_s_per_step", "counts",
-                                              "single_pair_latency_s", "max_offset_err_vs_injected_ms")}
+      res["secondary"] = {k: sec[k] for k in SECONDARY_KEYS}
+    if not args.no_cfg3:
+      sec = b.run("cfg3", max(args.steps, 64), max(args.warmup, 8), with_cpu_baseline=False, with_stretch=False)
+      if res is not None and sec is not None:
+        res["secondary_cfg3"] = {k: sec[k] for k in SECONDARY_KEYS}
   if grp.rank == 0:
     print(json.dumps(res))
   grp.close()

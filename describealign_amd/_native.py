@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DALIGN_LIB") or os.path.join(_HERE, "libdalign.so")   # DALIGN_LIB: diagnostic builds
 ABI_VERSION = 4
+BF16_GUARD = 2.0 ** -7 + 2.0 ** -14   # csrc/dalign_common.h kBf16Guard: subtracted from the norm slot of the bf16 GEMM
 
 PREC_F32, PREC_BF16 = 0, 1
 SIDE_VIDEO, SIDE_AUDIO = 0, 1

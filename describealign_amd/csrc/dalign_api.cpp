@@ -485,10 +485,11 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
   m.vlist = c->vlist.as<int32_t>(); m.n_v = n_v;
   m.alist = c->alist.as<int32_t>(); m.n_a = n_a;
   const double thr_exact = std::pow(1e-8, 1.0 / 2.9);
-  // safety margin of the prefilter: f32 MFMA is an exact fmaf chain (error ~1e-7 of |a||b|);
-  // bf16 operands carry 2^-9 relative rounding each, so the product of three (1-corr) terms is
-  // thresholded with a factor-2 margin and everything is re-verified in float64 afterwards.
-  m.thr = (float)(thr_exact * (c->precision == DA_PREC_F32 ? 1.001 : 2.0));
+  // safety margin of the prefilter: f32 MFMA is an exact fmaf chain (error ~1e-7 of |a||b|): 1.001.
+  // bf16: the operand rounding is covered by the guard subtracted from the norm slot (kBf16Guard: the
+  // accumulators never exceed the exact values), so the same 1.001 covers the f32 epilogue arithmetic;
+  // everything is re-verified in float64 afterwards.
+  m.thr = (float)(thr_exact * 1.001);
   if (const char* dbg = std::getenv("DALIGN_DEBUG_THR_SCALE")) m.thr *= (float)std::atof(dbg);   // profiling only
   // audio chunking: enough blocks to fill the chip several times over
   {

@@ -11,6 +11,12 @@ constexpr int kTaps = 7;            // hash taps per feature        (:610)
 constexpr int kTapStep = 6;         // (:611)
 constexpr int kTapStart = 2;        // (:613)
 constexpr int kPad = 64;            // zero padding (elements) after every per-frame device row
+// bf16 prefilter: guard subtracted from the audio window norm that rides in the GEMM's spare K slots.
+// Operands are rounded to bf16 (relative error <= 2^-8 each), products are exact in f32, so the computed
+// dot product differs from the exact one by at most (2^-7 + 2^-16) sum|x_k y_k| <= (2^-7 + 2^-16) |A|
+// (Cauchy-Schwarz, |x| = 1).  With |A| (1 - guard) in the norm slot the accumulator never exceeds the
+// exact |A| (1 - corr): every pair the exact criterion accepts survives the prefilter, whatever the data.
+constexpr double kBf16Guard = 0.0078125 + 0.00006103515625;      // 2^-7 + 2^-14
 
 // ---- feature kernel tables (built on the host in double, see dalign_api.cpp) ----------------
 struct FeatTables {

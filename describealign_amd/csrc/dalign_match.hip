@@ -82,9 +82,11 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
   a.nrm[j][i] = nr;
   if (j < 3) {
     a.inv32[j][i] = (float)(1.0 / nr); a.nrm32[j][i] = (float)nr;
-    const uint16_t hi = f32_to_bf16((float)nr);
+    // bf16 GEMM: the norm slot carries |A| (1 - guard), see kBf16Guard: the accumulator under-estimates
+    const double ng = nr * (1.0 - kBf16Guard);
+    const uint16_t hi = f32_to_bf16((float)ng);
     const float hif = __uint_as_float((uint32_t)hi << 16);
-    const uint16_t lo = f32_to_bf16((float)(nr - (double)hif));
+    const uint16_t lo = f32_to_bf16((float)(ng - (double)hif));
     a.nrmpk[j][i] = (uint32_t)hi | ((uint32_t)lo << 16);
   }
   uint32_t dig = 0, flg = 0;
@@ -381,8 +383,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 1) void k_match_f32(MatchArgs 
 // survivor is re-verified in float64 by k_verify).
 // K = 41 padded to 48 = three K-steps of 16, permuted so that lane half h, step s, element e holds
 // k = 24 h + 8 s + e (each lane's operands are 24 consecutive bf16; two shifted copies of the row
-// make any start 4-byte aligned).  Spare slots k = 42, 43 carry the audio window norm split into
-// two bf16 (A holds 1 there): the accumulator ends as |A| (1 - corr) and the epilogue per video row
+// make any start 4-byte aligned).  Spare slots k = 42, 43 carry the audio window norm, less the rounding
+// guard kBf16Guard, split into two bf16 (A holds 1 there): the accumulator ends as |A| (1 - guard - corr)
+// plus rounding that the guard bounds, i.e. never above the exact |A| (1 - corr), and the epilogue per video row
 // is three VALU instructions: p = a0 a1;  d = p a2 - thr |A|_0 |A|_1 |A|_2;  mask = (mask << 1) | sign(d).
 //
 // The kernel (k_match_bf16, further down) is organised like k_match_f32: one wave per SIMD, the resident
