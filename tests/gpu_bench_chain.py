@@ -29,7 +29,13 @@ def main():
     mi, mv, mq = ctx.match(vf, af)
     st = ctx.stats()
     t0 = time.perf_counter(); gi, gv = ctx.chain_resident(); wall_dev = time.perf_counter() - t0
-    dev_ms = ctx.stats()["chain_ms"]
+    dev_ms = ctx.stats()["chain_ms"]; n_cols = int(ctx.stats()["chain_columns"]); col_width = int(ctx.stats()["chain_column_width"])
+    # the round-2 kernel (one workgroup, four wavefronts per row) on the same list, for the record
+    os.environ["DALIGN_CHAIN_KERNEL"] = "rows"
+    ctx.match_begin(vf, af); ctx.match_finish()
+    ri, rv = ctx.chain_resident(); rows_ms = ctx.stats()["chain_ms"]
+    os.environ.pop("DALIGN_CHAIN_KERNEL")
+    same_rows = bool(np.array_equal(ri, gi) and np.array_equal(rv, gv))
     t0 = time.perf_counter(); hi, hv = _native.chain_host(mi, mv, mq); host_s = time.perf_counter() - t0
     same = bool(len(gi) == len(hi) and np.array_equal(gi, hi) and np.array_equal(gv, hv))
     rows = int(len(np.unique(mi)))
@@ -45,7 +51,8 @@ def main():
     ticket2 = ctx.chain_begin(); ctx.chain_finish(ticket2)
     print(json.dumps(dict(seconds=sec, matches=len(mi), rows=rows, matches_per_row=round(len(mi) / max(rows, 1), 2),
                           video_ranks=int(st["gemm_pairs"] / max(1, len(np.unique(mi)))) if False else None,
-                          path=len(gi), identical_to_host=same, device_chain_ms=round(dev_ms, 2),
+                          path=len(gi), identical_to_host=same, device_chain_ms=round(dev_ms, 2), columns=n_cols, column_width=col_width,
+                          one_workgroup_kernel_ms=round(rows_ms, 2), one_workgroup_kernel_identical=same_rows,
                           device_wall_ms=round(1e3 * wall_dev, 2), host_chain_ms=round(1e3 * host_s, 2),
                           ns_per_match_device=round(1e6 * dev_ms / max(1, len(mi)), 2),
                           us_per_row_device=round(1e3 * dev_ms / max(1, rows), 3),
