@@ -317,34 +317,59 @@ __global__ __launch_bounds__(FeatCfg<C>::kThreads, DA_FEAT_MIN_WAVES) void k_fea
   __syncthreads();
 
   // ---- stage 4: outputs -----------------------------------------------------------------------
-  for (int ml = tid; ml < Cfg::kOut; ml += Cfg::kThreads) {
+  // One lane per (row, output frame), the rows dealt over the workgroup's three waves: the float64-logarithm
+  // row on wave 0, the two float64 band rows on waves 1 and 2 together with the two light rows.  (With all five
+  // rows of a frame on one lane -- the first version -- wave 0 worked alone through ~500 dependent, mostly
+  // float64 instructions while the other two waves had already finished and the workgroup's slot stayed taken:
+  // measured on the streaming experiment, DESIGN.md section 4.1, this stage was a third of the kernel.)
+  {
+    const int wave = tid >> 6, ml = tid & 63;
     const int64_t mfr = f0 + ml;
     const int g = ml + Cfg::kHalo;
-    if (mfr < a.len_energy) {
-      float acc = 0.f;
+    if (ml < Cfg::kOut && Cfg::kThreads == 192) {
+      if (wave == 0) {
+        if (mfr < a.len_other) {
+          double b3 = 0.0;
 #pragma unroll
-      for (int t = -6; t <= 6; ++t) acc = fmaf(T.w13[t + 6], s_eb[2 * g + t], acc);
-      a.out[0 * a.row_stride + mfr] = log10f(1.0f + acc) * 0.5f;           // (:554)
-    }
-    if (mfr < a.len_other) {
-      float zacc = 0.f;
+          for (int k = 0; k < 15; ++k) b3 = fma((double)T.w15[k], s_F[6 * Cfg::kExt + g + 7 - k], b3);
+          a.out[4 * a.row_stride + mfr] = (float)(log10(1.0 + b3 / 210.0) * 0.5);
+        }
+      } else if (wave == 1) {
+        if (mfr < a.len_other) {
+          double b1 = 0.0;
 #pragma unroll
-      for (int t = -6; t <= 6; ++t) zacc = fmaf(T.w13[t + 6], s_zf[g + t], zacc);
-      a.out[1 * a.row_stride + mfr] = zacc;
-      double b1 = 0.0, b2 = 0.0, b3 = 0.0;
+          for (int k = 0; k < 15; ++k) {
+            const int gg = g + 7 - k;
+            b1 += s_F[0 * Cfg::kExt + gg] - T.ck1[k] * s_F[1 * Cfg::kExt + gg] + T.sk1[k] * s_F[2 * Cfg::kExt + gg];
+          }
+          b1 *= T.a1;
+          a.out[2 * a.row_stride + mfr] = log10f(1.0f + (float)(b1 / 210.0)) * 0.5f;   // (:589-590)
+        }
+        if (mfr < a.len_energy) {
+          float acc = 0.f;
 #pragma unroll
-      for (int k = 0; k < 15; ++k) {
-        const int gg = g + 7 - k;
-        b1 += s_F[0 * Cfg::kExt + gg] - T.ck1[k] * s_F[1 * Cfg::kExt + gg] + T.sk1[k] * s_F[2 * Cfg::kExt + gg];
-        b2 += s_F[3 * Cfg::kExt + gg] - T.ck2[k] * s_F[4 * Cfg::kExt + gg] + T.sk2[k] * s_F[5 * Cfg::kExt + gg];
-        b3 = fma((double)T.w15[k], s_F[6 * Cfg::kExt + gg], b3);
+          for (int t = -6; t <= 6; ++t) acc = fmaf(T.w13[t + 6], s_eb[2 * g + t], acc);
+          a.out[0 * a.row_stride + mfr] = log10f(1.0f + acc) * 0.5f;           // (:554)
+        }
+      } else {
+        if (mfr < a.len_other) {
+          double b2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 15; ++k) {
+            const int gg = g + 7 - k;
+            b2 += s_F[3 * Cfg::kExt + gg] - T.ck2[k] * s_F[4 * Cfg::kExt + gg] + T.sk2[k] * s_F[5 * Cfg::kExt + gg];
+          }
+          b2 *= T.a2;
+          a.out[3 * a.row_stride + mfr] = log10f(1.0f + (float)(b2 / 210.0)) * 0.5f;
+          float zacc = 0.f;
+#pragma unroll
+          for (int t = -6; t <= 6; ++t) zacc = fmaf(T.w13[t + 6], s_zf[g + t], zacc);
+          a.out[1 * a.row_stride + mfr] = zacc;
+        }
       }
-      b1 *= T.a1; b2 *= T.a2;
-      a.out[2 * a.row_stride + mfr] = log10f(1.0f + (float)(b1 / 210.0)) * 0.5f;   // (:589-590)
-      a.out[3 * a.row_stride + mfr] = log10f(1.0f + (float)(b2 / 210.0)) * 0.5f;
-      a.out[4 * a.row_stride + mfr] = (float)(log10(1.0 + b3 / 210.0) * 0.5);
     }
   }
+  static_assert(Cfg::kThreads == 192 && Cfg::kOut <= 64, "stage 4 deals the rows over three waves");
 }
 
 template <int C> static void launch_one(const FeatArgs& a, const FeatTables* d_tables, hipStream_t s) {
