@@ -673,9 +673,15 @@ extern "C" int da_match_import_device(da_ctx* c, const uint64_t* d_keys, const d
     launch_unpack_keys(sl.keys.as<unsigned long long>(), n, c->keys0.as<int32_t>(), c->keys0.as<int32_t>() + n, c->stream);
     HIP_TRY(c, hipGetLastError());
   }
+  // the audio rows the list covers (the column DP sizes its per-row records by it): counted here, the call synchronises anyway
+  unsigned long long n_rows = 0;
+  unsigned long long* d_rows = c->counters.as<unsigned long long>() + 7;      // bytes 56..63 of `counters`
+  HIP_TRY(c, hipMemsetAsync(d_rows, 0, sizeof n_rows, c->stream));
+  if (n > 0) da::launch_count_rows(sl.keys.as<unsigned long long>(), n, d_rows, c->stream);
+  HIP_TRY(c, hipMemcpyAsync(&n_rows, d_rows, sizeof n_rows, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   sl.n = n; sl.n_ranks = c->pend_nv; sl.state = 1;
-  sl.rows_hint = c->side[1].lmax;                       // the imported list may cover every audio row of the pair
+  sl.rows_hint = (int64_t)n_rows;
   c->res_slot = si;
   c->n_match_resident = (unsigned long long)n;
   c->st.matches = (double)n;

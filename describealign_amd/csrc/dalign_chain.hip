@@ -980,6 +980,24 @@ int launch_chain_dp(const ChainLaunch& c, hipStream_t s) {
   return 0;
 }
 
+// number of distinct audio rows of a sorted key list (i << 32 | v): one count per block, one atomic each
+__global__ __launch_bounds__(256) void k_count_rows(const unsigned long long* __restrict__ keys, int64_t n, unsigned long long* __restrict__ count) {
+  __shared__ int s_part[4];
+  int mine = 0;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+    mine += (k == 0 || (uint32_t)(keys[k - 1] >> 32) != (uint32_t)(keys[k] >> 32)) ? 1 : 0;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(count, (unsigned long long)(s_part[0] + s_part[1] + s_part[2] + s_part[3]));
+}
+void launch_count_rows(const unsigned long long* keys, int64_t n, unsigned long long* d_count, hipStream_t s) {
+  if (n <= 0) return;
+  const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_count_rows, dim3(blocks), dim3(256), 0, s, keys, n, d_count);
+}
+
 void launch_rankmap(const int32_t* vlist, int64_t n_v, int32_t* rankmap, hipStream_t s) {
   if (n_v <= 0) return;
   hipLaunchKernelGGL(k_rankmap, dim3((unsigned)((n_v + 255) / 256)), dim3(256), 0, s, vlist, n_v, rankmap);

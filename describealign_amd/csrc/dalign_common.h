@@ -208,5 +208,7 @@ size_t chain_rows_temp_bytes(int64_t n);
 int launch_chain_prep(const ChainLaunch& c, hipStream_t s, bool columns);
 int launch_chain_dp(const ChainLaunch& c, hipStream_t s);
 void launch_rankmap(const int32_t* vlist, int64_t n_v, int32_t* rankmap, hipStream_t s);
+// distinct audio rows of a sorted key list, ADDED to *d_count (zero it first)
+void launch_count_rows(const unsigned long long* keys, int64_t n, unsigned long long* d_count, hipStream_t s);
 
 }  // namespace da

@@ -439,13 +439,14 @@ def _match_keys(c, vf, af):
   return (mi.astype(np.int64) << 32) | mv.astype(np.int64), mq
 
 
-@pytest.mark.parametrize("seconds", [1800.0, 7200.0])
-def test_bf16_prefilter_loses_no_match_at_size(ctx, ctx_bf16, seconds):
-  """The bf16 GEMM is a prefilter with a relaxed threshold; every survivor is re-verified in float64.
-  Its verified match SET (and every quality) must equal the f32 path's -- checked on whole pairs of
-  config-4 and config-3 duration (3.8e6 / 7e7 matches), not by count."""
+@pytest.mark.parametrize("seconds,channels", [(1800.0, 1), (7200.0, 1), (7200.0, 2)])
+def test_bf16_prefilter_loses_no_match_at_size(ctx, ctx_bf16, seconds, channels):
+  """The bf16 GEMM is a prefilter (rounding guard in the norm slot, csrc/dalign_common.h kBf16Guard); every
+  survivor is re-verified in float64.  Its verified match SET (and every quality) must equal the f32 path's
+  -- checked on whole pairs of config-3 and config-2 duration (3.8e6 / 7e7 matches), mono and the
+  configs[2] stereo shape, not by count."""
   from describealign_amd import synth
-  pair = synth.make_pair(9 if seconds < 3000 else 11, seconds, n_jumps=10, first_gap=120.0)
+  pair = synth.make_pair(9 if seconds < 3000 else 11, seconds, n_jumps=10, first_gap=120.0, channels=channels)
   vf = ctx.features(pair.video, 0); af = ctx.features(pair.audio, 1)
   k32, q32 = _match_keys(ctx, vf, af)
   k16, q16 = _match_keys(ctx_bf16, [f.copy() for f in vf], [f.copy() for f in af])
