@@ -715,7 +715,7 @@ class AlignPipeline:
     self._n_done = 0
     self._queued = {}      # per GPU context: pairs submitted to its thread that have not started yet
     self._chains = {}      # per GPU context: pairs whose chain DP is enqueued (ticket, ...), oldest first
-    self.max_chains = int(os.environ.get("DALIGN_MAX_CHAINS", "12"))      # DPs in flight per context (the library allows 16)
+    self.max_chains = int(os.environ.get("DALIGN_MAX_CHAINS", "6"))       # DPs in flight per context (the library allows 16; a DP takes 10-70 ms)
     import sys
     self._old_switch = sys.getswitchinterval()
     sys.setswitchinterval(2e-4)

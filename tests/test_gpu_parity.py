@@ -225,6 +225,30 @@ def test_chain_kernel_equals_host_utility(ctx, native, shape, kernel, monkeypatc
   assert ctx.stats()["chain_ms"] > 0
 
 
+def test_chain_tiny_and_degenerate_instances(ctx, native):
+  """Corner shapes of the column pipeline: one match; one row; one video frame; a diagonal where every
+  match chains from the previous one; equal qualities everywhere (every comparison a tie); row counts
+  around the 256-row batch and match counts around the 64-match window."""
+  def check(i, v, q):
+    i = np.asarray(i, np.int32); v = np.asarray(v, np.int32); q = np.asarray(q, np.float64)
+    wi, wv = native.chain_host(i, v, q)
+    gi, gv = ctx.chain(i, v, q)
+    assert np.array_equal(gi, wi) and np.array_equal(gv, wv), (len(i), i[:8], v[:8])
+  check([5], [7], [1.5])
+  check([0, 0, 0], [0, 4, 8], [1.0, 1.0, 1.0])                               # one row: the whole row chains
+  check([0, 1, 2, 3], [8, 8, 8, 8], [2.0, 2.0, 2.0, 2.0])                      # one video frame
+  check([0, 1, 2, 3], [12, 8, 4, 0], [5.0, 1.0, 1.0, 1.0])                     # anti-diagonal: no chain longer than one
+  for n in (63, 64, 65, 255, 256, 257, 511, 513, 1000):
+    k = np.arange(n)
+    check(k, 4 * k, np.full(n, 50.0))                                         # diagonal, all ties
+    check(k, 4 * (k // 3), np.full(n, 12.5))                                  # three rows per video frame
+    check(k // 5, 4 * (k % 5) + 20 * (k // 5), np.full(n, 3.25))              # five matches per row
+  rng = np.random.default_rng(99)
+  for rows in (1, 2, 255, 256, 257, 600):
+    i, v, q = _random_chain_instance(rng, 4000, rows, 50, quals=(50.0,))
+    check(i, v, q)
+
+
 def test_chain_resident_equals_chain_of_fetched_matches(ctx, native):
   """da_chain_resident works on the match list left on the device by da_match; the same list copied
   out and run through the host utility gives the same path.  Two DPs may be in flight at once."""
