@@ -300,13 +300,14 @@ class Bench:
       gpu_rate = 1e3 / gpu_stage_ms if gpu_stage_ms > 0 else float("inf")
       gpu_rate_wall = k / acc["match_s"] if acc.get("match_s") else float("inf")
       lp_rate = workers * k / acc["lp_s"] if workers > 0 and acc.get("lp_s") else (k / acc["lp_s"] if acc.get("lp_s") else float("inf"))
-      res["gpu_stage_pairs_per_s"] = round(min(gpu_rate, gpu_rate_wall), 3)
-      res["lp_solves_per_s_host"] = round(lp_rate, 3)
+      res["gpu_stage_pairs_per_s"] = round(min(gpu_rate, gpu_rate_wall), 3)        # per GPU (rank 0's figures)
+      res["lp_solves_per_s_rank"] = round(lp_rate, 3)                               # this rank's worker processes
+      res["lp_solves_per_s_host"] = round(lp_rate * world, 3)                       # all ranks of the node share the host: rank 0's rate x ranks
       res["measured_pairs_per_s"] = round(world * steps / elapsed, 3)
       res["bound"] = "host_lp" if lp_rate < 0.9 * min(gpu_rate, gpu_rate_wall) else "gpu"
       res["bound_note"] = (f"GPU stage {gpu_stage_ms:.1f} ms of kernels per pair ({gpu_rate:.2f} pairs/s; {gpu_rate_wall:.2f} pairs/s by the feeding "
                            f"thread's wall clock); host LP {acc['lp_s'] / k:.2f} s per solve x {max(1, workers)} worker processes = {lp_rate:.2f} solves/s on "
-                           f"this host ({os.cpu_count()} logical CPUs, shared by every rank of the node)")
+                           f"this rank's share of the host ({os.cpu_count()} logical CPUs, {world} rank(s): the host's LP capacity does not grow with the GPU count)")
       # HBM traffic of the dominant kernel from the committed PMC profile of this workload (PMC
       # collection needs its own rocprofv3 passes; bench.py itself only times with HIP events)
       for prof_name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):

@@ -12,20 +12,17 @@
 // "predecessor's f plus q", one IEEE double addition, so the sums -- and therefore every
 // comparison and tie -- are bit-identical to the reference's whatever the evaluation order.
 //
-// The recurrence is sequential over audio rows.  One persistent wavefront per pair walks the
-// rows; the points of a row (sorted by v, typically 10-40) sit one per lane:
-//   * prefix maximum over the video ranks <= r from a Fenwick tree whose nodes are 16-byte
-//     (sum, id) records: the levels with span >= 2^S live in LDS, the S lowest levels in global
-//     memory (L2 resident); the <= S + 16 node addresses of a query depend on r alone, so all
-//     loads of a row -- queries AND the nodes the row will update -- are issued before any is used;
-//   * points of the same row may chain (v' < v): f[k] = q[k] + max(g[k], f[k-1]).  Since q > 0 the
-//     f of a row increase with the lane, so "best earlier point of the row" is the left neighbour:
-//     a Jacobi sweep with one DPP wave shift per step, exact in-order double additions;
-//   * tree update without atomics: a lane walks its update path only up to the first node that
-//     also covers the next lane's rank -- from there on the next lane's larger f wins anyway --
-//     so the node sets written by the lanes of one step are disjoint.
-// Many pairs run concurrently (one workgroup each, own stream) beside the similarity GEMM of
-// later pairs; nothing of the match list ever goes to the host, only the path does.
+// The recurrence is sequential over audio rows.  Two implementations:
+//   * k_chain_columns (the default, further down): the video ranks cut into columns, one wavefront per
+//     column with its Fenwick tree in LDS, the columns a pipeline over the rows -- the whole chip works
+//     on one pair's DP (2 h pair: 72 ms);
+//   * k_chain_forward / k_chain_forward_w4 (rounds 1-2, DALIGN_CHAIN_KERNEL=rows): ONE persistent
+//     workgroup per pair walks the rows, the points of a row one per lane, prefix maxima from a Fenwick
+//     tree split between LDS (levels with span >= 2^S) and global memory (the S lowest levels, L2
+//     resident), in-row chaining by Jacobi sweeps over a DPP wave shift, tree updates without atomics
+//     (a lane walks its update path only up to the first node that also covers the next lane's rank).
+//     1.75 s per 2 h pair; kept as an independent cross-check of the column pipeline in the GPU tests.
+// Nothing of the match list ever goes to the host, only the path does.
 #include "dalign_common.h"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
@@ -612,10 +609,9 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
   const bool has_right = C + 1 < a.n_cols;
   double Mf = 0.0; uint32_t Mid = 0u;               // running maximum over this column's matches (uniform)
   uint32_t last_id = 0u;                            // id of the record of the batch's last row (lane 63)
-  const unsigned long long t_start = wall_clock64();
 #ifdef DA_CHAIN_STAMPS
   unsigned long long cst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long cst_t = t_start;
+  unsigned long long cst_t = wall_clock64();
 #endif
 
   // the window at `cursor`, prefetched: one match per lane
@@ -648,12 +644,13 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
     // ---- the records of this batch's rows from the left neighbour: wait until every granule carries the tag
     if (C > 0) {
       unsigned spins = 0;
+      const unsigned long long t_wait = wall_clock64();
       while (!complete(tag)) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 255u) == 0u) {
           const uint32_t ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           if (ab != 0u) return;
-          if (wall_clock64() - t_start > a.spin_limit) {
+          if (wall_clock64() - t_wait > a.spin_limit) {
             if (lane == 0) __hip_atomic_store(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
           }

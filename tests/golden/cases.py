@@ -55,6 +55,10 @@ ALIGN_CASES = {
   "e600":   dict(seed=3, video_seconds=600.0, n_jumps=5, first_gap=60.0),
   "rate2":  dict(seed=4, video_seconds=300.0, jumps=([0.0], [20.0]), rate_change=0.02),
   "e1320":  dict(seed=5, video_seconds=1320.0, n_jumps=10, first_gap=200.0),
+  # BASELINE configs at their stated sizes, recorded from the reference itself (436 s and ~40 min of
+  # reference time, > 10 GB of Python objects for the 2 h pair): the fixtures hold nodes / similarity / slope only
+  "e3600":  dict(seed=6, video_seconds=3600.0, n_jumps=10, first_gap=200.0),
+  "e7200s": dict(seed=5, video_seconds=7200.0, n_jumps=10, first_gap=200.0, channels=2),   # = bench.py's configs[2] pair (rank 0)
 }
 
 

@@ -12,4 +12,7 @@ c.pcm_upload(0, pair.video); c.pcm_upload(1, pair.audio)
 vf = c.features_resident(0); af = c.features_resident(1)
 for _ in range(2):
   c.match(vf, af)
+if len(sys.argv) > 4 and sys.argv[4] == "chain":            # also the stage-2 chain DP on the resident matches
+  c.match_begin(vf, af); c.match_finish()
+  c.chain_resident()
 print(c.stats())
