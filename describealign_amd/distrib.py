@@ -109,6 +109,14 @@ class Group:
     if on_gpu:
       torch.cuda.synchronize(dev)
       ctx.match_import_device(all_k.data_ptr(), all_q.data_ptr(), total)
+    elif hasattr(ctx, "match_import_device") and isinstance(getattr(ctx, "device", None), int) and torch.cuda.is_available():
+      # gloo between processes that do have GPUs (tests, one-GPU emulation of a node): the gathered list goes
+      # up in one copy and is imported device-to-device like the RCCL path's -- no per-match host work
+      gdev = torch.device("cuda", ctx.device)
+      dk = all_k.to(gdev); dq = all_q.to(gdev)
+      torch.cuda.synchronize(gdev)
+      ctx.match_import_device(dk.data_ptr(), dq.data_ptr(), total)
+      del dk, dq
     else:
       k = all_k.numpy()
       # host lists: hand them to the context through a device upload of its own
