@@ -701,6 +701,7 @@ class AlignPipeline:
         self._old_affinity = None
     self.gpu_threads = [cf.ThreadPoolExecutor(max_workers=1) for _ in self.gpu_ctxs]
     self.refine_pool = cf.ThreadPoolExecutor(max_workers=max(1, int(refine_threads)))
+    self.handoff_pool = cf.ThreadPoolExecutor(max_workers=2)      # copies path + feature rows into the workers' /dev/shm blocks
     self._local = threading.local()
     self._ctxs = []
     self._lock = threading.Lock()
@@ -750,6 +751,7 @@ class AlignPipeline:
     for g in self.gpu_threads:
       g.shutdown(wait=True, cancel_futures=True)
     self.pool.shutdown(wait=True, cancel_futures=True)
+    self.handoff_pool.shutdown(wait=True, cancel_futures=False)
     self.refine_pool.shutdown(wait=True, cancel_futures=True)
     for c in self._ctxs:
       c.close()
@@ -825,11 +827,23 @@ class AlignPipeline:
       self._collect_chains(ctx, block_above=len(self._chains[id(ctx)]) - 1)
 
   def _hand_off(self, ctx, ticket, vf, af, tm, fname, done, t_begin):
+    """Collect a finished chain DP (on the thread that owns the context) and pass the pair on; the copy into
+    the workers' shared-memory block (10-70 MB: path + ten feature rows) and the submission run on a helper
+    thread, so the GPU-feeding thread goes straight back to the next pair's kernels."""
     try:
       dims = (len(vf[0]), len(vf[1]), len(af[0]), len(af[1]))
       px, py = ctx.chain_finish(ticket, min_len=min_path_length(dims[0], dims[2]))      # raises the mismatch error (:698)
       tm["device"]["chain_ms"] = ctx.stats()["chain_ms"]
       tm["chain_s"] = time.perf_counter() - t_begin          # enqueue -> collected (includes waiting in the queue)
+    except BaseException as e:
+      with self._lock:
+        self._n_done += 1
+      done.set_exception(e)
+      return
+    self.handoff_pool.submit(self._hand_off_copy, px, py, vf, af, dims, tm, fname, done)
+
+  def _hand_off_copy(self, px, py, vf, af, dims, tm, fname, done):
+    try:
       n = len(px)
       state = {}
       lay, size = _block_layout(n, *dims)

@@ -822,12 +822,23 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
   const int64_t n = sl.n;
   const size_t nn = (size_t)std::max<int64_t>(1, n);
   HIP_TRY(c, sl.rank.ensure(sizeof(int32_t) * nn)); HIP_TRY(c, sl.flags.ensure(nn));
-  HIP_TRY(c, sl.rows.ensure(sizeof(int32_t) * (nn + 1))); HIP_TRY(c, sl.pred.ensure(sizeof(int32_t) * nn));
+  // Which kernel: the column pipeline (default), or ONE workgroup of one / four wavefronts walking the rows
+  // (DALIGN_CHAIN_KERNEL=rows, then DALIGN_CHAIN_WAVES=1|4: the round-2 kernels, kept as a cross-check).
+  {
+    const char* kern = std::getenv("DALIGN_CHAIN_KERNEL");
+    const char* force = std::getenv("DALIGN_CHAIN_WAVES");
+    sl.mode = 0;
+    if (kern && std::strcmp(kern, "rows") == 0) sl.mode = force ? (std::atoi(force) >= 4 ? 4 : 1) : (n >= 4096 ? 4 : 1);
+  }
+  HIP_TRY(c, sl.pred.ensure(sizeof(int32_t) * nn));
   HIP_TRY(c, sl.ids.ensure(sizeof(int32_t) * nn)); HIP_TRY(c, sl.out_iv.ensure(sizeof(int32_t) * 2 * nn));
-  HIP_TRY(c, sl.tree.ensure(16 * ((size_t)sl.n_ranks + 2 + 256)));       // rows kernels: + one scrap record per thread
   HIP_TRY(c, sl.small.ensure(128));
-  const size_t tb = da::chain_rows_temp_bytes(n);
-  HIP_TRY(c, sl.temp.ensure(tb + 256));
+  const size_t tb = sl.mode == 0 ? 0 : da::chain_rows_temp_bytes(n);
+  if (sl.mode != 0) {                                                       // the one-workgroup kernels' row starts and tree
+    HIP_TRY(c, sl.rows.ensure(sizeof(int32_t) * (nn + 1)));
+    HIP_TRY(c, sl.tree.ensure(16 * ((size_t)sl.n_ranks + 2 + 256)));       // + one scrap record per thread
+    HIP_TRY(c, sl.temp.ensure(tb + 256));
+  }
   hipStream_t st = sl.stream;
   // `small`: int32 [0] rows, [1] err; int64 [1] best id, [2] path length
   ChainLaunch L{};
@@ -847,15 +858,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     L.rankmap = c->rankmap.as<int32_t>(); L.rankmap_len = c->res_lv;
   }
   HIP_TRY(c, hipMemsetAsync(sl.small.p, 0, 128, c->stream));
-  // Which kernel: the column pipeline (default), or ONE workgroup of one / four wavefronts walking the rows
-  // (DALIGN_CHAIN_KERNEL=rows, then DALIGN_CHAIN_WAVES=1|4: the round-2 kernels, kept as a cross-check).
-  {
-    const char* kern = std::getenv("DALIGN_CHAIN_KERNEL");
-    const char* force = std::getenv("DALIGN_CHAIN_WAVES");
-    sl.mode = 0;
-    if (kern && std::strcmp(kern, "rows") == 0) sl.mode = force ? (std::atoi(force) >= 4 ? 4 : 1) : (n >= 4096 ? 4 : 1);
-    L.wide = sl.mode == 4;
-  }
+  L.wide = sl.mode == 4;
   da::ChainColumns K{};
   if (sl.mode == 0 && n > 0) {
     const int64_t rows_bound = std::min<int64_t>(n, sl.rows_hint > 0 ? sl.rows_hint : n);

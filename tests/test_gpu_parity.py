@@ -813,3 +813,6 @@ def test_bench_launch_contract_two_ranks(tmp_path):
     assert key in d, key
   assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
   assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+  # the line says what bounds it and what the untimed lead-in really was
+  assert d["bound"] in ("host_lp", "gpu") and d["lead_in_pairs_actual"] >= d["warmup"] and d["whole_stream_value"] > 0
+  assert d["lp_solves_per_s_host"] == pytest.approx(2 * d["lp_solves_per_s_rank"], rel=1e-3) and d["gpu_stage_pairs_per_s"] > 0
