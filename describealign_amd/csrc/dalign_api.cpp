@@ -894,7 +894,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     L.temp = sl.temp.p;
     c->st.chain_columns = (double)K.n_cols; c->st.chain_column_width = (double)K.width;
   } else {
-    HIP_TRY(c, hipMemsetAsync(sl.tree.p, 0, 16 * ((size_t)sl.n_ranks + 2), c->stream));
+    if (sl.mode != 0) HIP_TRY(c, hipMemsetAsync(sl.tree.p, 0, 16 * ((size_t)sl.n_ranks + 2), c->stream));
     c->st.chain_columns = 0; c->st.chain_column_width = 0;
   }
   if (da::launch_chain_prep(L, c->stream, sl.mode == 0) != 0) return fail(c, DA_ERR_ARG, "da_chain: %lld matches / %lld video rows exceed the kernel's range", (long long)n, (long long)sl.n_ranks);
