@@ -274,7 +274,10 @@ class Bench:
         "roofline": {"bound": "mfma", "kernel": "k_match_" + prec_name, "achieved": gemm_tf, "peak": peak, "unit": "TFLOP/s",
                      "frac": gemm_tf / peak, "traffic": None,
                      "avg_launch_ms": acc["gemm_ms"] / k, "flops_per_launch": acc["gemm_flops"] / k,
-                     "algorithmic": "246 flop x (non-quiet audio frames) x (every 4th non-quiet video frame)"},
+                     "algorithmic": "246 flop x (non-quiet audio frames) x (every 4th non-quiet video frame)",
+                     "note": "avg_launch_ms = HIP events around the GEMM launches of the TIMED pairs; a rocprofv3 --stats average of the same command "
+                             "covers every launch of the run, lead-in included (those pairs are admitted at the GPU's own rate, with the previous pair's "
+                             "chain DP, verify and sort beside every GEMM: ~8 % longer) -- profiles/r03_bench_cfg2_bf16_gemm_by_region.json splits the trace"},
         "feature_stage": {"bound": "hbm", "achieved": acc["feat_bytes"] / (acc["feat_ms"] * 1e-3) / 1e9 if acc.get("feat_ms") else 0.0,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_step": acc["feat_bytes"] / k,
                           "ms_per_step": acc["feat_ms"] / k},
