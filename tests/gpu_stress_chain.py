@@ -1,0 +1,57 @@
+"""GPU-box script (not a pytest): the column chain DP vs the host utility on random instances for a time budget
+(default 300 s): 10 .. 2e6 matches, 1 .. 5e4 rows, 1 .. 3e5 video frames, qualities from small sets (ties abound)
+or uniform, the DP's own column count or 1 .. 4096 forced, every second instance while another context keeps the
+chip busy with f32 GEMMs.      python tests/gpu_stress_chain.py [seconds]
+Round 3: 58 092 instances, 3.8e9 matches, 0 mismatches in 600 s."""
+import os, sys, threading, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from describealign_amd import _native, synth
+
+def inst(rng, n, rows, cols, step, quals):
+  i = np.sort(rng.integers(0, rows, n)); v = rng.integers(0, cols, n) * step
+  keys = np.unique(i.astype(np.int64) * (1 << 32) + v)
+  i, v = (keys >> 32).astype(np.int32), (keys & 0xffffffff).astype(np.int32)
+  q = rng.choice(np.asarray(quals), len(i)) if quals is not None else rng.uniform(1e-3, 50, len(i))
+  return i, v, np.ascontiguousarray(q, dtype=np.float64)
+
+def main():
+  budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+  ctx = _native.Context(0, _native.PREC_F32)
+  load = _native.Context(0, _native.PREC_F32)
+  pair = synth.make_pair(23, 400.0, n_jumps=3, first_gap=40.0)
+  lvf = load.features(pair.video, 0); laf = load.features(pair.audio, 1)
+  stop = threading.Event(); busy = threading.Event()
+  def hammer():
+    while not stop.is_set():
+      if busy.is_set():
+        load.match_begin(lvf, laf); load.match_finish()
+      else:
+        time.sleep(0.01)
+  th = threading.Thread(target=hammer); th.start()
+  rng = np.random.default_rng(2026)
+  t0 = time.time(); done = 0; bad = 0; tot = 0
+  try:
+    while time.time() - t0 < budget:
+      n = int(10 ** rng.uniform(1, 6.3)); rows = int(10 ** rng.uniform(0, 4.7)); cols = int(10 ** rng.uniform(0, 5.5))
+      step = int(rng.choice([1, 4])); quals = [None, (50.0,), (50.0, 50.0, 12.5, 3.25, 0.75), (1.0, 2.0)][int(rng.integers(4))]
+      i, v, q = inst(rng, n, rows, cols, step, quals)
+      ncol = [None, "1", "2", "3", "17", "128", "999", "4096"][int(rng.integers(8))]
+      if ncol: os.environ["DALIGN_CHAIN_COLS"] = ncol
+      else: os.environ.pop("DALIGN_CHAIN_COLS", None)
+      (busy.set if done % 2 else busy.clear)()
+      wi, wv = _native.chain_host(i, v, q)
+      gi, gv = ctx.chain(i, v, q)
+      ok = len(gi) == len(wi) and np.array_equal(gi, wi) and np.array_equal(gv, wv)
+      done += 1; tot += len(i)
+      if not ok:
+        bad += 1
+        print("MISMATCH", len(i), rows, cols, step, quals, ncol, flush=True)
+  finally:
+    stop.set(); th.join(); load.close(); ctx.close()
+  print(f"instances {done}, matches {tot}, mismatches {bad}, {time.time() - t0:.0f} s", flush=True)
+  return 1 if bad else 0
+
+if __name__ == "__main__":
+  sys.exit(main())
