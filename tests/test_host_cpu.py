@@ -303,6 +303,9 @@ m = g.max_over_ranks(10.0 + g.rank)
 s = g.sum_over_ranks(float(len(mine)))
 assert m == 10.0 + g.world - 1, m
 assert s == 5.0, s
+# one failing rank must be seen by every rank (align_tiled aborts the gather everywhere instead of deadlocking)
+assert g.all_ok(True) is True
+assert g.all_ok(g.rank != g.world - 1) is False
 # the one exchange step of the tiled single-pair mode: ragged per-rank match lists gathered on rank 0
 import numpy as np
 n = 3 + 4 * g.rank
