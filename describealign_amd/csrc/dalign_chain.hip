@@ -839,12 +839,13 @@ ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint
   // the one column the diagonal is crossing -- are a serial chain that no column count shortens.
   // Measured (MI355X): 2 h pair, 7.2e7 matches: 64 columns 156 ms, 128: 97, 256: 74, 512: 72, 1024: 93;
   // 22 min pair, 3.1e6 matches: 32: 15.5, 64: 11.1, 128: 9.6, 256: 10.9, 512: 14.2.  About 25 k matches
-  // per column, at most 384 columns; a column is at least 64 ranks wide and must fit LDS.
+  // per column, at most 384 columns (1 024 beyond 3e8 matches: 8 h pair, 1.12e9 matches, 384 columns 950 ms,
+  // 1 024: 850 ms); a column is at least 64 ranks wide and must fit LDS.
   (void)rows_hint;
   if (n_ranks < 1) n_ranks = 1;
   int64_t nc = n / 24576;
   if (const char* e = std::getenv("DALIGN_CHAIN_COLS")) nc = std::atoll(e);
-  else nc = std::min<int64_t>(nc, 384);
+  else nc = std::min<int64_t>(nc, n >= 300000000LL ? 1024 : 384);
   nc = std::min<int64_t>(nc, (n_ranks + 63) / 64);
   nc = std::max<int64_t>(nc, (n_ranks + kColMaxWidth - 1) / kColMaxWidth);
   nc = std::max<int64_t>(1, std::min<int64_t>(nc, kColMaxCols));
