@@ -146,18 +146,42 @@ def _mux_command(ffmpeg, video_file, audio_desc_file, output_filename, setts_cmd
           output_filename, "-y"]
 
 
-def _replaced_media_command(ffmpeg, output_filename, video_file):
+def parse_first_audio_track_is_ad(ffprobe_json) -> bool:
+  """What is_first_video_track_ad (:460-462) reads out of `ffprobe -show_streams -select_streams a -of json`:
+  the first audio stream's `descriptions` or `visual_impaired` disposition."""
+  import json
+  streams = json.loads(ffprobe_json).get("streams", [])
+  if not streams:
+    return False
+  disp = streams[0].get("disposition", {})
+  return bool(disp.get("descriptions") or disp.get("visual_impaired"))
+
+
+def is_first_video_track_ad(video_file, ffprobe=None) -> bool:
+  """describealign.is_first_video_track_ad (:460-462) through the ffprobe binary directly."""
+  ffprobe = ffprobe or media.find_ffprobe()
+  if ffprobe is None:
+    raise RuntimeError("no ffprobe binary on PATH")
+  res = subprocess.run([ffprobe, "-show_format", "-show_streams", "-of", "json", "-select_streams", "a", video_file], capture_output=True)
+  if res.returncode != 0:
+    raise RuntimeError("ffprobe error: " + res.stderr.decode("utf-8", "replace"))
+  return parse_first_audio_track_is_ad(res.stdout.decode("utf-8", "replace"))
+
+
+def _replaced_media_command(ffmpeg, output_filename, video_file, first_track_is_ad=False):
   """ffmpeg argv for the --stretch_audio output (same options as :468-487): the new stereo track is
   piped in as s16le and either stored on its own (audio-only input) or muxed in front of the
-  original streams."""
+  original streams.  The video's own first audio track becomes "original" unless it already is an
+  audio description (the output of a previous run, :478-480)."""
   head = [ffmpeg, "-f", "s16le", "-acodec", "pcm_s16le", "-ac", "2", "-ar", str(media.AUDIO_SAMPLE_RATE), "-i", "pipe:"]
   if video_file is None:
     return head + ["-loglevel", "error", output_filename, "-y"]
+  second = (["-disposition:a:1", "visual_impaired+descriptions"] if first_track_is_ad else
+            ["-disposition:a:1", "original", "-metadata:s:a:1", "title=original"])
   return head + ["-dn", "-i", video_file, "-map", "0", "-map", "1",
                  "-acodec", "copy", "-vcodec", "copy", "-scodec", "copy", "-max_interleave_delta", "0",
                  "-loglevel", "error", "-c:a:0", "aac", "-disposition:a:0", "default+visual_impaired+descriptions",
-                 "-metadata:s:a:0", "title=AD", "-disposition:a:1", "original", "-metadata:s:a:1", "title=original",
-                 output_filename, "-y"]
+                 "-metadata:s:a:0", "title=AD"] + second + [output_filename, "-y"]
 
 
 def _write_replaced_media(ffmpeg, output_filename, frames, video_file):
@@ -169,7 +193,13 @@ def _write_replaced_media(ffmpeg, output_filename, frames, video_file):
     wav = os.path.splitext(output_filename)[0] + ".wav"
     media.write_wav(wav, np.ascontiguousarray(frames.T))
     return f"(no ffmpeg binary on PATH; replaced audio track written to {wav})"
-  argv = _replaced_media_command(ffmpeg, output_filename, video_file)
+  first_is_ad = False
+  if video_file is not None:
+    try:
+      first_is_ad = is_first_video_track_ad(video_file)
+    except (RuntimeError, OSError, ValueError, KeyError) as e:
+      print(f"  WARNING: could not probe the video's first audio track ({e}); labelling it \"original\"")
+  argv = _replaced_media_command(ffmpeg, output_filename, video_file, first_is_ad)
   res = subprocess.run(argv, input=np.ascontiguousarray(frames).tobytes(), capture_output=True)
   if res.returncode != 0 or len(res.stderr) > 0:
     print("  ERROR: ffmpeg failed to write output file: " + output_filename)

@@ -426,6 +426,14 @@ def test_stretch_audio_command_lines_follow_the_reference_options():
                  "-c:a:0 aac", "-disposition:a:0 default+visual_impaired+descriptions", "-metadata:s:a:0 title=AD",
                  "-disposition:a:1 original", "-metadata:s:a:1 title=original", "out/ad_show.mkv -y"):
     assert needle in joined, needle
+  # a video whose first audio track already is an audio description (output of a previous run, :478-480)
+  again = combine._replaced_media_command("ffmpeg", "out/ad_show.mkv", "show.mkv", first_track_is_ad=True)
+  k = again.index("-disposition:a:1")
+  assert again[k + 1] == "visual_impaired+descriptions" and "title=original" not in again
+  probe = '{"streams": [{"index": 1, "codec_type": "audio", "disposition": {"default": 1, "descriptions": 1, "visual_impaired": 0}}, {"index": 2}]}'
+  assert combine.parse_first_audio_track_is_ad(probe) is True
+  assert combine.parse_first_audio_track_is_ad('{"streams": [{"disposition": {"descriptions": 0, "visual_impaired": 0}}]}') is False
+  assert combine.parse_first_audio_track_is_ad('{"streams": []}') is False
   audio_only = combine._replaced_media_command("ffmpeg", "out/ad_show.wav", None)
   assert audio_only[-2:] == ["out/ad_show.wav", "-y"] and "-vcodec" not in audio_only
 
