@@ -10,9 +10,9 @@ worker process per GPU (`--gpus`).
 
 --stretch_audio (replace_aligned_segments, :230-416, and the loudness / peak handling around it,
 :1135-1153) runs on the GPU as well: the PCM uploaded for the feature kernels stays resident and
-only the finished int16 track is copied back.  The key-frame probe of the default mux (:443-458) goes
-through the ffprobe binary next to ffmpeg.  Out of scope: the GUI, the ffprobe-based "is the first
-track already AD" check (:460-462; the original track is always titled "original").
+only the finished int16 track is copied back.  The key-frame probe of the default mux (:443-458) and the
+"is the first audio track already an audio description" probe of the --stretch_audio mux (:460-462) go
+through the ffprobe binary next to ffmpeg.  Out of scope: the GUI.
 """
 from __future__ import annotations
 
