@@ -295,6 +295,22 @@ def test_chain_resident_equals_chain_of_fetched_matches(ctx, native):
     ctx.chain_finish(tickets[0])
 
 
+def test_chain_begin_refuses_the_next_pairs_row_list(ctx):
+  """da_chain_begin ranks the resident matches with the video row list of the match that produced them; the
+  next da_match_begin overwrites that list.  Calling chain_begin for pair k after match_begin of pair k+1 used to
+  pair k's matches with k+1's rows; now it is a state error, and the documented order keeps working."""
+  p1, p2 = cases.align_case("a40"), cases.align_case("e180")
+  vf1 = ctx.features(p1.video, 0); af1 = ctx.features(p1.audio, 1)
+  ctx.match_begin(vf1, af1); ctx.match_finish()
+  vf2 = ctx.features(p2.video, 0); af2 = ctx.features(p2.audio, 1)
+  ctx.match_begin(vf2, af2)                                  # pair 2's row lists replace pair 1's
+  with pytest.raises(RuntimeError, match="da_match_begin has been called since"):
+    ctx.chain_begin()
+  ctx.match_finish()
+  gi, gv = ctx.chain_resident()                              # pair 2 in the documented order: fine
+  assert len(gi) > 1000
+
+
 def test_chain_rejects_nonpositive_quality(ctx):
   i = np.arange(10, dtype=np.int32); v = np.arange(10, dtype=np.int32); q = np.ones(10); q[4] = 0.0
   with pytest.raises(RuntimeError, match="positive"):
