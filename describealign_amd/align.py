@@ -750,8 +750,9 @@ class AlignPipeline:
       self._old_affinity = None
     for g in self.gpu_threads:
       g.shutdown(wait=True, cancel_futures=True)
+    # the hand-off threads submit to self.pool: let them finish (or fail) before the workers go away
+    self.handoff_pool.shutdown(wait=True, cancel_futures=True)
     self.pool.shutdown(wait=True, cancel_futures=True)
-    self.handoff_pool.shutdown(wait=True, cancel_futures=False)
     self.refine_pool.shutdown(wait=True, cancel_futures=True)
     for c in self._ctxs:
       c.close()

@@ -43,7 +43,7 @@ struct Side {
   DevBuf feat; int64_t feat_stride = 0; int64_t len[2] = {0, 0};
   // match-prep buffers
   DevBuf mfeat;                  // 5 rows uploaded by da_match
-  DevBuf ms[5], nrm[5], dig[5], flg[5], ms32[3], inv32[3], nrm32[3], nrmpk[3], prod32, bfe[3], bfo[3];
+  DevBuf ms[5], nrm[5], dig[5], flg[5], ms32[3], inv32[3], nrm32[3], prod32;
   int64_t mlen[5] = {0, 0, 0, 0, 0}; int64_t lmax = 0;
   const float* prep_feat = nullptr;   // device rows the last preparation read (resident rows or the uploaded copy)
 };
@@ -91,7 +91,7 @@ struct da_ctx {
   std::string err;
   Side side[2];
   DevBuf tables, hann41;
-  DevBuf vlist, alist, surv, counters, keys0, q0, sort_tmp, rankmap, rowscratch, bfv;
+  DevBuf vlist, alist, surv, counters, keys0, q0, sort_tmp, rankmap, rowscratch, bfv, bfa;
   std::vector<ChainSlot*> slots;  // sorted match lists live in slots (see ChainSlot)
   int res_slot = -1;              // slot holding the results of the last finished match
   unsigned long long next_ticket = 1;
@@ -229,10 +229,10 @@ void da_destroy(da_ctx* c) {
     if (s.up1) (void)hipEventDestroy(s.up1);
     s.pcm.release(); s.feat.release(); s.mfeat.release();
     for (int j = 0; j < 5; ++j) { s.ms[j].release(); s.nrm[j].release(); s.dig[j].release(); s.flg[j].release(); }
-    for (int j = 0; j < 3; ++j) { s.ms32[j].release(); s.inv32[j].release(); s.nrm32[j].release(); s.nrmpk[j].release(); s.bfe[j].release(); s.bfo[j].release(); }
+    for (int j = 0; j < 3; ++j) { s.ms32[j].release(); s.inv32[j].release(); s.nrm32[j].release(); }
     s.prod32.release();
   }
-  DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->bfv, &c->counters, &c->keys0,
+  DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->bfv, &c->bfa, &c->counters, &c->keys0,
                    &c->q0, &c->sort_tmp, &c->rankmap, &c->rowscratch, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
                    &c->band_y, &c->band_q, &c->band_part, &c->band_tab, &c->band_cl, &c->band_keys, &c->band_ids, &c->band_head,
                    &c->band_out, &c->band_tmp};
@@ -395,9 +395,6 @@ int upload_and_prep(da_ctx* c, Side& s, const float* feat, int64_t stride, const
     HIP_TRY(c, s.ms32[j].ensure(sizeof(float) * n)); p.ms32[j] = s.ms32[j].as<float>();
     HIP_TRY(c, s.inv32[j].ensure(sizeof(float) * n)); p.inv32[j] = s.inv32[j].as<float>();
     HIP_TRY(c, s.nrm32[j].ensure(sizeof(float) * n)); p.nrm32[j] = s.nrm32[j].as<float>();
-    HIP_TRY(c, s.nrmpk[j].ensure(sizeof(uint32_t) * n)); p.nrmpk[j] = s.nrmpk[j].as<uint32_t>();
-    HIP_TRY(c, s.bfe[j].ensure(sizeof(uint16_t) * n + 64)); p.bf_even[j] = s.bfe[j].as<uint16_t>();
-    HIP_TRY(c, s.bfo[j].ensure(sizeof(uint16_t) * n + 64)); p.bf_odd[j] = s.bfo[j].as<uint16_t>();
   }
   HIP_TRY(c, s.prod32.ensure(sizeof(float) * n)); p.prod32 = s.prod32.as<float>();
   launch_prep(p, c->hann41.as<double>(), c->stream);
@@ -410,10 +407,13 @@ int upload_and_prep(da_ctx* c, Side& s, const float* feat, int64_t stride, const
 static int launch_gemm(da_ctx* c, MatchArgs& m, size_t cap) {
   HIP_TRY(c, c->surv.ensure(sizeof(unsigned long long) * cap));
   m.out = c->surv.as<unsigned long long>(); m.capacity = cap;
-  if (c->precision != DA_PREC_F32) {            // the video operand in MFMA fragment order: 9 KiB per 32 rows, whole row groups
-    m.bfv_tiles = (((m.n_v + 31) / 32 + da::kBfVideoTileGroup - 1) / da::kBfVideoTileGroup) * da::kBfVideoTileGroup;
+  if (c->precision != DA_PREC_F32) {            // both operands in MFMA fragment order: 9 KiB per 32 rows / columns
+    m.bfv_tiles = (((m.n_v + 31) / 32 + da::kBfVideoTileGroup - 1) / da::kBfVideoTileGroup) * da::kBfVideoTileGroup;   // whole row groups
     HIP_TRY(c, c->bfv.ensure((size_t)m.bfv_tiles * 9 * 1024));
     m.bfv_frag = c->bfv.p;
+    m.bfa_tiles = (m.n_a + 31) / 32 + da::kBfAudioTilePad;
+    HIP_TRY(c, c->bfa.ensure((size_t)m.bfa_tiles * 9 * 1024));
+    m.bfa_frag = c->bfa.p;
   }
   HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
   HIP_TRY(c, hipEventRecord(c->gemm_e0, c->stream));
@@ -477,9 +477,9 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
   for (int j = 0; j < 3; ++j) {
     m.ms_v[j] = V.ms32[j].as<float>(); m.ms_a[j] = A.ms32[j].as<float>();
     m.inv_v[j] = V.inv32[j].as<float>(); m.inv_a[j] = A.inv32[j].as<float>();
-    m.nrm_a[j] = A.nrm32[j].as<float>(); m.nrmpk_a[j] = A.nrmpk[j].as<uint32_t>();
-    m.bfa_even[j] = A.bfe[j].as<uint16_t>(); m.bfa_odd[j] = A.bfo[j].as<uint16_t>();
-    m.msd_v[j] = V.ms[j].as<double>();
+    m.nrm_a[j] = A.nrm32[j].as<float>();
+    m.msd_v[j] = V.ms[j].as<double>(); m.msd_a[j] = A.ms[j].as<double>();
+    m.nrmd_v[j] = V.nrm[j].as<double>(); m.nrmd_a[j] = A.nrm[j].as<double>();
   }
   m.prod_a = A.prod32.as<float>();
   m.vlist = c->vlist.as<int32_t>(); m.n_v = n_v;
@@ -490,7 +490,9 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
   // accumulators never exceed the exact values), so the same 1.001 covers the f32 epilogue arithmetic;
   // everything is re-verified in float64 afterwards.
   m.thr = (float)(thr_exact * 1.001);
-  if (const char* dbg = std::getenv("DALIGN_DEBUG_THR_SCALE")) m.thr *= (float)std::atof(dbg);   // profiling only
+  double thr_bf16 = thr_exact * 1.001;
+  if (const char* dbg = std::getenv("DALIGN_DEBUG_THR_SCALE")) { m.thr *= (float)std::atof(dbg); thr_bf16 *= std::atof(dbg); }   // profiling only
+  da::bf16_gemm_scales(thr_bf16, m.cscale);      // bf16: the threshold lives in the operand scales (dalign_match.hip)
   // audio chunking: enough blocks to fill the chip several times over
   {
     const int64_t vblocks = ((n_v + 31) / 32 + 3) / 4;
@@ -553,6 +555,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
       v.dig_v[j] = V.dig[j].as<uint32_t>(); v.flg_v[j] = V.flg[j].as<uint32_t>(); v.dig_a[j] = A.dig[j].as<uint32_t>();
     }
     v.mode = mode;
+    if (c->precision != DA_PREC_F32) { v.alist = c->alist.as<int32_t>(); v.n_a = c->last_match.n_a; }
     v.vlist = c->vlist.as<int32_t>(); v.n_v = n_v; v.n_pairs = d_cnt + 2;
     v.n_out = d_cnt + 1;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -699,7 +702,7 @@ extern "C" int da_trim(da_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-  for (DevBuf* b : {&c->surv, &c->bfv, &c->q0, &c->sort_tmp, &c->rowscratch, &c->rankmap, &c->band_y, &c->band_q, &c->band_part, &c->band_cl,
+  for (DevBuf* b : {&c->surv, &c->bfv, &c->bfa, &c->q0, &c->sort_tmp, &c->rowscratch, &c->rankmap, &c->band_y, &c->band_q, &c->band_part, &c->band_cl,
                     &c->band_keys, &c->band_ids, &c->band_head, &c->band_out, &c->band_tmp, &c->pair_i, &c->pair_v, &c->pair_c})
     b->release();
   // keys0 holds the unpacked (i, v) of the resident matches for da_match_fetch: shrink it to what they need
@@ -919,6 +922,9 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
 int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
   HIP_TRY(c, hipStreamSynchronize(sl.stream));
   float ms = 0.f; (void)hipEventElapsedTime(&ms, sl.e0, sl.e1); c->st.chain_ms = ms;
+  // the per-(column, row) hand-over records are the DP's largest buffer (2 h pair: 2.6 GB, 8 h pair at 1 024 columns: 28 GB):
+  // a long pair's copy is given back at once instead of sitting in the slot until da_trim (up to 16 slots per context)
+  if (sl.msg.cap > ((size_t)6 << 30)) { sl.msg.release(); sl.launches = 0; }
   if (std::getenv("DALIGN_DEBUG_STAMPS") && sl.mode == 0 && sl.n > 0) {   // diagnostic builds (-DDA_CHAIN_STAMPS) only
     const int nc = (int)c->st.chain_columns;
     std::vector<unsigned long long> st((size_t)nc * 8);

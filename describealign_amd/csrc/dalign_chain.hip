@@ -78,11 +78,14 @@ __global__ __launch_bounds__(256) void k_chain_prep(const unsigned long long* __
   if (rankmap) {
     int32_t r = 0;
     if ((int64_t)v < rankmap_len) r = rankmap[v];
-    if (r <= 0) atomicOr(err, 4);                       // video frame is not one of the matched rows
+    if (r <= 0) { atomicOr(err, 4); r = 1; }            // video frame is not one of the matched rows: reported by the host; rank 1 keeps every later kernel inside its arrays
     rank[k] = r;
   }
-  const double qq = q[k];
-  if (!(qq > 0.0) || !(qq < 1e300)) atomicOr(err, 1);   // the reference's qualities are in (0, 50] (:672)
+  // the reference's qualities are in (0, 50] (:672).  Tested on the bit pattern: this file is compiled with
+  // -ffinite-math-only, under which a floating-point comparison need not reject a NaN -- and a NaN pattern would win every
+  // ds_max_u64 of the column kernel.  0 < q < 1e300  <=>  0 < bits < bits(1e300), read as a signed integer.
+  const long long qbits = __double_as_longlong(q[k]);
+  if (!(qbits > 0 && qbits < 0x7E37E43C8800759CLL)) atomicOr(err, 1);
 }
 
 __global__ __launch_bounds__(256) void k_rankmap(const int32_t* __restrict__ vlist, int64_t n_v, int32_t* __restrict__ rankmap) {
@@ -449,7 +452,7 @@ constexpr int kBackStage = 2048;
 constexpr int kBackThreads = 1024;
 
 __global__ __launch_bounds__(kBackThreads) void k_chain_backtrack(const int32_t* __restrict__ pred, int64_t n, int32_t* __restrict__ path_ids,
-                                                                  int64_t* __restrict__ meta) {
+                                                                  int64_t* __restrict__ meta, const uint32_t* __restrict__ ctl) {
   __shared__ int32_t s_pred[2][kBackBlock];
   __shared__ int32_t s_out[kBackStage];
   __shared__ int32_t s_cur, s_nout;
@@ -457,6 +460,8 @@ __global__ __launch_bounds__(kBackThreads) void k_chain_backtrack(const int32_t*
   const int tid = threadIdx.x;
   int64_t total = 0;
   int32_t cur = (int32_t)meta[0];
+  // a column pipeline that gave up (ctl[1], the 20 s neighbour time-out) has left pred[] / meta[0] unwritten: no path
+  if ((ctl && ctl[1] != 0u) || (int64_t)cur >= n) cur = -1;
   int sel = 0;
   bool have = false;                                         // s_pred[sel] already holds the block of `cur`
   int4 pre[kPer / 4];
@@ -482,7 +487,11 @@ __global__ __launch_bounds__(kBackThreads) void k_chain_backtrack(const int32_t*
     while (true) {                                           // chase inside the block, flushing the stage when it fills
       if (tid == 0) {
         int32_t m = 0, p = cur;
-        while (p >= lo && m < kBackStage) { s_out[m++] = p; p = s_pred[sel][p - lo]; }
+        while (p >= lo && m < kBackStage) {
+          s_out[m++] = p;
+          const int32_t np = s_pred[sel][p - lo];
+          p = np < p ? np : -1;                               // predecessors have smaller ids: anything else ends the walk (never a cycle, never more than n ids)
+        }
         s_cur = p; s_nout = m;
       }
       __syncthreads();
@@ -801,11 +810,13 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
 // ---- preparation of the column-major arrays
 struct U8ToI32 { __device__ int32_t operator()(const uint8_t& x) const { return (int32_t)x; } };
 
-__global__ __launch_bounds__(256) void k_col_keys(const int32_t* __restrict__ rank, int64_t n, int width, uint16_t* __restrict__ key,
+__global__ __launch_bounds__(256) void k_col_keys(const int32_t* __restrict__ rank, int64_t n, int width, int n_cols, uint16_t* __restrict__ key,
                                                   uint32_t* __restrict__ val) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  key[k] = (uint16_t)((uint32_t)(rank[k] - 1) / (uint32_t)width);
+  uint32_t col = (uint32_t)(rank[k] - 1) / (uint32_t)width;           // ranks are 1 .. n_ranks (k_chain_prep clamps what the rank map does not know)
+  if (col >= (uint32_t)n_cols) col = (uint32_t)n_cols - 1u;          // belt and braces: k_col_gather indexes col_start[] by this
+  key[k] = (uint16_t)col;
   val[k] = (uint32_t)k;
 }
 
@@ -816,7 +827,7 @@ __global__ __launch_bounds__(256) void k_col_gather(const uint16_t* __restrict__
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j > n) return;
   const int prev = j > 0 ? (int)key[j - 1] : -1;
-  const int cur = j < n ? (int)key[j] : n_cols;
+  const int cur = j < n ? ((int)key[j] < n_cols ? (int)key[j] : n_cols - 1) : n_cols;
   for (int c = prev + 1; c <= cur; ++c) col_start[c] = (int32_t)j;      // first match of every column (empty ones included)
   if (j == n) return;
   const uint32_t g = val[j];
@@ -879,7 +890,7 @@ int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream
     if (hipcub::DeviceScan::InclusiveSum(cc.temp, bytes, it, cc.rowid1, n, s) != hipSuccess) return -1;
   }
   // stable partition of the match ids by column
-  hipLaunchKernelGGL(k_col_keys, dim3(blocks), dim3(256), 0, s, c.rank, c.n, cc.width, cc.key_in, cc.val_in);
+  hipLaunchKernelGGL(k_col_keys, dim3(blocks), dim3(256), 0, s, c.rank, c.n, cc.width, cc.n_cols, cc.key_in, cc.val_in);
   {
     size_t bytes = cc.temp_bytes;
     if (hipcub::DeviceRadixSort::SortPairs(cc.temp, bytes, (const uint16_t*)cc.key_in, cc.key_out, (const uint32_t*)cc.val_in, cc.val_out, n, 0,
@@ -907,7 +918,7 @@ int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream
   else if (lv <= 11) go(k_chain_columns<11>);
   else if (lv <= 12) go(k_chain_columns<12>);
   else go(k_chain_columns<13>);
-  hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(kBackThreads), 0, s, c.pred, c.n, c.path_ids, c.meta);
+  hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(kBackThreads), 0, s, c.pred, c.n, c.path_ids, c.meta, (const uint32_t*)cc.ctl);
   hipLaunchKernelGGL(k_chain_gather, dim3(256), dim3(256), 0, s, c.keys, c.path_ids, c.meta, c.out_i, c.out_v);
   return 0;
 }
@@ -973,7 +984,7 @@ int launch_chain_dp(const ChainLaunch& c, hipStream_t s) {
   DA_CHAIN_CASE(8, 10) DA_CHAIN_CASE(8, 13) DA_CHAIN_CASE(8, 16)
 #undef DA_CHAIN_CASE
   }
-  hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(kBackThreads), 0, s, c.pred, c.n, c.path_ids, c.meta);
+  hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(kBackThreads), 0, s, c.pred, c.n, c.path_ids, c.meta, (const uint32_t*)nullptr);
   hipLaunchKernelGGL(k_chain_gather, dim3(256), dim3(256), 0, s, c.keys, c.path_ids, c.meta, c.out_i, c.out_v);
   return 0;
 }

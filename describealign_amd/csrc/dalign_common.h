@@ -11,11 +11,12 @@ constexpr int kTaps = 7;            // hash taps per feature        (:610)
 constexpr int kTapStep = 6;         // (:611)
 constexpr int kTapStart = 2;        // (:613)
 constexpr int kPad = 64;            // zero padding (elements) after every per-frame device row
-// bf16 prefilter: guard subtracted from the audio window norm that rides in the GEMM's spare K slots.
-// Operands are rounded to bf16 (relative error <= 2^-8 each), products are exact in f32, so the computed
-// dot product differs from the exact one by at most (2^-7 + 2^-16) sum|x_k y_k| <= (2^-7 + 2^-16) |A|
-// (Cauchy-Schwarz, |x| = 1).  With |A| (1 - guard) in the norm slot the accumulator never exceeds the
-// exact |A| (1 - corr): every pair the exact criterion accepts survives the prefilter, whatever the data.
+// bf16 prefilter: guard subtracted from the 1 that rides in the GEMM's spare K slots.
+// Both operands are unit-norm windows rounded to bf16 (relative error <= 2^-8 each), products are exact in
+// f32, so the computed dot product differs from the exact correlation by at most
+// (2^-7 + 2^-16) sum|x_k y_k| <= 2^-7 + 2^-16 (Cauchy-Schwarz, |x| = |y| = 1).  With (1 - guard) in the norm
+// slot the accumulator never exceeds the exact (1 - corr): every pair the exact criterion accepts survives
+// the prefilter, whatever the data.
 constexpr double kBf16Guard = 0.0078125 + 0.00006103515625;      // 2^-7 + 2^-14
 
 // ---- feature kernel tables (built on the host in double, see dalign_api.cpp) ----------------
@@ -59,9 +60,6 @@ struct PrepArgs {
   float* inv32[3];        // 1/norm as float32
   float* nrm32[3];        // norm as float32
   float* prod32;          // nrm0*nrm1*nrm2 as float32 (per-frame threshold scale)
-  uint32_t* nrmpk[3];     // norm split into two bf16 (hi | lo << 16): rides in two spare K slots of the bf16 GEMM
-  uint16_t* bf_even[3];   // bf16 copy of ms: element e at [e]
-  uint16_t* bf_odd[3];    // bf16 copy of ms shifted by one: element e+1 at [e]
 };
 void launch_prep(const PrepArgs& a, const double* d_hann41n, hipStream_t s);
 
@@ -70,10 +68,13 @@ struct MatchArgs {
   const float* ms_v[3]; const float* ms_a[3];
   const float* inv_v[3]; const float* inv_a[3];
   const float* nrm_a[3]; const float* prod_a;                 // audio norms and their product
-  const uint32_t* nrmpk_a[3];                                 // bf16 GEMM: audio norm as two bf16
-  const uint16_t* bfa_even[3]; const uint16_t* bfa_odd[3];   // audio side bf16 copies
-  const double* msd_v[3];                                     // for building bf16 A fragments
-  void* bfv_frag; int64_t bfv_tiles;                          // bf16 GEMM: the video operand in MFMA fragment order [tile][feature][step][lane] x 16 B (scratch, filled per launch)
+  const double* msd_v[3]; const double* msd_a[3];             // bf16 GEMM: float64 rows and norms the operand
+  const double* nrmd_v[3]; const double* nrmd_a[3];           //   fragments are built from
+  // bf16 GEMM: BOTH operands in MFMA fragment order [tile][feature 3][step 3][lane 64] x 16 B = 9 KiB per 32 rows /
+  // columns (scratch, rebuilt per launch): the video rows scaled by -cscale_j / |V|, the audio columns by 1 / |A|
+  void* bfv_frag; int64_t bfv_tiles;
+  void* bfa_frag; int64_t bfa_tiles;
+  float cscale[3];                                            // per-feature scale (exact in bf16) that puts the threshold at 2^30 in the pattern sum
   const int32_t* vlist; int64_t n_v;      // every 4th non-quiet video frame (:629-630)
   const int32_t* alist; int64_t n_a;      // non-quiet audio frames within the requested rows (:657-658)
   unsigned long long* out;                // staged survivor records (see pack_record)
@@ -83,6 +84,9 @@ struct MatchArgs {
   int audio_tiles_per_block;
 };
 constexpr int kBfVideoTileGroup = 96;   // bfv_tiles is a multiple of this: a workgroup of the bf16 GEMM owns 16, 24 or 32 row tiles
+constexpr int kBfAudioTilePad = 2;      // bfa_tiles = column tiles + this: the GEMM requests one tile past the one it is working on
+// per-feature scales of the bf16 GEMM for the threshold `thr` on prod_j (1 - corr_j)
+void bf16_gemm_scales(double thr, float out[3]);
 void launch_match_f32(const MatchArgs& a, hipStream_t s);
 void launch_match_bf16(const MatchArgs& a, hipStream_t s);
 
@@ -101,6 +105,8 @@ struct VerifyArgs {
   const double* nrm_v[3]; const double* nrm_a[3];
   const uint32_t* dig_v[5]; const uint32_t* flg_v[5]; const uint32_t* dig_a[5];
   int mode;
+  const int32_t* alist; int64_t n_a;      // bf16 GEMM records carry the POSITION in the audio row list and reject bits (see bd_finalize); NULL: f32 records
+
   const int32_t* vlist; int64_t n_v;      // to expand staged records (video tile, row mask)
   unsigned long long* n_pairs;            // number of (i, v) pairs the records expand to
   unsigned long long* keys; double* quals; unsigned long long* n_out; unsigned long long out_capacity;

@@ -10,6 +10,7 @@
 // float64, applies the reference's hash vote (:649-660) in its closed form, and emits
 // (i, v, quality).
 #include "dalign_common.h"
+#include <cmath>
 #include <cstdlib>
 #include <string>
 
@@ -59,18 +60,13 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
   const int64_t L = a.len[j];
   if (i >= a.lmax + kPad) return;
   const double* ms = a.ms[j];
-  if (j < 3) {
-    // bf16 copies of the (unnormalised) mean-subtracted row, scaled into range by nothing: values are O(1)
-    a.bf_even[j][i] = f32_to_bf16((float)ms[i]);
-    a.bf_odd[j][i] = f32_to_bf16((i + 1 < a.lmax + kPad) ? (float)ms[i + 1] : 0.f);
-  }
   const int64_t nv = L - (kWin - 1);
   if (i >= nv || nv <= 0) {
     if (i < a.lmax + kPad) {
       a.nrm[j][i] = 1.0;
       a.digits[j][i] = 0xFFFFFFFFu;          // never matches
       if (a.is_video) a.flags[j][i] = 0xFFFFFFFFu;
-      if (j < 3) { a.inv32[j][i] = 0.f; a.nrm32[j][i] = 1.f; a.nrmpk[j][i] = 0x00003F80u; }
+      if (j < 3) { a.inv32[j][i] = 0.f; a.nrm32[j][i] = 1.f; }
     }
     return;
   }
@@ -82,12 +78,6 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
   a.nrm[j][i] = nr;
   if (j < 3) {
     a.inv32[j][i] = (float)(1.0 / nr); a.nrm32[j][i] = (float)nr;
-    // bf16 GEMM: the norm slot carries |A| (1 - guard), see kBf16Guard: the accumulator under-estimates
-    const double ng = nr * (1.0 - kBf16Guard);
-    const uint16_t hi = f32_to_bf16((float)ng);
-    const float hif = __uint_as_float((uint32_t)hi << 16);
-    const uint16_t lo = f32_to_bf16((float)(ng - (double)hif));
-    a.nrmpk[j][i] = (uint32_t)hi | ((uint32_t)lo << 16);
   }
   uint32_t dig = 0, flg = 0;
 #pragma unroll
@@ -380,142 +370,149 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 1) void k_match_f32(MatchArgs 
 
 // ------------------------------------------------------------------------------------------
 // similarity GEMM, bf16 inputs / f32 accumulate on v_mfma_f32_32x32x16_bf16 (a PREFILTER: every
-// survivor is re-verified in float64 by k_verify).
-// K = 41 padded to 48 = three K-steps of 16, permuted so that lane half h, step s, element e holds
-// k = 24 h + 8 s + e (each lane's operands are 24 consecutive bf16; two shifted copies of the row
-// make any start 4-byte aligned).  Spare slots k = 42, 43 carry the audio window norm, less the rounding
-// guard kBf16Guard, split into two bf16 (A holds 1 there): the accumulator ends as |A| (1 - guard - corr)
-// plus rounding that the guard bounds, i.e. never above the exact |A| (1 - corr), and the epilogue per video row
-// is three VALU instructions: p = a0 a1;  d = p a2 - thr |A|_0 |A|_1 |A|_2;  mask = (mask << 1) | sign(d).
+// survivor is re-verified in float64 by k_verify).  Version 8.
 //
-// The kernel (k_match_bf16, further down) is organised like k_match_f32: one wave per SIMD, the resident
-// operand in AGPRs, the streamed operand loaded straight into fragment registers.
+// BOTH operands are explicit, pre-normalised fragment streams (k_bf16_video_frags / k_bf16_audio_frags):
+// a 32-row (32-column) tile is 9 KiB = [feature 3][K step 3][lane 64] x 16 bytes, exactly what lane
+// (r, h) feeds to the MFMA.  K = 41 padded to 48 = three K-steps of 16; lane half h, step s, element e
+// holds k = 24 h + 8 s + e.  Video rows carry  -c_j ms_v[v + k] / |V|_v, audio columns  ms_a[i + k] / |A|_i;
+// the spare slots k = 42, 43 carry c_j (video side) and the two bf16 halves of (1 - guard) (audio side),
+// so the accumulator of feature j ends as
+//        acc_j = c_j (1 - guard - corr_j) + rounding  <=  c_j (1 - corr_j)   (kBf16Guard bounds the rounding).
+//
+// Acceptance test, two VALU instructions per pair.  The reference keeps a pair when
+// prod_j max(1e-8, 1 - corr_j) <= thr (:668-670).  For a positive float x = 2^e (1 + m) the bit pattern read
+// as an integer is 2^23 (e + 127 + m), and m <= log2(1 + m): the pattern under-estimates 2^23 (log2 x + 127)
+// by at most 0.0861 * 2^23.  So with S = bits(acc_0) + bits(acc_1) + bits(acc_2) (ONE v_add3_u32)
+//        prod_j acc_j <= thr c_0 c_1 c_2   ==>   S <= 2^23 (381 + log2(thr c_0 c_1 c_2)),
+// and the scales c_j (bf16_gemm_scales: about 2^-81 each, exact in bf16) put that bound just below 2^30:
+// every pair the exact criterion accepts has S < 2^30 when its three accumulators are positive -- a
+// superset, the threshold widened by at most 2^(3 * 0.0861) = 1.196.  Accumulators that the guard pushed
+// below zero (corr_j > 0.984: the reference's clamp regime, always accepted) set bit 31 of their pattern:
+//   one negative:    S = 2^31 + (< 2^31)                          -> S[31:30] = 10 or 11
+//   two negative:    S = 2^32 + X, X <= pattern sum of (2 guard)^2 * 2 c_0 c_1 c_2 < 2^30 (a factor 3.5 below thr)  -> 00
+//   three negative:  S = 2^31 + 2^32 + tiny                       -> 10
+// while three positive accumulators give S < 2^31, i.e. 00 (accept) or 01 (reject).  So
+//        reject  <=>  S[31:30] == 01,
+// and v_alignbit_b32(M, S, 30) appends those two bits to the lane's 32-bit code word M: 16 rows, 2 VALU each,
+// where the product form (p = a0 a1; d = fma(p, a2, -thr); sign) took 3 and a per-column threshold.  "No
+// survivor in these 16 rows" is M == 0x55555555.  Only lanes with a survivor turn M into 16 reject bits.
+//
+// Why explicit operands (v7 read the audio side as 16-byte windows out of two shifted bf16 copies of the
+// rows): a Hankel operand cannot be normalised per column, so v7 carried |A| in the norm slot, a per-column
+// threshold in a register, and per tile: the frame numbers two tiles ahead, five dword gathers hanging off
+// them, the norm patch into the fragments, even / odd copy selection -- ~50 instructions per tile on the
+// wave's one issue port, and a per-column threshold rules out the fixed-point test above.  Now a tile is
+// nine fully coalesced 1 KiB loads from one running pointer, and nothing else.  Price: 288 B per audio
+// column of scratch (2 h pair: 435 MB) streamed through L2 by every workgroup of a stripe in lock step.
 // ------------------------------------------------------------------------------------------
-
-// threshold epilogue of one accumulator row of a finished tile: three VALU instructions.
-// The three accumulator blocks of a tile are 16 registers apart, i.e. in the same VGPR bank for equal
-// row index g, and two operands from one bank cost the instruction an extra cycle.  Feature j's A
-// operand is therefore built with its rows rotated by j inside every group of four (bf_arow), so that
-// video row g's three values sit in registers g, g^+1, g^+2 (rotation inside the group of four): three
-// different banks.
-__device__ __forceinline__ constexpr int bf_rot(int g, int j) { return (g & ~3) | ((g + j) & 3); }
-// video row (0..31 within the MFMA tile) that lane r of feature j's A operand carries
-__device__ __forceinline__ int bf_arow(int r, int j) { return (r & ~3) | ((r - j) & 3); }
-__device__ __forceinline__ void bf_row(const f32x16 (&acc)[3], int g, float thr, uint32_t& mask) {
-  const float p = acc[0][g] * acc[1][bf_rot(g, 1)];
-  const float d = __builtin_fmaf(p, acc[2][bf_rot(g, 2)], -thr);    // < 0  <=>  a0 a1 a2 < thr |A|0 |A|1 |A|2
-  mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(d), 31);   // (mask << 1) | sign(d): rows fed 15..0
-}
-
-// the same in two steps, for kernels that spread the epilogue over MFMA slots: the product of the first two
-// features may be formed one matrix-pipe slot earlier than the third accumulator may be read
-__device__ __forceinline__ void bf_row_mul(f32x16 (&acc)[3], int g) { acc[0][g] = acc[0][g] * acc[1][bf_rot(g, 1)]; }
-__device__ __forceinline__ void bf_row_cmp(const f32x16 (&acc)[3], int g, float thr, uint32_t& mask) {
-  const float d = __builtin_fmaf(acc[0][g], acc[2][bf_rot(g, 2)], -thr);
-  mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(d), 31);
-}
-
-// Survivors of one finished tile: every lane with a non-zero row mask stages one record at the next free
-// slot of its wave's LDS buffer.  The caller flushes the buffer before it can overflow.
-__device__ __forceinline__ void bf_emit(SurvSink& sk, int h, int64_t vtile, uint32_t mask, int32_t ic) {
-  const unsigned long long m = __ballot(mask != 0u);
-  if (m == 0ull) return;               // the wave is instruction-issue bound: ~4 in 10 tiles have no survivor at all
-  const int pos = sk.count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-  // record = ic << 41 | vtile << 17 | h << 16 | mask, as two dwords (vtile < 2^24: its bits end at 40)
-  const uint32_t lo = mask | ((uint32_t)h << 16) | ((uint32_t)vtile << 17);
-  const uint32_t hi = ((uint32_t)ic << 9) | (uint32_t)(vtile >> 15);
-  if (mask != 0u) reinterpret_cast<uint2*>(sk.s_buf)[pos] = uint2{lo, hi};
-  sk.count += __popcll(m);
-}
-// ------------------------------------------------------------------------------------------
-// bf16 GEMM (v7).  One wave per SIMD with the whole 512-register budget, no LDS staging of operands, no
-// producer waves, no barriers (the round-1/2 kernel staged the streamed operand in LDS with four producer
-// waves per workgroup: v6, 11 % slower).  A wave keeps kBdRowTiles x 32 video
-// rows resident (216 AGPRs for six tiles) and streams 32-column tiles of the audio operand straight from
-// L2 into MFMA fragment registers -- nine 16-byte loads per lane and tile from the (even / odd) bf16 row
-// copies, issued one whole tile (54 MFMAs) ahead into a second register set -- so every fragment feeds
-// six MFMAs.  What this removes from the SIMD's instruction stream: the producers' LDS-DMA pieces
-// (measured: 17 % of the staged kernel's time), the group barriers and two thirds of the fragment reads.
 #ifndef DA_BD_ROWTILES
 #define DA_BD_ROWTILES 6
 #endif
 constexpr int kBdRowTiles = DA_BD_ROWTILES;       // even: the two accumulator sets alternate
 constexpr int kBdWaves = 4;
-constexpr int kBdLoadSlot = 7;                    // MFMA slot of a phase that carries the next tile's loads (it has two epilogue instructions; with the loads in slots 2 / 4 / 5 the kernel was 5 % slower)
 constexpr int kBdRows = 32 * kBdRowTiles;
 constexpr int kBdRowsPerBlock = kBdRows * kBdWaves;
 static_assert(kBdRowTiles % 2 == 0 && kBdRowTiles >= 4 && kBfVideoTileGroup % (kBdRowTiles * kBdWaves) == 0, "row tiling");
 constexpr int kBdSurv = 128 * kBdRowTiles;        // a column tile adds at most 64 records per row tile
-typedef short bf16x8u __attribute__((ext_vector_type(8), aligned(4)));   // 16-byte load, 4-byte aligned
+constexpr uint32_t kBdAllReject = 0x55555555u;    // code word of 16 rejected rows
+constexpr uint32_t kBdIdleBits = 0x20000000u;     // accumulator pattern whose triple sum reads "reject" (nothing owed)
 
-struct BdTile {                  // streamed operand of one 32-column tile, as this lane's MFMAs take it
-  bf16x8 frag[3][3];
-  uint32_t nrm[3];               // audio window norms of the lane's column (hi + lo bf16)
-  float prod;                    // |A|_0 |A|_1 |A|_2 of the column
-  int32_t ic;                    // its frame number
-};
+// The three accumulator blocks of a tile are 16 registers apart, i.e. in the same VGPR bank for equal
+// row index g, and three operands from one bank cost the instruction extra cycles.  Feature j's video
+// operand is therefore built with its rows rotated by j inside every group of four (bf_arow), so that
+// video row g's three values sit in registers g, g^+1, g^+2: three different banks.
+__device__ __forceinline__ constexpr int bf_rot(int g, int j) { return (g & ~3) | ((g + j) & 3); }
+// video row (0..31 within the MFMA tile) that lane r of feature j's video operand carries
+__device__ __forceinline__ int bf_arow(int r, int j) { return (r & ~3) | ((r - j) & 3); }
 
-// loads of feature j of the tile whose frame numbers are `ic`
-__device__ __forceinline__ void bd_issue_feature(const MatchArgs& a, int32_t ic, int h, int j, BdTile& t) {
-  const int32_t st = ic + 24 * h;                // first element of this lane's run (K permutation: k = 24 h + 8 s + e)
-  const int32_t odd = st & 1;
-  const int32_t ev = st - odd;                   // even element index into the chosen copy: 4-byte aligned
-  const uint16_t* base = (odd ? a.bfa_odd[j] : a.bfa_even[j]) + ev;
-#pragma unroll
-  for (int s = 0; s < 3; ++s) t.frag[j][s] = *reinterpret_cast<const bf16x8u*>(base + 8 * s);
+// one row of the epilogue: two VALU instructions (see the header comment)
+__device__ __forceinline__ void bf_row(const f32x16 (&acc)[3], int g, uint32_t& codes) {
+  const uint32_t s = __float_as_uint(acc[0][g]) + __float_as_uint(acc[1][bf_rot(g, 1)]) + __float_as_uint(acc[2][bf_rot(g, 2)]);
+  codes = __builtin_amdgcn_alignbit(codes, s, 30);                  // (codes << 2) | S[31:30]: rows fed 15 .. 0, row g ends at bits 2g+1 : 2g
 }
-// what a tile needs besides its fragments: the column norms (they go into K slots 42 / 43) and their product (threshold)
-__device__ __forceinline__ void bd_issue_side(const MatchArgs& a, int32_t ic, BdTile& t) {
-  t.ic = ic;
-  t.prod = a.prod_a[ic];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) t.nrm[j] = a.nrmpk_a[j][ic];
+// code word -> 16 reject bits (0 = survivor): bit 2k = row k, bit 2k + 1 = row 8 + k (k = 0..7).  Rare path only.
+__device__ __forceinline__ uint32_t bf_reject_bits(uint32_t codes) {
+  const uint32_t rej = codes & ~(codes >> 1);                       // bit 2g = (code_g == 01)
+  return (rej & 0x5555u) | ((rej >> 15) & 0xAAAAu);
+}
+// inverse, for k_verify: accumulator register g of reject-bit position b
+__device__ __forceinline__ int bf_bit_row(int b) { return (b & 1) ? 8 + (b >> 1) : (b >> 1); }
+
+// Survivors of one finished phase: every lane whose code word is not all-reject stages one record
+//   lo = reject bits | h << 16 | vtile << 17,   hi = vtile >> 15 | (position in the audio row list) << 9
+// at the next free slot of its wave's LDS buffer.  The caller flushes the buffer before it can overflow.
+__device__ __forceinline__ void bf_emit(SurvSink& sk, int h, int64_t vtile, uint32_t codes, uint32_t acol) {
+  const bool any = codes != kBdAllReject;
+  const unsigned long long m = __ballot(any);
+  if (m == 0ull) return;               // ~4 in 10 phases have no survivor at all
+  const int pos = sk.count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  const uint32_t lo = bf_reject_bits(codes) | ((uint32_t)h << 16) | ((uint32_t)vtile << 17);
+  const uint32_t hi = (acol << 9) | (uint32_t)(vtile >> 15);
+  if (any) reinterpret_cast<uint2*>(sk.s_buf)[pos] = uint2{lo, hi};
+  sk.count += __popcll(m);
 }
 
-// names every register of a tile: the compiler retires its loads (vmcnt) here, before the next batch is issued
-__device__ __forceinline__ void bd_retire(const BdTile& t) {
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-#pragma unroll
-    for (int s = 0; s < 3; ++s) asm volatile("" ::"v"(t.frag[j][s]));
-    asm volatile("" ::"v"(t.nrm[j]));
+struct BdTile { bf16x8 frag[3][3]; };             // streamed operand of one 32-column tile, as this lane's MFMAs take it
+
+// The nine loads of a tile, in the order the MFMAs of a phase consume them (m = 0..8 <-> feature m % 3, step m / 3),
+// from a wave-uniform tile pointer (SGPR pair) + this lane's byte offset.  Inline assembly: the wave counts its own
+// vmcnt (bd_phase waits for fragment m in front of MFMA m of a tile's first phase), which the compiler cannot do
+// for loads whose uses are inline-assembly MFMAs.  Extra vector-memory operations of the compiler (the survivor
+// flush) only make those waits stricter: the counter retires in issue order.
+template <int kM, int kLast>
+__device__ __forceinline__ void bd_issue(BdTile& t, const void* tile, uint32_t off0, uint32_t off1, uint32_t off2) {
+  if constexpr (kM < kLast) {
+    constexpr int j = kM % 3, s = kM / 3, q = 3 * j + s;           // fragment q of the tile sits at byte q * 1024
+    if constexpr (q < 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(t.frag[j][s]) : "v"(off0), "s"(tile), "n"(q * 1024));
+    else if constexpr (q < 8) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(t.frag[j][s]) : "v"(off1), "s"(tile), "n"((q - 4) * 1024));
+    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(t.frag[j][s]) : "v"(off2), "s"(tile), "n"((q - 8) * 1024));
+    bd_issue<kM + 1, kLast>(t, tile, off0, off1, off2);
   }
-  asm volatile("" ::"v"(t.prod));
 }
 
-// 9 MFMAs of one (32 rows x 32 columns) phase into `acc`, the threshold epilogue of the previous phase
-// (`accp`, `thr_p`) between them.  The MFMAs are inline assembly so that the register files can be
-// chosen: the resident A operand lives in AGPRs (only MFMAs read it), accumulators and streamed
-// fragments in VGPRs (the epilogue reads accumulators with plain VALU: no v_accvgpr_read).  The
-// compiler does not know these statements are MFMAs, so
+// 9 MFMAs of one (32 rows x 32 columns) phase into `acc`, the epilogue of the previous phase (`accp` -> `codes`)
+// between them.  The MFMAs are inline assembly so that the register files can be chosen: the resident
+// video operand lives in AGPRs (only MFMAs read it), accumulators and streamed fragments in VGPRs (the
+// epilogue reads accumulators with plain VALU: no v_accvgpr_read).  The compiler does not know these
+// statements are MFMAs, so
 //  (1) a scheduling barrier closes every MFMA slot -- nothing moves across;
-//  (2) the slot layout itself keeps the MFMA -> VALU read distance (a result may be read 11 wait states =
-//      44 cycles after its MFMA was issued; the matrix pipe takes one MFMA per 32 cycles): slot 0 only
-//      multiplies the first two accumulators, whose last MFMAs are two and three pipe slots old there,
-//      and the third accumulator is first read in slot 1, two pipe slots behind its last MFMA;
-//  (3) nothing but loads and the norm patch (fenced, at the top of a tile) ever writes an MFMA source
-//      register, so no "VALU write -> MFMA read" wait states are owed in front of an MFMA.
+//  (2) the slot layout itself keeps the MFMA -> VALU read distance: the epilogue starts in slot 1, when two
+//      further MFMAs have been issued behind the last MFMA of the previous phase (its third accumulator);
+//      slot 0 carries the next tile's loads instead (`extra`);
+//  (3) nothing but loads ever writes an MFMA source register.
 // profiles/tools/check_mfma_asm_hazards.py checks (2) and (3) on the generated ISA.
-// `extra(m)` is issued in slot m.
-template <class Extra>
+// kWait: this is the first phase of a column tile -- MFMA m waits until at most 8 - m of the wave's vector-memory
+// operations are outstanding, i.e. until fragment m (requested a whole tile ago, oldest first) has landed.
+template <bool kWait, class Extra>
 __device__ __forceinline__ void bd_phase(const bf16x8 (&A)[3][3], const bf16x8 (&frag)[3][3], f32x16 (&acc)[3],
-                                         f32x16 (&accp)[3], float thr_p, uint32_t& mask_p, Extra extra) {
-  // epilogue of the previous phase, 48 VALU over the nine slots: products a0 a1 (in place) first -- they
-  // only read accumulators whose last MFMA is at least two slots old even in slot 0 -- then, from slot 1
-  // on, the fused multiply-add with the third accumulator and the sign collection, rows 15 .. 0
-  constexpr int kMulFrom[10] = {16, 10, 6, 2, 0, 0, 0, 0, 0, 0};   // slot m multiplies rows kMulFrom[m+1] .. kMulFrom[m]-1
-  constexpr int kCmpFrom[10] = {16, 16, 15, 14, 12, 9, 6, 3, 1, 0};  // slot m finishes rows kCmpFrom[m+1] .. kCmpFrom[m]-1
+                                         const f32x16 (&accp)[3], uint32_t& codes, Extra extra) {
 #pragma unroll
   for (int m = 0; m < 9; ++m) {
     const int j = m % 3, s = m / 3;
+    if (kWait) {
+      switch (m) {
+        case 0: asm volatile("s_waitcnt vmcnt(8)"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(7)"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(6)"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(5)"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(3)"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(2)"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(1)"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)"); break;
+      }
+    }
     if (s == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[j]) : "a"(A[j][s]), "v"(frag[j][s]));
     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[j]) : "a"(A[j][s]), "v"(frag[j][s]));
     __builtin_amdgcn_sched_barrier(0);
 #ifndef DA_DBG_BF_NOEPI
-#pragma unroll
-    for (int g = kMulFrom[m] - 1; g >= kMulFrom[m + 1]; --g) bf_row_mul(accp, g);
-#pragma unroll
-    for (int g = kCmpFrom[m] - 1; g >= kCmpFrom[m + 1]; --g) bf_row_cmp(accp, g, thr_p, mask_p);
+    if (m >= 1) {                                                   // slots 1 .. 8: rows 15 .. 0, two per slot
+      bf_row(accp, 17 - 2 * m, codes);
+      bf_row(accp, 16 - 2 * m, codes);
+    }
+#else
+    codes = kBdAllReject;
 #endif
     extra(m);
     __builtin_amdgcn_sched_barrier(0);
@@ -523,10 +520,10 @@ __device__ __forceinline__ void bd_phase(const bf16x8 (&A)[3][3], const bf16x8 (
 }
 
 // The resident (video) operand in MFMA fragment order, one wavefront per 32-row tile: out[tile][feature][step][lane]
-// is the 16 bytes lane (r, h) feeds to step s of feature j -- the bf16 of -ms_v[v + k] / |V|_v for
-// k = 24 h + 8 s + e < 41, 1.0 in the two norm slots, 0 elsewhere; rows rotated per feature (bf_arow).
-// Tiles past the last row hold the "no row" operand (zeros and the norm ones): a wave may own up to
-// kBdRowTiles - 1 of them.  The GEMM waves load these straight into AGPRs.
+// is the 16 bytes lane (r, h) feeds to step s of feature j -- the bf16 of -c_j ms_v[v + k] / |V|_v for
+// k = 24 h + 8 s + e < 41, c_j in the two norm slots, 0 elsewhere; rows rotated per feature (bf_arow).
+// Tiles past the last row hold the "no row" operand (zeros and the norm slots: every accumulator c_j (1 - guard),
+// which the test rejects): a wave may own up to kBdRowTiles - 1 of them.  The GEMM waves load these straight into AGPRs.
 __global__ __launch_bounds__(64) void k_bf16_video_frags(MatchArgs a) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, h = lane >> 5;
@@ -537,7 +534,9 @@ __global__ __launch_bounds__(64) void k_bf16_video_frags(MatchArgs a) {
     const int64_t vr = tile * 32 + bf_arow(r, j);
     const bool vok = vr < a.n_v;
     const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
-    const double sc = vok ? -(double)a.inv_v[j][v] : 0.0;
+    const double cj = (double)a.cscale[j];
+    const double sc = vok ? -cj / a.nrmd_v[j][v] : 0.0;
+    const uint16_t cbits = (uint16_t)(__float_as_uint(a.cscale[j]) >> 16);      // exact: the scale is a bf16 number
     const double* p = a.msd_v[j] + v;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -547,7 +546,7 @@ __global__ __launch_bounds__(64) void k_bf16_video_frags(MatchArgs a) {
         const int k = 24 * h + 8 * s + e;
         uint16_t x = 0;
         if (k < kWin) x = f32_to_bf16((float)(p[k] * sc));
-        else if (k == 42 || k == 43) x = 0x3F80;            // 1.0: the norm slots
+        else if (k == 42 || k == 43) x = cbits;
         if (e & 1) w[e >> 1] |= (uint32_t)x << 16; else w[e >> 1] = x;
       }
       out[(3 * j + s) * 64] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -555,22 +554,61 @@ __global__ __launch_bounds__(64) void k_bf16_video_frags(MatchArgs a) {
   }
 }
 
+// The streamed (audio) operand, one wavefront per 32-column tile: column r of tile t is entry 32 t + r of the audio
+// row list; lane (r, h) of step s of feature j gets the bf16 of ms_a[i + k] / |A|_i for k = 24 h + 8 s + e < 41 and
+// the two bf16 halves of 1 - kBf16Guard (0.9921875 and -2^-14: exact) in the norm slots.  Columns past the end
+// of the list (and the kBfAudioTilePad tiles the GEMM requests but never uses) hold zeros and the norm slots.
+__global__ __launch_bounds__(64) void k_bf16_audio_frags(MatchArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t tile = blockIdx.x;
+  uint4* out = reinterpret_cast<uint4*>(a.bfa_frag) + tile * 9 * 64 + lane;
+  const int64_t col = tile * 32 + r;
+  const bool ok = col < a.n_a;
+  const int32_t i = a.alist[ok ? col : (a.n_a > 0 ? a.n_a - 1 : 0)];
+  const double one = 1.0 - kBf16Guard;
+  const uint16_t hi = f32_to_bf16((float)one);
+  const uint16_t lo = f32_to_bf16((float)(one - (double)__uint_as_float((uint32_t)hi << 16)));
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double sc = ok ? 1.0 / a.nrmd_a[j][i] : 0.0;
+    const double* p = a.msd_a[j] + i;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      uint32_t w[4];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 24 * h + 8 * s + e;
+        uint16_t x = 0;
+        if (k < kWin) x = f32_to_bf16((float)(p[k] * sc));
+        else if (k == 42) x = hi;
+        else if (k == 43) x = lo;
+        if (e & 1) w[e >> 1] |= (uint32_t)x << 16; else w[e >> 1] = x;
+      }
+      out[(3 * j + s) * 64] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+// One wave per SIMD with the whole 512-register budget, no LDS staging of operands, no producer waves, no
+// barriers.  A wave keeps kBdRowTiles x 32 video rows resident (216 AGPRs for six tiles) and streams 32-column
+// tiles of the audio operand: nine 1 KiB loads per tile, issued one whole tile (54 MFMAs) ahead into a second
+// register set, every fragment feeding six MFMAs.
 __global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
   __shared__ unsigned long long s_surv[kBdWaves][kBdSurv + 64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int64_t vt0 = ((int64_t)blockIdx.x * kBdWaves + wave) * kBdRows;
-  const int64_t a_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block * 32;
-  int64_t a_end = a_begin + (int64_t)a.audio_tiles_per_block * 32;
-  if (a_end > a.n_a) a_end = a.n_a;
-  if (vt0 >= a.n_v || a_begin >= a_end) return;
+  const int64_t atiles = (a.n_a + 31) >> 5;
+  const int64_t t_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block;
+  int64_t t_end = t_begin + a.audio_tiles_per_block;
+  if (t_end > atiles) t_end = atiles;
+  if (vt0 >= a.n_v || t_begin >= t_end) return;
   SurvSink sk{s_surv[wave], 0, kBdSurv};
   const int64_t vtile0 = vt0 >> 5;
   // The resident operand goes from memory straight into AGPRs: only MFMAs read it, and the VGPR half of
-  // the register file belongs to the accumulators and the streamed fragments.  (Inline assembly: this
-  // is the one way to make the definition itself an AGPR; the compiler does not count these loads, hence
-  // the explicit wait.)
+  // the register file belongs to the accumulators and the streamed fragments.
   bf16x8 A[kBdRowTiles][3][3];
   {
     const uint4* src = reinterpret_cast<const uint4*>(a.bfv_frag) + vtile0 * 9 * 64 + lane;
@@ -583,66 +621,82 @@ __global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
   }
   f32x16 acc0[3], acc1[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) acc1[j] = f32x16{0};
-  float thr_prev = -__builtin_inff();                   // threshold row of acc1's columns; -inf: nothing owed
-  int32_t ic_prev = 0;
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc1[j][g] = __uint_as_float(kBdIdleBits);     // "nothing owed": reads as 16 rejected rows
+  const uint32_t off0 = (uint32_t)lane * 16u, off1 = off0 + 4096u, off2 = off0 + 8192u;
+  const char* tiles = reinterpret_cast<const char*>(a.bfa_frag);
   BdTile X, Y;
-  int64_t at = a_begin;
-  bd_issue_side(a, fetch_index(a, at, a_end, r), X);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) bd_issue_feature(a, X.ic, h, j, X);
-  int32_t ic_next = fetch_index(a, at + 32, a_end, r);
-  // one column tile: kBdRowTiles phases on tile CUR while tile NXT streams in behind the MFMAs of the first
-  // three phases (frame numbers are fetched two tiles ahead, so no load waits for another)
+  int64_t t = t_begin;
+  bd_issue<0, 9>(X, tiles + t * 9216, off0, off1, off2);
+  uint32_t acol_prev = 0;
+  // one column tile: kBdRowTiles phases on tile CUR while tile NXT streams in behind the MFMAs of phases 1 .. 3
   auto run_tile = [&](BdTile& CUR, BdTile& NXT) {
-    bd_retire(CUR);
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-      if (h) reinterpret_cast<uint32_t*>(&CUR.frag[j][2])[1] = CUR.nrm[j];      // K slots 42 / 43 carry the audio norm
-    // the patched words are MFMA sources: keep the patch here (an MFMA may read a VALU result two wait states later at the earliest)
-    asm volatile("s_nop 1" : "+v"(CUR.frag[0][2]), "+v"(CUR.frag[1][2]), "+v"(CUR.frag[2][2]));
-    __builtin_amdgcn_sched_barrier(0);
-#ifdef DA_DBG_BF_NOTHR
-    const float thr_cur = ((at + r) < a_end) ? -a.thr * CUR.prod : -__builtin_inff();
-#else
-    const float thr_cur = ((at + r) < a_end) ? a.thr * CUR.prod : -__builtin_inff();
-#endif
-    asm volatile("" ::"v"(ic_next));
-    const int32_t icn = ic_next;
+    const void* nxt = tiles + (t + 1) * 9216;                      // one tile past the stripe at its end: inside the padded buffer, never used
+    const uint32_t acol = (uint32_t)(t << 5) + (uint32_t)r;
 #pragma unroll
     for (int rt = 0; rt < kBdRowTiles; ++rt) {
-      uint32_t mask = 0;
+      uint32_t codes = 0;
       auto extra = [&](int m) {
-        // the next tile's loads go into the lightest slot (two epilogue instructions) of the first four phases
-        if (rt == 0 && m == kBdLoadSlot) { bd_issue_side(a, icn, NXT); ic_next = fetch_index(a, at + 64, a_end, r); }
-        if (rt == 1 && m == kBdLoadSlot) bd_issue_feature(a, icn, h, 0, NXT);
-        if (rt == 2 && m == kBdLoadSlot) bd_issue_feature(a, icn, h, 1, NXT);
-        if (rt == 3 && m == kBdLoadSlot) bd_issue_feature(a, icn, h, 2, NXT);
+#ifndef DA_DBG_BF_NOLOAD
+        if (rt == 1 && m == 0) bd_issue<0, 3>(NXT, nxt, off0, off1, off2);
+        if (rt == 2 && m == 0) bd_issue<3, 6>(NXT, nxt, off0, off1, off2);
+        if (rt == 3 && m == 0) bd_issue<6, 9>(NXT, nxt, off0, off1, off2);
+#endif
       };
-      const float thr_p = rt == 0 ? thr_prev : thr_cur;            // the epilogue in flight belongs to the phase before
-      if (rt & 1) bd_phase(A[rt], CUR.frag, acc1, acc0, thr_p, mask, extra);
-      else bd_phase(A[rt], CUR.frag, acc0, acc1, thr_p, mask, extra);
-      bf_emit(sk, h, vtile0 + (rt == 0 ? kBdRowTiles - 1 : rt - 1), mask, rt == 0 ? ic_prev : CUR.ic);
+#ifdef DA_DBG_BF_NOLOAD
+      constexpr bool kWaitFirst = false;
+#else
+      constexpr bool kWaitFirst = true;
+#endif
+      if (rt == 0) bd_phase<kWaitFirst>(A[rt], CUR.frag, acc0, acc1, codes, extra);
+      else if (rt & 1) bd_phase<false>(A[rt], CUR.frag, acc1, acc0, codes, extra);
+      else bd_phase<false>(A[rt], CUR.frag, acc0, acc1, codes, extra);
+#ifdef DA_DBG_BF_NOEMIT
+      asm volatile("" ::"v"(codes));
+#else
+      // the epilogue in flight belongs to the phase before: the last row tile of the previous column tile when rt == 0
+      bf_emit(sk, h, vtile0 + (rt == 0 ? kBdRowTiles - 1 : rt - 1), codes, rt == 0 ? acol_prev : acol);
+#endif
     }
-    thr_prev = thr_cur; ic_prev = CUR.ic;
+    acol_prev = acol;
     if (sk.count > kBdSurv - 64 * kBdRowTiles) sink_flush(sk, a, lane);
-    at += 32;
+    ++t;
   };
+#ifdef DA_DBG_BF_NOLOAD
+  bd_issue<0, 9>(Y, tiles + t * 9216, off0, off1, off2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   while (true) {
     run_tile(X, Y);
-    if (at >= a_end) break;
+    if (t >= t_end) break;
     run_tile(Y, X);
-    if (at >= a_end) break;
+    if (t >= t_end) break;
   }
   {                                                                // drain: the last tile's last row tile
     // the last MFMAs have left the pipe before the accumulators are read (tied to them, so that the reads cannot be moved above the wait)
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]));
-    uint32_t mask = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the request past the last tile: nobody reads it, but it must not outlive its registers
+    uint32_t codes = 0;
 #pragma unroll
-    for (int g = 15; g >= 0; --g) bf_row(acc1, g, thr_prev, mask);
-    bf_emit(sk, h, vtile0 + kBdRowTiles - 1, mask, ic_prev);
+    for (int g = 15; g >= 0; --g) bf_row(acc1, g, codes);
+    bf_emit(sk, h, vtile0 + kBdRowTiles - 1, codes, acol_prev);
   }
   sink_flush(sk, a, lane);
+}
+
+// Scales c_j for the threshold `thr` (see the header comment of this section): the bound
+// 2^23 (381 + log2(thr c_0 c_1 c_2)) on the pattern sum of an accepted pair must stay below 2^30, so
+// log2(c_0 c_1 c_2) < -253 - log2(thr).  c_0 = c_1 = a power of two, c_2 rounded DOWN to a bf16 number
+// (7 fraction bits): the scales themselves are exact operands.
+void bf16_gemm_scales(double thr, float out[3]) {
+  const double L = -253.0 - std::log2(thr) - 1e-6;
+  const int e01 = (int)std::floor(L / 3.0);
+  const double l2 = L - 2.0 * e01;
+  const int e2 = (int)std::floor(l2);
+  const double mant = std::floor(std::exp2(l2 - e2) * 128.0) / 128.0;
+  out[0] = out[1] = (float)std::ldexp(1.0, e01);
+  out[2] = (float)std::ldexp(mant, e2);
 }
 
 static dim3 match_grid(const MatchArgs& a) {
@@ -669,12 +723,14 @@ void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   if ((atiles + tpb - 1) / tpb > 65535) tpb = (atiles + 65534) / 65535;
   b.audio_tiles_per_block = (int)tpb;
   hipLaunchKernelGGL(k_bf16_video_frags, dim3((unsigned)b.bfv_tiles), dim3(64), 0, s, b);
+  hipLaunchKernelGGL(k_bf16_audio_frags, dim3((unsigned)b.bfa_tiles), dim3(64), 0, s, b);
   hipLaunchKernelGGL(k_match_bf16, dim3((unsigned)bx, (unsigned)((atiles + tpb - 1) / tpb)), dim3(64 * kBdWaves), 0, s, b);
 }
 
 // diagnostics: the raw MFMA accumulators of ONE (32 video rows x 32 audio columns) tile, formed with
-// the production kernels' own operand construction and instruction sequence (K permutation, norm
-// slots, bf16 rounding, per-feature row rotation): out[j][row][col] = |A|_j(col) (1 - corr_j(row, col)).
+// the production kernels' operands and instruction sequence (f32: the same operand construction; bf16: the
+// very fragment streams k_match_bf16 read in the last launch): out[j][row][col] = |A|_j(col) (1 - corr_j(row, col))
+// for f32, and (1 - guard - corr_j(row, col)) for bf16 (the accumulator divided by its scale c_j).
 // One wavefront.  The matrix instructions are deterministic, so these are the values the threshold
 // epilogue of k_match_f32 / k_match_bf16 sees for that tile.
 __global__ __launch_bounds__(64) void k_dump_tile(MatchArgs a, int64_t vtile, int64_t atile, int bf16, float* __restrict__ out,
@@ -706,34 +762,16 @@ __global__ __launch_bounds__(64) void k_dump_tile(MatchArgs a, int64_t vtile, in
       for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j][s], b[j][s], acc[j], 0, 0, 0);
     if (h == 0) { vframes[r] = vok ? v : -1; aframes[r] = (at + r) < a.n_a ? ic : -1; }
   } else {
-    bf16x8 A[3][3], B[3][3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int64_t vr = vtile * 32 + bf_arow(r, j);
-      const bool vok = vr < a.n_v;
-      const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
-      const double sc = vok ? -(double)a.inv_v[j][v] : 0.0;
-      const double* p = a.msd_v[j] + v;
-      const uint32_t pk = a.nrmpk_a[j][ic];
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int k = 24 * h + 8 * s + e;
-          uint16_t x = 0;
-          if (k < kWin) x = f32_to_bf16((float)(p[k] * sc));
-          else if (k == 42 || k == 43) x = 0x3F80;
-          A[j][s][e] = (short)x;
-          uint16_t y = a.bfa_even[j][ic + k];                         // what the LDS-DMA stages (either copy holds the same values)
-          if (k == 42) y = (uint16_t)(pk & 0xFFFFu);                  // the producers' norm patch: hi, lo halves of |A|
-          if (k == 43) y = (uint16_t)(pk >> 16);
-          B[j][s][e] = (short)y;
-        }
-    }
+    // the production operands themselves: the fragment streams the last launch built (k_bf16_video_frags / k_bf16_audio_frags)
+    const uint4* va = reinterpret_cast<const uint4*>(a.bfv_frag) + vtile * 9 * 64 + lane;
+    const uint4* au = reinterpret_cast<const uint4*>(a.bfa_frag) + atile * 9 * 64 + lane;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][s], B[j][s], acc[j], 0, 0, 0);
+      for (int s = 0; s < 3; ++s) {
+        const uint4 x = va[(3 * j + s) * 64], y = au[(3 * j + s) * 64];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&x), *reinterpret_cast<const bf16x8*>(&y), acc[j], 0, 0, 0);
+      }
     if (h == 0) {
       const int64_t vr = vtile * 32 + r;
       vframes[r] = vr < a.n_v ? a.vlist[vr] : -1;
@@ -745,7 +783,7 @@ __global__ __launch_bounds__(64) void k_dump_tile(MatchArgs a, int64_t vtile, in
     const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      out[(j * 32 + row) * 32 + r] = bf16 ? acc[j][bf_rot(g, j)] : acc[j][g];
+      out[(j * 32 + row) * 32 + r] = bf16 ? acc[j][bf_rot(g, j)] / a.cscale[j] : acc[j][g];
   }
 }
 void launch_dump_tile(const MatchArgs& a, int64_t vtile, int64_t atile, int bf16, float* d_out, int32_t* d_vframes, int32_t* d_aframes,
@@ -767,15 +805,15 @@ __global__ void k_corr(CorrArgs c) {
       const float sc = -c.m.inv_v[j][v];
       for (int k = 0; k < kWin; ++k) acc = fmaf(c.m.ms_v[j][v + k] * sc, c.m.ms_a[j][i + k], acc);
     } else {
-      const double sc = -(double)c.m.inv_v[j][v];
+      const double sc = -1.0 / c.m.nrmd_v[j][v], sa = 1.0 / c.m.nrmd_a[j][i];
       for (int k = 0; k < kWin; ++k) {
         const uint16_t ab = f32_to_bf16((float)(c.m.msd_v[j][v + k] * sc));
-        const uint16_t bb = c.m.bfa_even[j][i + k];
+        const uint16_t bb = f32_to_bf16((float)(c.m.msd_a[j][i + k] * sa));
         const float af = __uint_as_float((uint32_t)ab << 16), bf = __uint_as_float((uint32_t)bb << 16);
         acc = fmaf(af, bf, acc);
       }
     }
-    c.corr[3 * p + j] = -acc * c.m.inv_a[j][i];
+    c.corr[3 * p + j] = c.precision == 0 ? -acc * c.m.inv_a[j][i] : -acc;
   }
 }
 void launch_corr(const CorrArgs& a, hipStream_t s) {
@@ -845,13 +883,19 @@ __global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyArgs a, unsigne
   for (unsigned long long rnd = 0; rnd < rounds; ++rnd) {
     const unsigned long long p = rnd * stride + (unsigned long long)blockIdx.x * kVerifyThreads + threadIdx.x;
     const unsigned long long rec = (p < n_rec) ? a.surv[p] : 0ull;
-    const int32_t i = (int32_t)(rec >> 41);
+    // f32 GEMM records: audio frame | video tile | lane half | accept bit per accumulator register;
+    // bf16 GEMM records: position in the audio row list | video tile | lane half | REJECT bits in bf_emit's order
+    const bool coded = a.alist != nullptr;
+    int32_t i = (int32_t)(rec >> 41);
     const int64_t vtile = (int64_t)((rec >> 17) & 0xFFFFFFull);
     const int h = (int)((rec >> 16) & 1ull);
     uint32_t mask = (uint32_t)(rec & 0xFFFFull);
+    if (coded) { mask ^= 0xFFFFu; if (i < a.n_a) i = a.alist[i]; else mask = 0u; }
+    if (p >= n_rec) mask = 0u;
     while (mask != 0u) {                                              // step 1: expand + vote
-      const int g = __ffs(mask) - 1;
+      const int b = __ffs(mask) - 1;
       mask &= mask - 1u;
+      const int g = coded ? bf_bit_row(b) : b;
       const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
       const int64_t vr = vtile * 32 + row;
       if (vr < a.n_v) {

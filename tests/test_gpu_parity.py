@@ -131,8 +131,9 @@ def test_dense_mode_is_superset_and_matches_oracle_threshold(ctx, a40):
 def test_similarity_values_vs_fp64(ctx, ctx_bf16, native, a40, prec, tol):
   """north_star: similarity values within 1e-3 relative (fp32 GEMM).  Checked on the matrix cores'
   own accumulators: da_match_dump_tile returns, for whole 32 x 32 tiles, what the threshold epilogue
-  of k_match_f32 / k_match_bf16 sees -- |A|_j (1 - corr_j), formed with the production operand
-  layout and MFMA sequence -- against the float64 correlation of the oracle.  bf16 inputs are a
+  of k_match_f32 / k_match_bf16 sees -- f32: |A|_j (1 - corr_j), formed with the production operand
+  layout and MFMA sequence; bf16: 1 - guard - corr_j, formed from the very fragment streams the last
+  k_match_bf16 launch read -- against the float64 correlation of the oracle.  bf16 inputs are a
   prefilter only (everything is re-verified in float64); their tolerance is 2e-2 absolute."""
   g, vf, af = a40
   c = ctx if prec == "f32" else ctx_bf16
@@ -155,13 +156,13 @@ def test_similarity_values_vs_fp64(ctx, ctx_bf16, native, a40, prec, tol):
     corr64, _, _ = O.verify(ii, vv, ms_v, nv, ms_a, na)                 # [pairs][3]
     corr64 = corr64.reshape(len(cols), len(rows), 3)
     for j in range(3):
-      norm_a = na[j][afr[cols]]
+      norm_a = na[j][afr[cols]] if prec == "f32" else np.ones(len(cols))
       got = 1.0 - acc[j][np.ix_(rows, cols)].astype(np.float64) / norm_a[None, :]       # [rows][cols]
       want = corr64[:, :, j].T
       if prec == "f32":
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-5, err_msg=f"tile {vt},{at} feature {j}")
       else:
-        # the bf16 norm slot carries |A| (1 - guard): the accumulator is |A| (1 - guard - corr) + rounding, and the
+        # the bf16 norm slot carries 1 - guard: the accumulator is 1 - guard - corr + rounding, and the
         # guard is a proven bound on that rounding -- so the prefilter never over-estimates 1 - corr (superset property)
         assert np.all(got >= want - 1e-6), f"tile {vt},{at} feature {j}: bf16 accumulator above the exact value"
         np.testing.assert_allclose(got - native.BF16_GUARD, want, rtol=0, atol=tol, err_msg=f"tile {vt},{at} feature {j}")
@@ -172,7 +173,7 @@ def test_similarity_values_vs_fp64(ctx, ctx_bf16, native, a40, prec, tol):
   acc, vfr, afr = c.match_dump_tile(0, 0)
   side = c.match_corr(np.repeat(afr[:4], 4), np.tile(vfr[:4], 4))
   for j in range(3):
-    tile = 1.0 - acc[j][:4, :4] / na[j][afr[:4]][None, :]
+    tile = 1.0 - acc[j][:4, :4] / (na[j][afr[:4]][None, :] if prec == "f32" else 1.0)
     np.testing.assert_allclose(side[:, j].reshape(4, 4).T, tile, atol=2e-3 if prec == "f32" else 3e-2)
 
 
@@ -317,6 +318,49 @@ def test_chain_rejects_nonpositive_quality(ctx):
     ctx.chain(i, v, q)
 
 
+def test_chain_rejects_nan_and_infinite_quality_on_the_column_path(ctx):
+  """The column kernel orders sums by their bit patterns (ds_max_u64): a NaN or an infinity must be refused by
+  the validation kernel, which is compiled with -ffinite-math-only and therefore tests the bit pattern."""
+  n = 5000
+  i = np.arange(n, dtype=np.int32); v = np.arange(n, dtype=np.int32)
+  for bad in (np.nan, np.inf, -1.0, -0.0, 1e301):
+    q = np.ones(n); q[n // 2] = bad
+    with pytest.raises(RuntimeError, match="positive"):
+      ctx.chain(i, v, q)
+  q = np.full(n, 5e-324)                                    # the smallest positive double is a legal quality
+  gi, gv = ctx.chain(i, v, q)
+  assert len(gi) == n
+
+
+def test_imported_match_with_an_unlisted_video_frame_is_refused_cleanly(ctx):
+  """da_match_import_device with a key whose video frame is not one of the matched rows: the rank map has no
+  rank for it.  The column path used to turn rank 0 into column 65535 and write far past col_start[]; now the
+  match is clamped to rank 1, the DP runs inside its arrays and the host reports DA_ERR_ARG.  The resident
+  buffers of the context stay intact: the same list without the bad key gives the right path afterwards."""
+  import torch
+  pair = cases.align_case("e180")
+  vf = ctx.features(pair.video, 0); af = ctx.features(pair.audio, 1)
+  mi, mv, mq = ctx.match(vf, af)
+  n = len(mi)
+  want = ctx.chain(mi, mv, mq)
+  keys = (mi.astype(np.int64) << 32) | mv
+  listed = set(O.video_rows(vf[0]).tolist())
+  k = n // 2
+  bad_v = next(x for x in range(int(mv[k]) + 1, int(mv[k]) + 8) if x not in listed)      # rows are every 4th non-quiet frame
+  bad = keys.copy(); bad[k] = (int(mi[k]) << 32) | bad_v
+  bad = np.sort(bad)
+  for arr, ok in ((bad, False), (keys, True)):
+    ctx.match(vf, af)                                       # the row list that ranks the imported matches
+    tk = torch.from_numpy(arr).cuda(); tq = torch.from_numpy(mq).cuda()
+    ctx.match_import_device(tk.data_ptr(), tq.data_ptr(), n)
+    if ok:
+      gi, gv = ctx.chain_resident()
+      assert np.array_equal(gi, want[0]) and np.array_equal(gv, want[1])
+    else:
+      with pytest.raises(RuntimeError, match="outside the matched rows"):
+        ctx.chain_resident()
+
+
 def test_chain_mismatch_error(ctx):
   i = np.arange(10, dtype=np.int32); v = np.arange(10, dtype=np.int32); q = np.ones(10)
   with pytest.raises(RuntimeError, match="Alignment failed, are the input files mismatched"):
@@ -361,6 +405,16 @@ def test_end_to_end_from_pcm(ctx, ctx_bf16, name, prec):
   assert len(x) == len(g["x"])
   assert np.max(np.abs(x - g["x"])) < HOP_S and np.max(np.abs(y - g["y"])) < HOP_S
   assert abs(sim - float(g["sim"])) < 0.5 and abs(med - float(g["med"])) < 1e-4
+  # the pass-2 path itself against the reference's (every 20th row was recorded, which is also what the reference
+  # plots, :179): same number of rows; video / audio positions (seconds) and line cluster of every recorded row
+  # equal -- index work --, qualities and running sums to 1e-3 (float32 feature rows differ from the reference's
+  # by summation order, 2e-6 relative, and reach these through log10 of small differences)
+  assert len(path) == int(g["path_rows"])
+  got20, want20 = np.asarray(path)[::20], g["path20"]
+  assert got20.shape == want20.shape
+  np.testing.assert_allclose(got20[:, :2], want20[:, :2], rtol=0, atol=1e-6)
+  assert np.array_equal(got20[:, 2], want20[:, 2])
+  np.testing.assert_allclose(got20[:, 3:], want20[:, 3:], rtol=1e-3, atol=1e-3)
 
 
 def test_mismatched_pair_raises(ctx):

@@ -414,6 +414,38 @@ def test_lp_without_rate_terms_is_certified_or_falls_back(n, seed, rate, second)
     assert abs(ref.fun - float(c @ reduced)) < 1e-6 * max(1.0, abs(ref.fun))
 
 
+def test_lp_retries_with_interior_point_on_status_4_as_the_reference_does(monkeypatch):
+  """describealign.py:843-844: when the dual simplex stops with status 4 (numerical difficulties) the reference
+  solves the same LP again with method='highs-ipm'.  HiGHS does not fail on its own on these LPs, so the first
+  call is made to report status 4: the retry must be the interior-point method on the identical problem, its
+  solution must be used (it is the same optimum to 1e-6 frames), and any other failure must raise the reference's error."""
+  import scipy.optimize
+  from describealign_amd import align as A
+  x, y = _trend_points(600, 3, 0.01, None)
+  want = A.solve_trend_lp(x, y, reduce=False)
+  real = scipy.optimize.linprog
+  calls = []
+
+  def flaky(c, **kw):
+    calls.append(kw.get("method"))
+    fit = real(c, **kw)
+    if len(calls) == 1:
+      fit = scipy.optimize.OptimizeResult(x=None, success=False, status=4, message="forced: numerical difficulties")
+    return fit
+
+  monkeypatch.setattr(scipy.optimize, "linprog", flaky)
+  got = A.solve_trend_lp(x, y, reduce=False)
+  assert calls == ["highs-ds", "highs-ipm"]
+  assert np.abs(got["solution"] - want["solution"]).max() < 1e-6
+  assert abs(got["median_slope"] - want["median_slope"]) < 1e-9
+
+  calls.clear()
+  monkeypatch.setattr(scipy.optimize, "linprog",
+                      lambda c, **kw: scipy.optimize.OptimizeResult(x=None, success=False, status=2, message="forced: infeasible"))
+  with pytest.raises(RuntimeError, match="Smooth Alignment L1-Min Optimization Failed"):
+    A.solve_trend_lp(x, y, reduce=False)
+
+
 def test_stretch_audio_command_lines_follow_the_reference_options():
   """write_replaced_media_to_disk with a media array (describealign.py:468-487): the new stereo
   track is piped in as s16le; with a video it is muxed in front of the original streams and tagged
