@@ -27,8 +27,10 @@ ERR_CAPACITY = -3
 ERR_MISMATCH = -4
 
 EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm_upload", "da_pcm_upload_async", "da_host_alloc", "da_host_free",
+           "da_pcm_stream_open", "da_pcm_stream_piece", "da_pcm_stream_sync", "da_pcm_stream_frames", "da_pcm_stream_error", "da_pcm_adopt",
+           "da_pcm_stream_close",
            "da_features_resident", "da_features", "da_match", "da_match_begin", "da_match_finish", "da_match_fetch",
-           "da_match_corr", "da_trim", "da_match_dump_tile", "da_match_export_device", "da_match_import_device", "da_chain", "da_chain_begin", "da_chain_finish", "da_chain_resident", "da_chain_poll",
+           "da_match_corr", "da_trim", "da_match_dump_tile", "da_match_export_device", "da_match_import_device", "da_match_import_reserve", "da_match_import_commit", "da_chain", "da_chain_begin", "da_chain_finish", "da_chain_resident", "da_chain_poll",
            "da_refine", "da_stats", "da_replace_segments", "da_stretch_resident", "da_stretch_schedule"]
 
 
@@ -84,6 +86,13 @@ def load():
     lib.da_pcm_upload_async.argtypes = [vp, i32, vp, i64, i32, i32]
     lib.da_host_alloc.argtypes = [C.c_size_t, P(vp)]
     lib.da_host_free.argtypes = [vp]
+    lib.da_pcm_stream_open.argtypes = [i32, i32, i64, P(vp)]
+    lib.da_pcm_stream_piece.argtypes = [vp, vp, i64]
+    lib.da_pcm_stream_sync.argtypes = [vp]
+    lib.da_pcm_stream_frames.argtypes = [vp]; lib.da_pcm_stream_frames.restype = i64
+    lib.da_pcm_stream_error.argtypes = [vp]; lib.da_pcm_stream_error.restype = C.c_char_p
+    lib.da_pcm_adopt.argtypes = [vp, i32, vp]
+    lib.da_pcm_stream_close.argtypes = [vp]; lib.da_pcm_stream_close.restype = None
     lib.da_features_resident.argtypes = [vp, i32, vp, i64, P(i64)]
     lib.da_features.argtypes = [vp, vp, i64, i32, i32, vp, i64, P(i64)]
     lib.da_match.argtypes = [vp, vp, i64, P(i64), vp, i64, P(i64), i32, i64, i64, vp, vp, vp, P(i64)]
@@ -94,6 +103,8 @@ def load():
     lib.da_trim.argtypes = [vp]
     lib.da_match_export_device.argtypes = [vp, vp, vp, i64]
     lib.da_match_import_device.argtypes = [vp, vp, vp, i64]
+    lib.da_match_import_reserve.argtypes = [vp, i64, P(vp), P(vp)]
+    lib.da_match_import_commit.argtypes = [vp, i64]
     lib.da_match_dump_tile.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.da_chain.argtypes = [vp, vp, vp, vp, i64, C.c_double, vp, vp, P(i64)]
     lib.da_chain_begin.argtypes = [vp, P(C.c_uint64)]
@@ -141,6 +152,53 @@ def pinned_empty(shape, dtype=np.int16) -> np.ndarray:
   buf = (C.c_uint8 * nbytes).from_address(owner.ptr.value)
   buf._owner = owner                     # every numpy view keeps `buf` (its base) alive, and `buf` the allocation
   return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+
+class PcmStream:
+  """Streaming ingest handle (da_pcm_stream): owned by one decoder thread.  piece() enqueues the host->device
+  copy of interleaved int16 frames (an (n, C) array, ideally a view of pinned_empty memory) and returns at once;
+  the array must stay untouched until sync() has returned.  Context.pcm_adopt takes the device buffer over."""
+
+  def __init__(self, device: int, channels: int, frames_hint: int = 0):
+    self._lib = load()
+    self._h = C.c_void_p()
+    rc = self._lib.da_pcm_stream_open(int(device), int(channels), int(frames_hint), C.byref(self._h))
+    if rc != 0 or not self._h:
+      raise RuntimeError(f"da_pcm_stream_open failed with code {rc} (needs an MI355X / gfx950 device)")
+    self.device, self.channels = int(device), int(channels)
+    self._keep = []
+
+  def _check(self, rc):
+    if rc != 0:
+      msg = self._lib.da_pcm_stream_error(self._h).decode("utf-8", "replace")
+      raise RuntimeError(msg if msg else f"da_pcm_stream error {rc}")
+
+  def piece(self, frames: np.ndarray):
+    frames = np.asarray(frames)
+    if frames.dtype != np.int16 or not frames.flags.c_contiguous or frames.size % self.channels:
+      raise ValueError("a piece is a C-contiguous int16 array of whole interleaved frames")
+    self._check(self._lib.da_pcm_stream_piece(self._h, _ptr(frames), frames.size // self.channels))
+    self._keep.append(frames)                       # alive until the copy has left it
+
+  def sync(self):
+    self._check(self._lib.da_pcm_stream_sync(self._h))
+    self._keep.clear()
+
+  @property
+  def frames(self) -> int:
+    return int(self._lib.da_pcm_stream_frames(self._h))
+
+  def close(self):
+    if self._h:
+      self._lib.da_pcm_stream_close(self._h)
+      self._h = C.c_void_p()
+      self._keep.clear()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
 
 
 def chain_host(i, v, q, min_len: float = 0.0):
@@ -199,22 +257,49 @@ class Context:
       raise RuntimeError(msg if msg else f"libdalign error {rc}")
 
   # ---- features ----------------------------------------------------------------------------
-  def pcm_upload(self, side: int, pcm: np.ndarray):
-    """pcm: int16 (C, N) planar (the reference's array layout) or (N, C) interleaved if
-    given as a C-contiguous (N, C) array with C in {1, 2} and N > 2."""
+  @staticmethod
+  def _pcm_layout(pcm: np.ndarray, allow_copy: bool):
+    """(array to hand to the library, frames, channels, planar) for int16 PCM given as (C, N) planar (the
+    reference's array layout), as C-contiguous (N, C) interleaved frames, or as the (C, N) transposed VIEW of
+    such frames (what media.parse_audio_from_file returns: the decoder's own layout, passed on without a copy)."""
     pcm = np.asarray(pcm)
     if pcm.dtype != np.int16 or pcm.ndim != 2:
       raise ValueError("PCM must be a 2-D int16 array")
-    planar = 1
     if pcm.shape[0] in (1, 2):
       channels, n = pcm.shape
+      if pcm.flags.c_contiguous:
+        return pcm, n, channels, 1
+      if pcm.T.flags.c_contiguous:
+        return pcm.T, n, channels, 0
     elif pcm.shape[1] in (1, 2):
       n, channels = pcm.shape
-      planar = 0
+      if pcm.flags.c_contiguous:
+        return pcm, n, channels, 0
     else:
       raise ValueError("PCM must have 1 or 2 channels")
-    pcm = np.ascontiguousarray(pcm)
-    self._check(self._lib.da_pcm_upload(self._h, side, _ptr(pcm), n, channels, planar))
+    if not allow_copy:
+      raise ValueError("PCM must be C-contiguous (planar (C, N), interleaved (N, C), or the transpose of either)")
+    if pcm.shape[0] in (1, 2):
+      return np.ascontiguousarray(pcm), pcm.shape[1], pcm.shape[0], 1
+    return np.ascontiguousarray(pcm), pcm.shape[0], pcm.shape[1], 0
+
+  def pcm_upload(self, side: int, pcm: np.ndarray):
+    """pcm: int16 (C, N) planar (the reference's array layout) or (N, C) interleaved if
+    given as a C-contiguous (N, C) array with C in {1, 2} and N > 2."""
+    arr, n, channels, planar = self._pcm_layout(pcm, allow_copy=True)
+    self._check(self._lib.da_pcm_upload(self._h, side, _ptr(arr), n, channels, planar))
+    self._n[side] = n
+    self._channels[side] = channels
+    self._rows.pop(side, None)
+    return n, channels
+
+  def pcm_adopt(self, side: int, stream: "PcmStream"):
+    """Take over the device buffer a PcmStream has filled (no copy); the side's next features_resident waits
+    for the last piece on the device.  The stream is left empty, ready for the next file."""
+    n, channels = stream.frames, stream.channels
+    self._check(self._lib.da_pcm_adopt(self._h, side, stream._h))
+    self._inflight[side] = list(stream._keep)        # pieces still in flight stay alive until the features call
+    stream._keep.clear()
     self._n[side] = n
     self._channels[side] = channels
     self._rows.pop(side, None)
@@ -224,19 +309,9 @@ class Context:
     """Enqueue the host->device copy of `pcm` (int16 (C, N) or (N, C), ideally page-locked: see
     pinned_empty) and return at once; the side's next features_resident waits for it on the device.
     `pcm` must stay alive and unchanged until that call has returned (a reference is kept here)."""
-    pcm = np.asarray(pcm)
-    if pcm.dtype != np.int16 or pcm.ndim != 2 or not pcm.flags.c_contiguous:
-      raise ValueError("PCM must be a C-contiguous 2-D int16 array")
-    planar = 1
-    if pcm.shape[0] in (1, 2):
-      channels, n = pcm.shape
-    elif pcm.shape[1] in (1, 2):
-      n, channels = pcm.shape
-      planar = 0
-    else:
-      raise ValueError("PCM must have 1 or 2 channels")
-    self._check(self._lib.da_pcm_upload_async(self._h, side, _ptr(pcm), n, channels, planar))
-    self._inflight[side] = pcm
+    arr, n, channels, planar = self._pcm_layout(pcm, allow_copy=False)
+    self._check(self._lib.da_pcm_upload_async(self._h, side, _ptr(arr), n, channels, planar))
+    self._inflight[side] = arr
     self._n[side] = n
     self._channels[side] = channels
     self._rows.pop(side, None)
@@ -345,6 +420,16 @@ class Context:
     """Make a sorted match list that lives in device memory the resident result of this context
     (chain_begin / chain_resident then run on it)."""
     self._check(self._lib.da_match_import_device(self._h, C.c_void_p(d_keys), C.c_void_p(d_q), int(n)))
+
+  def match_import_reserve(self, n: int):
+    """Device arrays (keys int64 address, qualities float64 address) for n matches that a gather fills in place;
+    match_import_commit(m) makes the first m the resident list.  The list resident so far stays exportable until then."""
+    k, q = C.c_void_p(), C.c_void_p()
+    self._check(self._lib.da_match_import_reserve(self._h, int(n), C.byref(k), C.byref(q)))
+    return int(k.value or 0), int(q.value or 0)
+
+  def match_import_commit(self, n: int):
+    self._check(self._lib.da_match_import_commit(self._h, int(n)))
 
   def match_dump_tile(self, video_tile: int, audio_tile: int):
     """Raw MFMA accumulators |A|_j (1 - corr_j) of one 32 x 32 tile of the last match:

@@ -430,12 +430,14 @@ def align_tiled(video_features, audio_desc_features, video_energy, audio_desc_en
   After matching every rank gives the stage's scratch memory back (da_trim: an 8 h pair's survivor buffer
   is 23 GB per rank).  match_lock: optional context manager held during this rank's matching stage --
   for ranks that SHARE a device (tests, one-GPU emulation of an 8-GPU run) and would not fit side by side."""
-  from .distrib import row_blocks
+  from .distrib import row_blocks_by_load
   ctx = ctx or default_context()
   tm = timings if timings is not None else {}
   n_ve, n_ae = len(video_energy), len(audio_desc_energy)
   t0 = time.perf_counter()
-  rb, re = row_blocks(max(0, n_ae - (2 * NODE_FRAMES - 1)), group.world)[group.rank]
+  # blocks of about equal numbers of non-quiet audio rows (:657-658), the rows that cost anything
+  n_rows = max(0, n_ae - (2 * NODE_FRAMES - 1))
+  rb, re = row_blocks_by_load(np.asarray(audio_desc_energy[:n_rows]) > 0.5, group.world)[group.rank]
   import contextlib
   n_local, match_err = 0, None
   try:

@@ -281,16 +281,24 @@ def process_pair(video_file, audio_desc_file, has_audio_extension, ctx, stretch_
     print("   output file already exists, skipping...")
     return None
   num_channels = 2 if stretch_audio else 1
-  print("  reading video file...\r", end='')
-  video_arr = media.parse_audio_from_file(video_file, num_channels)
-  print("  computing video features... \r", end='')
-  video_features = ctx.features(video_arr, _native.SIDE_VIDEO)      # the PCM stays resident on the GPU
-  del video_arr
-  print("  reading audio file...       \r", end='')
-  audio_desc_arr = media.parse_audio_from_file(audio_desc_file, num_channels)
-  print("  computing audio features...\r", end='')
-  audio_desc_features = ctx.features(audio_desc_arr, _native.SIDE_AUDIO)
-  del audio_desc_arr
+  # decoder pipe -> ring of page-locked pieces -> HBM: every piece's copy is enqueued while the next is being decoded,
+  # and the host never holds a whole file (parse_audio_from_file + the float16 array of :149-157)
+  stream = _native.PcmStream(ctx.device, num_channels)
+  ring = [_native.pinned_empty((media.PIECE_BYTES // 2,), np.int16) for _ in range(3)]
+  try:
+    print("  reading video file...\r", end='')
+    media.stream_file_to_device(stream, video_file, num_channels, ring)
+    ctx.pcm_adopt(_native.SIDE_VIDEO, stream)                       # the PCM stays resident on the GPU
+    print("  computing video features... \r", end='')
+    video_features = ctx.features_resident(_native.SIDE_VIDEO)
+    print("  reading audio file...       \r", end='')
+    media.stream_file_to_device(stream, audio_desc_file, num_channels, ring)
+    ctx.pcm_adopt(_native.SIDE_AUDIO, stream)
+    print("  computing audio features...\r", end='')
+    audio_desc_features = ctx.features_resident(_native.SIDE_AUDIO)
+  finally:
+    stream.close()
+    del ring
   outputs = align(video_features, audio_desc_features, video_features[0], audio_desc_features[0], ctx=ctx)
   return _finish_pair(outputs, video_file, audio_desc_file, has_audio_extension, ctx, output_filename, stretch_audio,
                       no_pitch_correction, alignment_dir)
@@ -368,11 +376,32 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
   held = threading.BoundedSemaphore(max_held)
 
   pool = _PinnedPool()
+  # without --stretch_audio nothing needs the PCM on the host: each decoder thread streams its file through a ring of
+  # page-locked pieces into a device buffer of its own (PcmStream) and the GPU thread adopts that buffer -- no
+  # whole-file host array, no second pass.  (With --stretch_audio the second context uploads the PCM again from the host.)
+  streams, streams_lock, tls = [], threading.Lock(), threading.local()
+
+  def decode_to_device(path):
+    with streams_lock:
+      st = streams.pop() if streams else None
+    if st is None:
+      st = _native.PcmStream(ctx.device, num_channels)
+    if not hasattr(tls, "ring"):
+      tls.ring = [_native.pinned_empty((media.PIECE_BYTES // 2,), np.int16) for _ in range(3)]
+    try:
+      media.stream_file_to_device(st, path, num_channels, tls.ring)
+    except BaseException:
+      st.close()
+      raise
+    return st
 
   def request(k):
     if k < len(work) and k not in decoded:
-      decoded[k] = (decoders.submit(media.parse_audio_from_file, work[k][0], num_channels, pool.alloc),
-                    decoders.submit(media.parse_audio_from_file, work[k][1], num_channels, pool.alloc))
+      if stretch_audio:
+        decoded[k] = (decoders.submit(media.parse_audio_from_file, work[k][0], num_channels, pool.alloc),
+                      decoders.submit(media.parse_audio_from_file, work[k][1], num_channels, pool.alloc))
+      else:
+        decoded[k] = (decoders.submit(decode_to_device, work[k][0]), decoders.submit(decode_to_device, work[k][1]))
 
   def make_job(k):
     def job(c):
@@ -381,6 +410,13 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
       if stretch_audio:
         held.acquire()         # released when pair k's track has been written (below)
       fv, fa = decoded.pop(k)
+      if not stretch_audio:
+        sv, sa = fv.result(), fa.result()
+        c.pcm_adopt(_native.SIDE_VIDEO, sv)
+        c.pcm_adopt(_native.SIDE_AUDIO, sa)
+        with streams_lock:
+          streams.extend((sv, sa))                 # they now hold the buffers of the pair before: the next files' targets
+        return c.features_resident(_native.SIDE_VIDEO), c.features_resident(_native.SIDE_AUDIO)
       video_arr, audio_desc_arr = fv.result(), fa.result()
       if stretch_audio:
         kept[k] = (video_arr, audio_desc_arr)
@@ -418,6 +454,12 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
         if stretch_audio:
           held.release()
   decoders.shutdown(wait=True)
+  for pending in decoded.values():                 # decoded ahead but never consumed (an exception above)
+    for f in pending:
+      if not stretch_audio and f.exception() is None:
+        f.result().close()
+  for st in streams:
+    st.close()
   if stretch_ctx is not None:
     stretch_ctx.close()
   return results

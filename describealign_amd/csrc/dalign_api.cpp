@@ -62,7 +62,7 @@ struct ChainSlot {
   hipStream_t stream = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr, ready = nullptr;
   int64_t n = 0, n_ranks = 0;
-  int state = 0;                  // 0 free, 1 holds the last finished match, 2 chain DP enqueued
+  int state = 0;                  // 0 free, 1 holds the last finished match, 2 chain DP enqueued, 3 reserved for an import
   unsigned long long ticket = 0;
   long long* h_small = nullptr;   // pinned copy of `small`: [0] rows | err << 32, [1] best id, [2] path length
   void release() {
@@ -94,6 +94,7 @@ struct da_ctx {
   DevBuf vlist, alist, surv, counters, keys0, q0, sort_tmp, rankmap, rowscratch, bfv, bfa;
   std::vector<ChainSlot*> slots;  // sorted match lists live in slots (see ChainSlot)
   int res_slot = -1;              // slot holding the results of the last finished match
+  int import_slot = -1;           // slot reserved by da_match_import_reserve (state 3) until da_match_import_commit
   unsigned long long next_ticket = 1;
   int64_t res_lv = 0;             // video frames of the last match (rank map size)
   DevBuf pair_i, pair_v, pair_c;
@@ -303,6 +304,101 @@ int da_pcm_upload_async(da_ctx* c, int side, const int16_t* pcm, int64_t n, int 
   s.upload_pending = true;
   s.n = n; s.channels = channels; s.planar = planar ? 1 : 0;
   s.len[0] = s.len[1] = 0;
+  return DA_OK;
+}
+
+// Streaming ingest: a decoder thread's handle.  Its device buffer and copy queue are its own; a context only
+// ever sees it in da_pcm_adopt, where the buffers are swapped.
+struct da_pcm_stream {
+  int device = 0, channels = 0;
+  int64_t frames = 0;
+  DevBuf buf;
+  hipStream_t q = nullptr;
+  hipEvent_t t0 = nullptr, landed = nullptr;
+  bool started = false;
+  std::string err;
+};
+
+static int stream_fail(da_pcm_stream* st, int code, const char* what, hipError_t e) {
+  if (st) st->err = std::string(what) + ": " + hipGetErrorString(e);
+  return code;
+}
+#define STREAM_TRY(st, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return stream_fail((st), DA_ERR_DEVICE, #call, e_); } while (0)
+
+int da_pcm_stream_open(int device_id, int channels, int64_t frames_hint, da_pcm_stream** out) {
+  if (!out) return DA_ERR_ARG;
+  *out = nullptr;
+  if ((channels != 1 && channels != 2) || frames_hint < 0) return DA_ERR_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return DA_ERR_DEVICE;
+  da_pcm_stream* st = new da_pcm_stream();
+  st->device = device_id; st->channels = channels;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&st->q, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&st->t0) != hipSuccess || hipEventCreate(&st->landed) != hipSuccess ||
+      st->buf.ensure(sizeof(int16_t) * (size_t)frames_hint * channels + 64) != hipSuccess) {
+    da_pcm_stream_close(st);
+    return DA_ERR_DEVICE;
+  }
+  *out = st;
+  return DA_OK;
+}
+
+int da_pcm_stream_piece(da_pcm_stream* st, const int16_t* frames, int64_t n_frames) {
+  if (!st || n_frames < 0 || (n_frames > 0 && !frames)) return DA_ERR_ARG;
+  if (n_frames == 0) return DA_OK;
+  STREAM_TRY(st, hipSetDevice(st->device));
+  const size_t fb = sizeof(int16_t) * (size_t)st->channels;
+  const size_t have = (size_t)st->frames * fb, add = (size_t)n_frames * fb;
+  if (have + add + 64 > st->buf.cap) {                       // the hint was short: grow by half, device to device, in queue order
+    DevBuf bigger;
+    STREAM_TRY(st, bigger.ensure((have + add) + (have + add) / 2 + 64));
+    if (have) STREAM_TRY(st, hipMemcpyAsync(bigger.p, st->buf.p, have, hipMemcpyDeviceToDevice, st->q));
+    STREAM_TRY(st, hipStreamSynchronize(st->q));
+    st->buf.release();
+    st->buf = bigger;
+  }
+  if (!st->started) { STREAM_TRY(st, hipEventRecord(st->t0, st->q)); st->started = true; }
+  STREAM_TRY(st, hipMemcpyAsync(static_cast<char*>(st->buf.p) + have, frames, add, hipMemcpyHostToDevice, st->q));
+  st->frames += n_frames;
+  return DA_OK;
+}
+
+int da_pcm_stream_sync(da_pcm_stream* st) {
+  if (!st) return DA_ERR_ARG;
+  STREAM_TRY(st, hipSetDevice(st->device));
+  STREAM_TRY(st, hipStreamSynchronize(st->q));
+  return DA_OK;
+}
+
+int64_t da_pcm_stream_frames(const da_pcm_stream* st) { return st ? st->frames : -1; }
+const char* da_pcm_stream_error(const da_pcm_stream* st) { return st ? st->err.c_str() : "null stream"; }
+
+void da_pcm_stream_close(da_pcm_stream* st) {
+  if (!st) return;
+  (void)hipSetDevice(st->device);
+  if (st->q) { (void)hipStreamSynchronize(st->q); (void)hipStreamDestroy(st->q); }
+  for (hipEvent_t e : {st->t0, st->landed}) if (e) (void)hipEventDestroy(e);
+  st->buf.release();
+  delete st;
+}
+
+int da_pcm_adopt(da_ctx* c, int side, da_pcm_stream* st) {
+  if (!c) return DA_ERR_ARG;
+  if (side < 0 || side > 1 || !st) return fail(c, DA_ERR_ARG, "da_pcm_adopt: bad argument");
+  if (st->device != c->device) return fail(c, DA_ERR_ARG, "da_pcm_adopt: the stream lives on device %d, the context on %d", st->device, c->device);
+  HIP_TRY(c, hipSetDevice(c->device));
+  Side& s = c->side[side];
+  if (!s.up0) { HIP_TRY(c, hipEventCreate(&s.up0)); HIP_TRY(c, hipEventCreate(&s.up1)); }
+  // the side's kernels may still be reading its old buffer (it becomes the stream's next target): the context
+  // owns that order -- every kernel reading PCM is followed by a stream synchronisation inside the call that launched it
+  if (!st->started) HIP_TRY(c, hipEventRecord(st->t0, st->q));
+  HIP_TRY(c, hipEventRecord(st->landed, st->q));
+  std::swap(s.pcm, st->buf);
+  std::swap(s.up0, st->t0); std::swap(s.up1, st->landed);    // up0 .. up1 bracket the pieces: da_stats().h2d_ms as for da_pcm_upload_async
+  s.upload_pending = true;
+  s.n = st->frames; s.channels = st->channels; s.planar = 0;
+  s.len[0] = s.len[1] = 0;
+  st->frames = 0; st->started = false;
   return DA_OK;
 }
 
@@ -656,22 +752,39 @@ extern "C" int da_match_export_device(da_ctx* c, uint64_t* d_keys, double* d_q, 
   return DA_OK;
 }
 
-extern "C" int da_match_import_device(da_ctx* c, const uint64_t* d_keys, const double* d_q, int64_t n) {
+// Import of a gathered match list in two steps, so that the gather can land IN the slot (multi-GPU long-pair mode:
+// rank 0 posts its receives straight into these buffers): reserve -> fill the returned device arrays -> commit.
+extern "C" int da_match_import_reserve(da_ctx* c, int64_t n, uint64_t** d_keys, double** d_q) {
   if (!c) return DA_ERR_ARG;
   if (!c->match_ready || !c->rows_of_resident)
-    return fail(c, DA_ERR_STATE, "da_match_import_device: call da_match on this context first (its video row list ranks the matches)");
-  if (n < 0 || (n > 0 && (!d_keys || !d_q))) return fail(c, DA_ERR_ARG, "da_match_import_device: bad argument");
+    return fail(c, DA_ERR_STATE, "da_match_import_reserve: call da_match on this context first (its video row list ranks the matches)");
+  if (n < 0 || !d_keys || !d_q) return fail(c, DA_ERR_ARG, "da_match_import_reserve: bad argument");
   HIP_TRY(c, hipSetDevice(c->device));
-  if (c->res_slot >= 0 && c->slots[c->res_slot]->state == 1) c->slots[c->res_slot]->state = 0;
-  c->res_slot = -1;
+  if (c->import_slot >= 0 && c->slots[c->import_slot]->state == 3) c->slots[c->import_slot]->state = 0;   // an abandoned reservation
+  c->import_slot = -1;
   const int si = acquire_slot(c);
-  if (si < 0) return fail(c, DA_ERR_STATE, "da_match_import_device: all chain slots are in flight");
+  if (si < 0) return fail(c, DA_ERR_STATE, "da_match_import_reserve: all chain slots are in flight");
   ChainSlot& sl = *c->slots[si];
   const size_t nn = (size_t)std::max<int64_t>(1, n);
   HIP_TRY(c, sl.keys.ensure(sizeof(uint64_t) * nn)); HIP_TRY(c, sl.q.ensure(sizeof(double) * nn));
+  sl.state = 3;                                             // reserved: not free, not yet a match list
+  sl.n = n;
+  c->import_slot = si;
+  *d_keys = sl.keys.as<uint64_t>(); *d_q = sl.q.as<double>();
+  return DA_OK;
+}
+
+extern "C" int da_match_import_commit(da_ctx* c, int64_t n) {
+  if (!c) return DA_ERR_ARG;
+  if (c->import_slot < 0 || c->slots[c->import_slot]->state != 3) return fail(c, DA_ERR_STATE, "da_match_import_commit: no da_match_import_reserve pending");
+  ChainSlot& sl = *c->slots[c->import_slot];
+  if (n < 0 || n > sl.n) return fail(c, DA_ERR_ARG, "da_match_import_commit: %lld matches, %lld reserved", (long long)n, (long long)sl.n);
+  HIP_TRY(c, hipSetDevice(c->device));
+  // the list the context held so far (this rank's own block, usually already copied into the new one) goes
+  if (c->res_slot >= 0 && c->slots[c->res_slot]->state == 1) c->slots[c->res_slot]->state = 0;
+  c->res_slot = -1;
+  const size_t nn = (size_t)std::max<int64_t>(1, n);
   if (n > 0) {
-    HIP_TRY(c, hipMemcpyAsync(sl.keys.p, d_keys, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(sl.q.p, d_q, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, c->keys0.ensure(sizeof(uint64_t) * nn));
     launch_unpack_keys(sl.keys.as<unsigned long long>(), n, c->keys0.as<int32_t>(), c->keys0.as<int32_t>() + n, c->stream);
     HIP_TRY(c, hipGetLastError());
@@ -685,11 +798,24 @@ extern "C" int da_match_import_device(da_ctx* c, const uint64_t* d_keys, const d
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   sl.n = n; sl.n_ranks = c->pend_nv; sl.state = 1;
   sl.rows_hint = (int64_t)n_rows;
-  c->res_slot = si;
+  c->res_slot = c->import_slot; c->import_slot = -1;
   c->n_match_resident = (unsigned long long)n;
   c->st.matches = (double)n;
   c->fetch_ready = true;
   return DA_OK;
+}
+
+extern "C" int da_match_import_device(da_ctx* c, const uint64_t* d_keys, const double* d_q, int64_t n) {
+  if (!c) return DA_ERR_ARG;
+  if (n < 0 || (n > 0 && (!d_keys || !d_q))) return fail(c, DA_ERR_ARG, "da_match_import_device: bad argument");
+  uint64_t* k = nullptr; double* q = nullptr;
+  int rc = da_match_import_reserve(c, n, &k, &q);
+  if (rc) return rc;
+  if (n > 0) {
+    HIP_TRY(c, hipMemcpyAsync(k, d_keys, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(q, d_q, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return da_match_import_commit(c, n);
 }
 
 // Give back the scratch memory of the matching stage (survivor records, unsorted matches, sort and

@@ -414,7 +414,7 @@ constexpr int kBdWaves = 4;
 constexpr int kBdRows = 32 * kBdRowTiles;
 constexpr int kBdRowsPerBlock = kBdRows * kBdWaves;
 static_assert(kBdRowTiles % 2 == 0 && kBdRowTiles >= 4 && kBfVideoTileGroup % (kBdRowTiles * kBdWaves) == 0, "row tiling");
-constexpr int kBdSurv = 128 * kBdRowTiles;        // a column tile adds at most 64 records per row tile
+constexpr int kBdSurv = 128 * kBdRowTiles + 64;   // a column tile adds at most 64 records per row tile (flush check once per tile, one phase's emit behind)
 constexpr uint32_t kBdAllReject = 0x55555555u;    // code word of 16 rejected rows
 constexpr uint32_t kBdIdleBits = 0x20000000u;     // accumulator pattern whose triple sum reads "reject" (nothing owed)
 
@@ -482,8 +482,9 @@ __device__ __forceinline__ void bd_issue(BdTile& t, const void* tile, uint32_t o
 //      slot 0 carries the next tile's loads instead (`extra`);
 //  (3) nothing but loads ever writes an MFMA source register.
 // profiles/tools/check_mfma_asm_hazards.py checks (2) and (3) on the generated ISA.
-// kWait: this is the first phase of a column tile -- MFMA m waits until at most 8 - m of the wave's vector-memory
-// operations are outstanding, i.e. until fragment m (requested a whole tile ago, oldest first) has landed.
+// kWait: this is the first phase of a column tile -- MFMA m waits until fragment m (requested a whole tile ago, oldest
+// first) has landed; the NEXT tile's nine loads are issued in this same phase (`extra`, behind MFMA 0, 1, 2), as soon as
+// the register set they fill is free, so they have the whole tile -- 54 MFMAs, ~1.3 us -- to arrive.
 template <bool kWait, class Extra>
 __device__ __forceinline__ void bd_phase(const bf16x8 (&A)[3][3], const bf16x8 (&frag)[3][3], f32x16 (&acc)[3],
                                          const f32x16 (&accp)[3], uint32_t& codes, Extra extra) {
@@ -491,16 +492,18 @@ __device__ __forceinline__ void bd_phase(const bf16x8 (&A)[3][3], const bf16x8 (
   for (int m = 0; m < 9; ++m) {
     const int j = m % 3, s = m / 3;
     if (kWait) {
+      // outstanding operations allowed in front of MFMA m: the 8 - m younger fragments of this tile plus the next tile's
+      // loads issued so far in this phase (three behind each of MFMA 0, 1, 2): 8, 10, 12, 14, 13, 12, 11, 10, 9
       switch (m) {
         case 0: asm volatile("s_waitcnt vmcnt(8)"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(7)"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(6)"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(5)"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(3)"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(2)"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(1)"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(10)"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(12)"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(14)"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(13)"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(12)"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(11)"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(10)"); break;
+        default: asm volatile("s_waitcnt vmcnt(9)"); break;
       }
     }
     if (s == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[j]) : "a"(A[j][s]), "v"(frag[j][s]));
@@ -630,8 +633,11 @@ __global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
   int64_t t = t_begin;
   bd_issue<0, 9>(X, tiles + t * 9216, off0, off1, off2);
   uint32_t acol_prev = 0;
-  // one column tile: kBdRowTiles phases on tile CUR while tile NXT streams in behind the MFMAs of phases 1 .. 3
+  // one column tile: kBdRowTiles phases on tile CUR while tile NXT streams in (requested in the first phase)
   auto run_tile = [&](BdTile& CUR, BdTile& NXT) {
+    // survivors go out BEFORE the next loads are requested: the flush's stores are then older than every load the
+    // fragment waits below count, instead of sitting between them and holding vmcnt up for a microsecond
+    if (sk.count > kBdSurv - 64 * (kBdRowTiles + 1)) sink_flush(sk, a, lane);
     const void* nxt = tiles + (t + 1) * 9216;                      // one tile past the stripe at its end: inside the padded buffer, never used
     const uint32_t acol = (uint32_t)(t << 5) + (uint32_t)r;
 #pragma unroll
@@ -639,9 +645,9 @@ __global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
       uint32_t codes = 0;
       auto extra = [&](int m) {
 #ifndef DA_DBG_BF_NOLOAD
-        if (rt == 1 && m == 0) bd_issue<0, 3>(NXT, nxt, off0, off1, off2);
-        if (rt == 2 && m == 0) bd_issue<3, 6>(NXT, nxt, off0, off1, off2);
-        if (rt == 3 && m == 0) bd_issue<6, 9>(NXT, nxt, off0, off1, off2);
+        if (rt == 0 && m == 0) bd_issue<0, 3>(NXT, nxt, off0, off1, off2);
+        if (rt == 0 && m == 1) bd_issue<3, 6>(NXT, nxt, off0, off1, off2);
+        if (rt == 0 && m == 2) bd_issue<6, 9>(NXT, nxt, off0, off1, off2);
 #endif
       };
 #ifdef DA_DBG_BF_NOLOAD
@@ -660,7 +666,6 @@ __global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
 #endif
     }
     acol_prev = acol;
-    if (sk.count > kBdSurv - 64 * kBdRowTiles) sink_flush(sk, a, lane);
     ++t;
   };
 #ifdef DA_DBG_BF_NOLOAD
@@ -716,9 +721,14 @@ void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   MatchArgs b = a;
   const int64_t bx = (a.n_v + kBdRowsPerBlock - 1) / kBdRowsPerBlock;
   const int64_t atiles = (a.n_a + 31) / 32;
-  int64_t want_y = (256 * 12 + bx - 1) / bx;                      // one workgroup per CU at a time: 12 rounds of them (6: 143 ms, 24: 140 ms, 12: 137 ms on the 2 h pair)
-  if (want_y < 1) want_y = 1;
-  int64_t tpb = (atiles + want_y - 1) / want_y;
+  // Stripe of audio column tiles per workgroup.  The streamed operand is 9 KiB per tile and every workgroup of a stripe
+  // reads all of it: a stripe must FIT THE 4 MiB L2 of an XCD, so that whenever a workgroup starts on it, the tiles are
+  // already there (the workgroups of one stripe are dispatched back to back: x runs fastest).  With long stripes
+  // (v8 as first measured: 6 700 tiles = 62 MB) the workgroups of an XCD drift apart and 41 % of the stream misses L2
+  // (FETCH_SIZE 89 GB per launch, 17 % of the wave cycles in s_waitcnt).  Price: the resident operand (55 KB per wave)
+  // is loaded once per stripe instead of once per 12th of the audio side: ~2 % of a 192-tile stripe.
+  int64_t tpb = 192;
+  if (const char* e = std::getenv("DALIGN_BF16_STRIPE_TILES")) tpb = std::atoll(e);
   if (tpb < 1) tpb = 1;
   if ((atiles + tpb - 1) / tpb > 65535) tpb = (atiles + 65534) / 65535;
   b.audio_tiles_per_block = (int)tpb;

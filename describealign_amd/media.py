@@ -1,10 +1,11 @@
 """Minimal PCM ingest for the alignment path.
 
 The reference decodes everything through an ffmpeg child process (describealign.py:149-157).
-Media I/O is outside the accelerated path: this module reads
-44.1 kHz 16-bit WAV / raw s16le directly, and shells out to an `ffmpeg` binary with the
-reference's decode arguments when one is on PATH.  It returns int16 (C, N) -- the integer
-values the reference then holds as float16.
+SURVEY section 8(f) item 1: this module reads 44.1 kHz 16-bit WAV / raw s16le directly and runs an `ffmpeg`
+binary with the reference's decode arguments for everything else, reading its pipe with readinto() into
+page-locked memory: either a ring of pieces whose host->device copies are enqueued as they fill
+(stream_file_to_device: no whole-file host buffer), or one whole-file buffer (parse_audio_from_file, the
+reference's interface: int16 (C, N) -- the integer values the reference then holds as float16).
 """
 from __future__ import annotations
 
@@ -86,33 +87,176 @@ def _read_wav_any_channels(media_file):
     return None
 
 
+def _ffmpeg_decode_command(exe, media_file, num_channels):
+  """The reference's decode (describealign.py:149-153): first audio stream, s16le at 44.1 kHz,
+  aresample=async=1:first_pts=0, downmix to num_channels."""
+  return [exe, "-i", media_file, "-f", "s16le", "-acodec", "pcm_s16le", "-af", "aresample=async=1:first_pts=0",
+          "-map", "0:a:0", "-ac", str(num_channels), "-ar", str(AUDIO_SAMPLE_RATE), "-loglevel", "error", "-"]
+
+
+def _wav_pcm_span(media_file, num_channels):
+  """(byte offset, byte length) of the sample data of a 44.1 kHz 16-bit PCM WAV with num_channels channels, or None
+  when the file is anything else (those go through ffmpeg, see _read_native)."""
+  try:
+    with wave.open(media_file, "rb") as w:
+      if w.getframerate() != AUDIO_SAMPLE_RATE or w.getsampwidth() != 2 or w.getnchannels() != num_channels or w.getcomptype() != "NONE":
+        return None
+      nbytes = w.getnframes() * 2 * num_channels
+      w.setpos(0)
+      # the wave module has parsed the chunks and stands at the first frame: the underlying file's position is the data offset
+      return w.getfp().file.tell() if hasattr(w.getfp(), "file") else None, nbytes
+  except (wave.Error, EOFError, OSError, ValueError, AttributeError):
+    return None
+
+
+class PcmSource:
+  """Interleaved s16le frames of a media file as a byte stream read with readinto() -- straight from the decoder's
+  pipe (or from the file itself for 44.1 kHz 16-bit WAV / raw s16le with the wanted channel count), never through
+  an intermediate `bytes`.  frames_hint: the number of frames when it is known up front (0 otherwise).
+  close() raises the reference's "FFmpeg error." when the decoder failed."""
+
+  def __init__(self, media_file, num_channels):
+    self.media_file, self.num_channels = media_file, num_channels
+    self.frames_hint = 0
+    self._proc = self._file = self._errlog = None
+    self._left = None
+    ext = os.path.splitext(media_file)[1].lower()
+    if ext == ".wav":
+      span = _wav_pcm_span(media_file, num_channels)
+      if span is not None and span[0] is not None:
+        self._file = open(media_file, "rb", buffering=0)
+        self._file.seek(span[0]); self._left = span[1]
+        self.frames_hint = span[1] // (2 * num_channels)
+        return
+    elif ext in (".raw", ".s16le", ".pcm"):
+      size = os.path.getsize(media_file)
+      if size % (2 * num_channels) == 0:
+        self._file = open(media_file, "rb", buffering=0); self._left = size
+        self.frames_hint = size // (2 * num_channels)
+        return
+    exe = find_ffmpeg()
+    if exe is None:
+      raise RuntimeError(f"cannot decode {media_file}: no ffmpeg binary on PATH "
+                         "(only 44.1 kHz 16-bit .wav and raw s16le are read natively)")
+    import tempfile
+    self._errlog = tempfile.TemporaryFile()          # stderr to a file: a full pipe nobody reads would stall the decoder
+    self._proc = subprocess.Popen(_ffmpeg_decode_command(exe, media_file, num_channels), stdout=subprocess.PIPE,
+                                  stderr=self._errlog, stdin=subprocess.DEVNULL, bufsize=0)
+
+  def readinto(self, view) -> int:
+    """Fill `view` (a writable bytes-like object) as far as the stream goes; returns the bytes written (short only at the end)."""
+    mv = memoryview(view).cast("B")
+    got = 0
+    src = self._proc.stdout if self._proc is not None else self._file
+    while got < len(mv):
+      want = len(mv) - got
+      if self._left is not None:
+        want = min(want, self._left)
+        if want == 0:
+          break
+      k = src.readinto(mv[got:got + want])
+      if not k:
+        break
+      got += k
+      if self._left is not None:
+        self._left -= k
+    return got
+
+  def close(self):
+    if self._file is not None:
+      self._file.close(); self._file = None
+    if self._proc is not None:
+      proc, self._proc = self._proc, None
+      proc.stdout.close()
+      rc = proc.wait()
+      self._errlog.seek(0); err = self._errlog.read(); self._errlog.close()
+      if rc != 0:
+        print("  ERROR: ffmpeg failed to parse audio from input file: " + self.media_file)
+        print("FFmpeg error:")
+        print(err.decode("utf-8", "replace"))
+        raise RuntimeError("FFmpeg error.")
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, et, ev, tb):
+    if et is None:
+      self.close()
+    else:                                            # already failing: do not mask the first error
+      try:
+        self.close()
+      except RuntimeError:
+        pass
+
+
+PIECE_BYTES = 64 << 20
+
+
+def stream_file_to_device(stream, media_file, num_channels, ring=None, piece_bytes=PIECE_BYTES) -> int:
+  """parse_audio_from_file (:149-157) without the array: decoder pipe -> a ring of page-locked pieces -> HBM
+  (`stream`: _native.PcmStream).  Each piece's host->device copy is enqueued as soon as the piece is full, so decode
+  and transfer of one file overlap and the host never holds more than the ring (3 x 64 MiB by default, against
+  1.27 GB for a 2 h stereo side).  Returns the frames uploaded; hand the stream to Context.pcm_adopt."""
+  from . import _native
+  fb = 2 * num_channels
+  piece_bytes = max(fb, piece_bytes // fb * fb)
+  if ring is None:
+    ring = [_native.pinned_empty((piece_bytes // 2,), np.int16) for _ in range(3)]
+  k = 0
+  with PcmSource(media_file, num_channels) as src:
+    while True:
+      buf = ring[k % len(ring)]
+      if k >= len(ring):
+        stream.sync()                                # the copies enqueued so far have left the ring
+      got = src.readinto(buf)
+      got -= got % fb                                # a torn last frame is dropped
+      if got:
+        stream.piece(buf[:got // 2].reshape(-1, num_channels))
+      if got < buf.nbytes:
+        break
+      k += 1
+  stream.sync()
+  return stream.frames
+
+
 def parse_audio_from_file(media_file, num_channels=2, alloc=None) -> np.ndarray:
   """describealign.parse_audio_from_file (:149-157) returning the int16 values as int16 (C, N).
   alloc: optional allocator shape -> int16 array the result is written into (combine hands out
-  page-locked buffers, so the upload of this file overlaps the kernels of the previous pair)."""
+  page-locked buffers, so the upload of this file overlaps the kernels of the previous pair).
+  The frames are read from the decoder's pipe straight into that buffer (readinto, no intermediate bytes
+  object) and stay interleaved: the (C, N) array returned is the transposed VIEW of the (N, C) frames, which
+  the upload calls recognise and copy as they are."""
   ext = os.path.splitext(media_file)[1].lower()
-  if ext in (".wav", ".raw", ".s16le", ".pcm"):
-    pcm = _read_native(media_file, ext, num_channels, alloc)
+  if find_ffmpeg() is None and ext == ".wav" and _wav_pcm_span(media_file, num_channels) is None:
+    # no decoder at all: 1 <-> 2 channel WAVs are still usable
+    pcm = _read_wav_any_channels(media_file)
+    pcm = None if pcm is None else _downmix_like_swresample(pcm, num_channels)
     if pcm is not None:
-      return pcm
-  exe = find_ffmpeg()
-  if exe is None:
-    if ext == ".wav":              # no decoder at all: 1 <-> 2 channel WAVs are still usable
-      pcm = _read_wav_any_channels(media_file)
-      pcm = None if pcm is None else _downmix_like_swresample(pcm, num_channels)
-      if pcm is not None:
-        return _deliver(pcm, alloc)
-    raise RuntimeError(f"cannot decode {media_file}: no ffmpeg binary on PATH "
-                       "(only 44.1 kHz 16-bit .wav and raw s16le are read natively)")
-  cmd = [exe, "-i", media_file, "-f", "s16le", "-acodec", "pcm_s16le", "-af", "aresample=async=1:first_pts=0",
-         "-map", "0:a:0", "-ac", str(num_channels), "-ar", str(AUDIO_SAMPLE_RATE), "-loglevel", "error", "-"]
-  res = subprocess.run(cmd, capture_output=True)
-  if res.returncode != 0:
-    print("  ERROR: ffmpeg failed to parse audio from input file: " + media_file)
-    print("FFmpeg error:")
-    print(res.stderr.decode("utf-8", "replace"))
-    raise RuntimeError("FFmpeg error.")
-  return _deliver(np.frombuffer(res.stdout, np.int16).reshape((-1, num_channels)).T, alloc)
+      return _deliver(pcm, alloc)
+  fb = 2 * num_channels
+  make = alloc if alloc is not None else (lambda shape: np.empty(shape, dtype=np.int16))
+  with PcmSource(media_file, num_channels) as src:
+    if src.frames_hint:                              # length known: one buffer, one pass
+      out = make((src.frames_hint, num_channels))
+      got = src.readinto(out)
+      return out[:got // fb].T
+    # length unknown (a decoder pipe): pieces as they come, then one gathering pass into a buffer of the final size
+    pieces, total = [], 0
+    while True:
+      buf = np.empty((PIECE_BYTES // fb, num_channels), dtype=np.int16)
+      got = src.readinto(buf)
+      got -= got % fb
+      if got:
+        pieces.append(buf[:got // fb]); total += got // fb
+      if got < buf.nbytes:
+        break
+  out = make((total, num_channels))
+  at = 0
+  while pieces:
+    p = pieces.pop(0)
+    out[at:at + len(p)] = p; at += len(p)
+    del p                                            # a piece is given back as soon as it has been copied: peak = total + one piece
+  return out.T
 
 
 def write_wav(path, pcm: np.ndarray):

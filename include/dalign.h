@@ -63,6 +63,27 @@ int da_host_alloc(size_t bytes, void** out);
 int da_host_free(void* p);
 int da_pcm_upload_async(da_ctx* ctx, int side, const int16_t* pcm, int64_t n_samples, int channels, int planar);
 
+/* Streaming ingest: decoder pipe -> page-locked pieces -> HBM, with no whole-file host buffer (replaces the
+ * `ffmpeg ... -f s16le -` child + blocking pipe read + cast of describealign.py:123-157; the frames are taken
+ * interleaved, as the decoder emits them).  A da_pcm_stream is owned by ONE thread (a decoder thread) and needs
+ * no context: da_pcm_stream_open reserves device memory for frames_hint frames (it grows on demand, device to
+ * device); da_pcm_stream_piece enqueues the host->device copy of the next n_frames interleaved frames on the
+ * stream's own copy queue and returns at once -- the piece's host buffer must stay untouched until
+ * da_pcm_stream_sync has returned (all pieces enqueued so far have left their host buffers; a ring of a few
+ * page-locked pieces from da_host_alloc is the intended use: read piece k + 2 from the pipe while piece k is in
+ * flight).  da_pcm_adopt hands the device buffer over to `side` of a context in place of da_pcm_upload (no copy:
+ * the buffers are swapped; that side's next da_features_resident waits for the last piece ON THE DEVICE) and
+ * leaves the stream empty, ready for the next file.  da_pcm_stream_close releases everything.
+ * Errors: DA_ERR_ARG / DA_ERR_DEVICE; da_pcm_stream_error returns the message of the last failure. */
+typedef struct da_pcm_stream da_pcm_stream;
+int da_pcm_stream_open(int device_id, int channels, int64_t frames_hint, da_pcm_stream** out);
+int da_pcm_stream_piece(da_pcm_stream* st, const int16_t* frames, int64_t n_frames);
+int da_pcm_stream_sync(da_pcm_stream* st);
+int64_t da_pcm_stream_frames(const da_pcm_stream* st);
+const char* da_pcm_stream_error(const da_pcm_stream* st);
+int da_pcm_adopt(da_ctx* ctx, int side, da_pcm_stream* st);
+void da_pcm_stream_close(da_pcm_stream* st);
+
 /* ---- features -------------------------------------------------------------------------------
  * get_energy + get_zero_crossings + get_freq_bands (describealign.py:545-593) as one fused
  * kernel over the resident PCM of `side`.  feats receives 5 rows (energy, zero crossings,
@@ -115,6 +136,13 @@ int da_match_fetch(da_ctx* ctx, int32_t* out_i, int32_t* out_v, double* out_q, i
  * range): the video row list of that match provides the video ranks. */
 int da_match_export_device(da_ctx* ctx, uint64_t* d_keys, double* d_q, int64_t n);
 int da_match_import_device(da_ctx* ctx, const uint64_t* d_keys, const double* d_q, int64_t n);
+/* The same import in two steps, so that a gather can land IN the context's buffers instead of being copied into
+ * them: da_match_import_reserve returns device arrays for n matches (keys (i << 32 | v), qualities), the caller
+ * fills the first m <= n entries in (i, v) order -- RCCL receives posted straight into them, and
+ * da_match_export_device of this rank's own block --, da_match_import_commit(m) makes them the resident match
+ * list.  The list resident before stays readable (da_match_export_device) until the commit. */
+int da_match_import_reserve(da_ctx* ctx, int64_t n, uint64_t** d_keys, double** d_q);
+int da_match_import_commit(da_ctx* ctx, int64_t n);
 
 /* Release the scratch memory of the matching stage (survivor records, unsorted matches, sort / pass-2
  * scratch, idle chain slots); the resident sorted match list, PCM and feature rows stay.  For long pairs

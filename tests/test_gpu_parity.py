@@ -407,14 +407,16 @@ def test_end_to_end_from_pcm(ctx, ctx_bf16, name, prec):
   assert abs(sim - float(g["sim"])) < 0.5 and abs(med - float(g["med"])) < 1e-4
   # the pass-2 path itself against the reference's (every 20th row was recorded, which is also what the reference
   # plots, :179): same number of rows; video / audio positions (seconds) and line cluster of every recorded row
-  # equal -- index work --, qualities and running sums to 1e-3 (float32 feature rows differ from the reference's
-  # by summation order, 2e-6 relative, and reach these through log10 of small differences)
+  # equal -- index work.  Qualities are -log10(1e-4 + |a - v|) of float32 feature rows that differ from the
+  # reference's by summation order (2e-6 relative): where the two rows nearly agree that difference is a few per
+  # cent of |a - v|, i.e. ~1e-2 in a quality of ~4, and the running sum collects these as a random walk
   assert len(path) == int(g["path_rows"])
   got20, want20 = np.asarray(path)[::20], g["path20"]
   assert got20.shape == want20.shape
   np.testing.assert_allclose(got20[:, :2], want20[:, :2], rtol=0, atol=1e-6)
   assert np.array_equal(got20[:, 2], want20[:, 2])
-  np.testing.assert_allclose(got20[:, 3:], want20[:, 3:], rtol=1e-3, atol=1e-3)
+  np.testing.assert_allclose(got20[:, 3], want20[:, 3], rtol=0, atol=0.1)
+  np.testing.assert_allclose(got20[:, 4], want20[:, 4], rtol=5e-3, atol=0.5)
 
 
 def test_mismatched_pair_raises(ctx):
@@ -515,22 +517,23 @@ def test_tiled_over_rccl_one_rank_equals_untiled_exactly(ctx, tmp_path):
 
 
 @pytest.mark.slow
-def test_tiled_four_hour_pair_eight_ranks_recovers_every_offset():
-  """configs[4] at half its stated length inside the test run: ONE 4 h pair (2.9e8 matches), its matching
-  stage tiled over 8 ranks (processes sharing the one GPU, gloo), gathered, chain DP on the device, LP,
-  pass 2 -- every injected segment found, offsets within one hop of the truth.  (The 8 h / 8 rank run of
-  the same script is recorded in profiles/.)"""
+@pytest.mark.parametrize("seconds,min_matches", [(14400, 1e8), (28800, 5e8)])
+def test_tiled_long_pair_eight_ranks_recovers_every_offset(seconds, min_matches):
+  """configs[4] inside the test run, at half its stated length and AT its stated length: ONE 4 h / 8 h pair
+  (2.9e8 / 1.1e9 matches), its matching stage tiled over 8 ranks (processes sharing the one GPU, gloo; the loop
+  being tiled is describealign.py:658-682), gathered, chain DP on the device, LP, pass 2 -- every injected
+  segment found, offsets within one hop of the truth."""
   import json, subprocess, sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  res = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_tiled_long_pair.py"), "14400", "8"],
-                       capture_output=True, text=True, timeout=1500, env=dict(os.environ, DALIGN_DIST_BACKEND="gloo"))
+  res = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_tiled_long_pair.py"), str(seconds), "8"],
+                       capture_output=True, text=True, timeout=2400, env=dict(os.environ, DALIGN_DIST_BACKEND="gloo"))
   assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
   line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
   r = json.loads(line)
-  assert r["world"] == 8 and r["seconds"] == 14400.0
+  assert r["world"] == 8 and r["seconds"] == float(seconds)
   assert r["nodes"] == 2 * r["segments_expected"], r            # two nodes per constant-offset segment
   assert r["max_offset_err_vs_injected_ms"] < 1e3 * HOP_S, r
-  assert r["matches"] > 1e8 and 50.0 < r["similarity"] <= 100.0, r
+  assert r["matches"] > min_matches and 50.0 < r["similarity"] <= 100.0, r
 
 
 # ------------------------------------------------------------------------------------ properties at size
@@ -861,6 +864,54 @@ def test_async_pinned_upload_equals_blocking_upload(ctx, native):
   for g_, w_ in zip(got_v + got_a, want_v + want_a):
     assert np.array_equal(g_, w_)
   del pv, pa                                            # frees the page-locked memory with the last view
+
+
+def test_streaming_ingest_pipe_to_hbm_equals_blocking_upload(ctx, native, tmp_path, monkeypatch):
+  """SURVEY section 8(f) item 1 / describealign.py:149-157: decoder pipe -> ring of page-locked pieces -> HBM
+  (media.stream_file_to_device + da_pcm_stream_* + da_pcm_adopt).  The feature rows of the adopted buffer equal those
+  of da_pcm_upload of the same PCM -- through the decoder process (a test double, tests/doubles/fake_decoder.py) and
+  for a natively read WAV, with pieces small enough that the ring is reused many times and the device buffer has to
+  grow (the pipe's length is unknown) -- and the host side allocates nothing beyond the ring."""
+  import tracemalloc
+  from describealign_amd import media
+  sys.path.insert(0, os.path.join(ROOT, "tests", "doubles"))
+  import fake_decoder
+  bindir = tmp_path / "bin"; bindir.mkdir()
+  fake_decoder.install(bindir)
+  monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ.get("PATH", ""))
+  rng = np.random.default_rng(3)
+  n = 44100 * 240 + 1234                                              # 4 minutes: 42 MB stereo
+  env = (np.sin(np.arange(n) / 5000.0) * 0.5 + 0.5)
+  st = (rng.integers(-20000, 20000, size=(2, n)) * env).astype(np.int16)
+  media.write_wav(str(tmp_path / "clip.wav"), st)
+  os.link(tmp_path / "clip.wav", tmp_path / "clip.mka")               # same bytes under a name only the decoder takes
+  want = {c: ctx.features(st if c == 2 else ((st[0].astype(np.int32) + st[1] + 1) >> 1).astype(np.int16)[None, :], 0) for c in (1, 2)}
+  piece = 1 << 20
+  ring = [native.pinned_empty((piece // 2,), np.int16) for _ in range(3)]
+  for name, channels in (("clip.mka", 2), ("clip.mka", 1), ("clip.wav", 2)):
+    stream = native.PcmStream(ctx.device, channels)                   # no length hint: grows on the device
+    tracemalloc.start()
+    frames = media.stream_file_to_device(stream, str(tmp_path / name), channels, ring, piece_bytes=piece)
+    _, peak = tracemalloc.get_traced_memory(); tracemalloc.stop()
+    assert frames == n and stream.frames == n
+    assert peak < (4 << 20), f"streaming {name} allocated {peak} bytes on the host (file: {st.nbytes})"
+    ctx.pcm_adopt(1, stream)                                          # side 1 this time
+    assert stream.frames == 0                                         # empty again, reusable
+    got = ctx.features_resident(1)
+    for k in range(5):
+      assert np.array_equal(got[k], want[channels][k]), (name, channels, k)
+    # the same stream object takes the next file (its buffer is now the side's previous one)
+    frames = media.stream_file_to_device(stream, str(tmp_path / "clip.wav"), 2, ring, piece_bytes=piece) if channels == 2 else 0
+    if frames:
+      ctx.pcm_adopt(0, stream)
+      again = ctx.features_resident(0)
+      assert all(np.array_equal(again[k], want[2][k]) for k in range(5))
+    stream.close()
+  # a stream of another channel count than its frames, or torn input, is refused by the binding
+  stream = native.PcmStream(ctx.device, 2)
+  with pytest.raises(ValueError):
+    stream.piece(np.zeros(5, dtype=np.int16))
+  stream.close()
 
 
 def test_bench_launch_contract_two_ranks(tmp_path):

@@ -248,6 +248,51 @@ def test_media_native_reader_only_takes_what_ffmpeg_would_return_untouched(tmp_p
   assert media._read_native(str(tmp_path / "r48.wav"), ".wav", 1) is None
 
 
+def _install_fake_decoder(tmp_path, monkeypatch):
+  sys.path.insert(0, os.path.join(ROOT, "tests", "doubles"))
+  import fake_decoder
+  bindir = tmp_path / "bin"; bindir.mkdir()
+  fake_decoder.install(bindir)
+  monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ.get("PATH", ""))
+
+
+def test_decoder_pipe_is_read_in_place_and_equals_the_reference_array(tmp_path, monkeypatch):
+  """parse_audio_from_file through a decoder process (describealign.py:149-157): the frames are read from the pipe
+  with readinto() -- into one buffer when the length is known, else piece by piece -- and come back as the (C, N)
+  view of the interleaved frames; same values as decoding the WAV natively; a failing decoder raises the reference's
+  error.  The decoder here is a test double (tests/doubles/fake_decoder.py): this image has no ffmpeg."""
+  from describealign_amd import media
+  _install_fake_decoder(tmp_path, monkeypatch)
+  assert media.find_ffmpeg() == str(tmp_path / "bin" / "ffmpeg")
+  rng = np.random.default_rng(11)
+  st = rng.integers(-32768, 32768, size=(2, 300001), dtype=np.int16)
+  media.write_wav(str(tmp_path / "clip.wav"), st)
+  os.rename(tmp_path / "clip.wav", tmp_path / "clip.mka")             # not a name the native reader takes: goes to the decoder
+  monkeypatch.setattr(media, "PIECE_BYTES", 1 << 18)                  # several pieces, a ragged last one
+  got = media.parse_audio_from_file(str(tmp_path / "clip.mka"), 2)
+  assert got.shape == st.shape and got.dtype == np.int16 and np.array_equal(got, st)
+  assert got.T.flags.c_contiguous                                     # the decoder's own layout, not a transposed copy
+  mono = media.parse_audio_from_file(str(tmp_path / "clip.mka"), 1)
+  assert np.array_equal(mono[0], (st[0].astype(np.int32) + st[1] + 1) >> 1)
+  taken = []
+  def alloc(shape):
+    taken.append(shape); return np.empty(shape, dtype=np.int16)
+  again = media.parse_audio_from_file(str(tmp_path / "clip.mka"), 2, alloc)
+  assert taken == [(300001, 2)] and np.array_equal(again, st)
+  # the byte stream itself, in caller-sized bites
+  with media.PcmSource(str(tmp_path / "clip.mka"), 2) as src:
+    buf = np.empty(100003, dtype=np.int16); parts = []
+    while True:
+      k = src.readinto(buf)
+      parts.append(buf[:k // 2].copy())
+      if k < buf.nbytes:
+        break
+  assert np.array_equal(np.concatenate(parts).reshape(-1, 2).T, st)
+  os.rename(tmp_path / "clip.mka", tmp_path / "broken.mka")
+  with pytest.raises(RuntimeError, match="FFmpeg error"):
+    media.parse_audio_from_file(str(tmp_path / "broken.mka"), 2)
+
+
 def test_float16_pcm_full_scale_does_not_wrap():
   """the reference's float16 array holds 32768.0 for samples 32760..32767; converting it
   back for the int16 kernel input must clamp, not wrap to -32768."""
