@@ -725,9 +725,11 @@ void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   // reads all of it: a stripe must FIT THE 4 MiB L2 of an XCD, so that whenever a workgroup starts on it, the tiles are
   // already there (the workgroups of one stripe are dispatched back to back: x runs fastest).  With long stripes
   // (v8 as first measured: 6 700 tiles = 62 MB) the workgroups of an XCD drift apart and 41 % of the stream misses L2
-  // (FETCH_SIZE 89 GB per launch, 17 % of the wave cycles in s_waitcnt).  Price: the resident operand (55 KB per wave)
-  // is loaded once per stripe instead of once per 12th of the audio side: ~2 % of a 192-tile stripe.
-  int64_t tpb = 192;
+  // (FETCH_SIZE 89 GB per launch against 13 GB, +4.5 % time).  Price: the resident operand (55 KB per wave) is loaded
+  // once per stripe instead of once per 12th of the audio side: ~1 % of a 384-tile stripe.  Sweep on a 2 h pair
+  // (profiles/r04_match_bf16_stripes.txt): 96 tiles 27.9 GB, 192: 15.9, 384: 12.8, 768: 9.7, 1536: 9.6, 3072: 20.4,
+  // 6 700: 88.7; kernel time equal within 0.5 % from 192 to 1536 (the MALL catches what a 3.5-7 MB stripe loses in L2).
+  int64_t tpb = 384;
   if (const char* e = std::getenv("DALIGN_BF16_STRIPE_TILES")) tpb = std::atoll(e);
   if (tpb < 1) tpb = 1;
   if ((atiles + tpb - 1) / tpb > 65535) tpb = (atiles + 65534) / 65535;

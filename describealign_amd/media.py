@@ -203,6 +203,16 @@ def stream_file_to_device(stream, media_file, num_channels, ring=None, piece_byt
   if ring is None:
     ring = [_native.pinned_empty((piece_bytes // 2,), np.int16) for _ in range(3)]
   k = 0
+  ext = os.path.splitext(media_file)[1].lower()
+  if find_ffmpeg() is None and ext == ".wav" and _wav_pcm_span(media_file, num_channels) is None:
+    # no decoder at all and the WAV has the other channel count: mixed on the host (parse_audio_from_file), then streamed
+    pcm = parse_audio_from_file(media_file, num_channels)
+    frames = np.ascontiguousarray(pcm.T)
+    step = piece_bytes // fb
+    for at in range(0, len(frames), step):
+      stream.piece(frames[at:at + step])
+    stream.sync()
+    return stream.frames
   with PcmSource(media_file, num_channels) as src:
     while True:
       buf = ring[k % len(ring)]
