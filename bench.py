@@ -277,7 +277,9 @@ class Bench:
                      "algorithmic": "246 flop x (non-quiet audio frames) x (every 4th non-quiet video frame)",
                      "note": "avg_launch_ms = HIP events around the GEMM launches of the TIMED pairs; a rocprofv3 --stats average of the same command "
                              "covers every launch of the run, lead-in included (those pairs are admitted at the GPU's own rate, with the previous pair's "
-                             "chain DP, verify and sort beside every GEMM: ~8 % longer) -- profiles/r03_bench_cfg2_bf16_gemm_by_region.json splits the trace"},
+                             "chain DP, verify and sort beside every GEMM) -- profiles/r03_bench_cfg2_bf16_gemm_by_region.json split such a trace. "
+                             "bf16: the kernel is bound by board power, not by its schedule -- a loop of nothing but its MFMAs on random operands holds "
+                             "1.86 GHz on 256 CUs (2.38 on one) = 0.60-0.66 of the 2.4 GHz dense peak (profiles/r04_issue_microbench.txt, DESIGN.md 4.3)"},
         "feature_stage": {"bound": "hbm", "achieved": acc["feat_bytes"] / (acc["feat_ms"] * 1e-3) / 1e9 if acc.get("feat_ms") else 0.0,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_step": acc["feat_bytes"] / k,
                           "ms_per_step": acc["feat_ms"] / k},
@@ -287,6 +289,10 @@ class Bench:
                             "gpu_match_stage_wall": round(acc["match_s"] / k, 4),
                             "chain_enqueue_to_collected": round(acc["chain_s"] / k, 4)},
         "pipeline": {"lp_worker_processes": workers, "gpu_streams": len(gpu_ctxs), "host_cores": os.cpu_count(),
+                     "worker_count_rationale": "1.5 worker processes per L3 domain of the host (align.default_worker_count): one HiGHS solve of a long pair "
+                                               "wants a whole L3 slice, so the host's solves/s do not grow beyond one worker per domain (configs[2] sweep, "
+                                               "profiles/r04_worker_sweep_cfg2.jsonl: the time per solve grows in proportion to the count), and the half "
+                                               "worker more per domain keeps every domain busy while its neighbour's result is being handed off",
                      "note": "GPU stages of pair k+1 and the device chain DPs of earlier pairs overlap the host LP of pair k; "
                              "results identical to sequential align()"},
         "counts": {"gemm_pairs": acc["gemm_pairs"] / k, "survivors": acc["survivors"] / k, "matches": acc["matches"] / k,
@@ -313,13 +319,19 @@ class Bench:
                            f"this rank's share of the host ({os.cpu_count()} logical CPUs, {world} rank(s): the host's LP capacity does not grow with the GPU count)")
       # HBM traffic of the dominant kernel from the committed PMC profile of this workload (PMC
       # collection needs its own rocprofv3 passes; bench.py itself only times with HIP events)
-      for prof_name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+      for prof_name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
           prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
           key = workload + "_" + prec_name
           if key in prof:
             res["roofline"]["traffic"] = prof[key]["k_match_" + prec_name]["traffic_bytes_per_launch"]
             res["roofline"]["traffic_source"] = f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            # the GEMM's algorithmic output is 12 B per surviving (verified) pair; operand bytes are
+            # negligible by the algorithm.  What the kernel moves beyond that (survivor records of the prefilter, the
+            # explicit operand streams as far as they miss L2) is this ratio -- its design, not the algorithm.
+            alg = 12.0 * acc["matches"] / k
+            res["roofline"]["algorithmic_bytes_per_launch"] = alg
+            res["roofline"]["traffic_over_algorithmic"] = round(res["roofline"]["traffic"] / alg, 2) if alg > 0 else None
             break
         except Exception:
           pass

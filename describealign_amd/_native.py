@@ -432,7 +432,7 @@ class Context:
     self._check(self._lib.da_match_import_commit(self._h, int(n)))
 
   def match_dump_tile(self, video_tile: int, audio_tile: int):
-    """Raw MFMA accumulators |A|_j (1 - corr_j) of one 32 x 32 tile of the last match:
+    """Raw MFMA accumulators (divided by their scale: 1 - corr_j for f32, 1 - guard - corr_j for bf16) of one 32 x 32 tile of the last match:
     (acc[3, 32 rows, 32 cols] float32, video_frames[32], audio_frames[32])."""
     acc = np.empty((3, 32, 32), dtype=np.float32)
     vfr = np.empty(32, dtype=np.int32); afr = np.empty(32, dtype=np.int32)

@@ -56,35 +56,29 @@ struct PrepArgs {
   double* nrm[5];         // window norms, float64 (len-40 valid entries)
   uint32_t* digits[5];    // packed base-7 digits, one nibble per tap (audio: | 0x8888888)
   uint32_t* flags[5];     // video only: ~(probe-next flags at bit 0 of each nibble)
-  float* ms32[3];         // float32 copy of ms (features 0-2), padded
-  float* inv32[3];        // 1/norm as float32
-  float* nrm32[3];        // norm as float32
-  float* prod32;          // nrm0*nrm1*nrm2 as float32 (per-frame threshold scale)
 };
 void launch_prep(const PrepArgs& a, const double* d_hann41n, hipStream_t s);
 
 // ---- similarity GEMM -----------------------------------------------------------------------
 struct MatchArgs {
-  const float* ms_v[3]; const float* ms_a[3];
-  const float* inv_v[3]; const float* inv_a[3];
-  const float* nrm_a[3]; const float* prod_a;                 // audio norms and their product
-  const double* msd_v[3]; const double* msd_a[3];             // bf16 GEMM: float64 rows and norms the operand
+  const double* msd_v[3]; const double* msd_a[3];             // float64 rows and window norms the operand
   const double* nrmd_v[3]; const double* nrmd_a[3];           //   fragments are built from
-  // bf16 GEMM: BOTH operands in MFMA fragment order [tile][feature 3][step 3][lane 64] x 16 B = 9 KiB per 32 rows /
-  // columns (scratch, rebuilt per launch): the video rows scaled by -cscale_j / |V|, the audio columns by 1 / |A|
+  // BOTH operands in MFMA fragment order (scratch, rebuilt per launch), the video rows scaled by -cscale_j / |V|, the
+  // audio columns by 1 / |A|.  bf16: [tile][feature 3][step 3][lane 64] x 16 B = 9 KiB per 32 rows / columns;
+  // f32: [tile][chunk 16][lane 64] x 16 B = 16 KiB (fragment 21 j + s of a lane at chunk (21 j + s) / 4)
   void* bfv_frag; int64_t bfv_tiles;
   void* bfa_frag; int64_t bfa_tiles;
-  float cscale[3];                                            // per-feature scale (exact in bf16) that puts the threshold at 2^30 in the pattern sum
+  float cscale[3];                                            // per-feature scale (a bf16 number) that puts the threshold at 2^30 in the pattern sum
   const int32_t* vlist; int64_t n_v;      // every 4th non-quiet video frame (:629-630)
   const int32_t* alist; int64_t n_a;      // non-quiet audio frames within the requested rows (:657-658)
   unsigned long long* out;                // staged survivor records (see pack_record)
   unsigned long long* out_count;
   unsigned long long capacity;
-  float thr;                              // (1e-8)^(1/2.9) times the precision's safety margin
   int audio_tiles_per_block;
 };
-constexpr int kBfVideoTileGroup = 96;   // bfv_tiles is a multiple of this: a workgroup of the bf16 GEMM owns 16, 24 or 32 row tiles
-constexpr int kBfAudioTilePad = 2;      // bfa_tiles = column tiles + this: the GEMM requests one tile past the one it is working on
+constexpr int kBfVideoTileGroup = 96;   // bfv_tiles is a multiple of this: a workgroup of the GEMMs owns 16 (f32), 24 (bf16) or 32 row tiles
+constexpr int kBfAudioTilePad = 2;      // bfa_tiles = column tiles + this: the GEMMs request one tile past the one they are working on
+constexpr int kBfTileBytes = 9 * 1024, kF32TileBytes = 16 * 1024;
 // per-feature scales of the bf16 GEMM for the threshold `thr` on prod_j (1 - corr_j)
 void bf16_gemm_scales(double thr, float out[3]);
 void launch_match_f32(const MatchArgs& a, hipStream_t s);
@@ -105,7 +99,7 @@ struct VerifyArgs {
   const double* nrm_v[3]; const double* nrm_a[3];
   const uint32_t* dig_v[5]; const uint32_t* flg_v[5]; const uint32_t* dig_a[5];
   int mode;
-  const int32_t* alist; int64_t n_a;      // bf16 GEMM records carry the POSITION in the audio row list and reject bits (see bd_finalize); NULL: f32 records
+  const int32_t* alist; int64_t n_a;      // survivor records carry the POSITION in the audio row list and reject bits (bf_emit)
 
   const int32_t* vlist; int64_t n_v;      // to expand staged records (video tile, row mask)
   unsigned long long* n_pairs;            // number of (i, v) pairs the records expand to

@@ -12,6 +12,7 @@
 #include "dalign_common.h"
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <string>
 
 namespace da {
@@ -24,7 +25,7 @@ typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // ------------------------------------------------------------------------------------------
 // prep: mean subtraction (:598-599, :605-606), window norms (:600-602), hash digits (:623-628,
-// :639-643) and the GEMM operand copies.  One thread per frame.
+// :639-643).  One thread per frame.  (The GEMM operands are built from these float64 rows per launch.)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prep_ms(PrepArgs a, const double* __restrict__ w /*41, normalised*/) {
   const int j = blockIdx.y;
@@ -44,9 +45,6 @@ __global__ __launch_bounds__(256) void k_prep_ms(PrepArgs a, const double* __res
     out = (double)f[n] - acc;
   }
   a.ms[j][n] = out;
-  if (j < 3) {
-    a.ms32[j][n] = (float)out;
-  }
 }
 
 __device__ inline uint16_t f32_to_bf16(float x) {
@@ -66,7 +64,6 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
       a.nrm[j][i] = 1.0;
       a.digits[j][i] = 0xFFFFFFFFu;          // never matches
       if (a.is_video) a.flags[j][i] = 0xFFFFFFFFu;
-      if (j < 3) { a.inv32[j][i] = 0.f; a.nrm32[j][i] = 1.f; }
     }
     return;
   }
@@ -76,9 +73,6 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
   double nr = sqrt(ss);
   nr = nr < 0.001 ? 0.001 : nr;
   a.nrm[j][i] = nr;
-  if (j < 3) {
-    a.inv32[j][i] = (float)(1.0 / nr); a.nrm32[j][i] = (float)nr;
-  }
   uint32_t dig = 0, flg = 0;
 #pragma unroll
   for (int b = 0; b < kTaps; ++b) {
@@ -103,18 +97,11 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_prep_prod(PrepArgs a) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.lmax + kPad) return;
-  a.prod32[i] = (float)(a.nrm[0][i] * a.nrm[1][i] * a.nrm[2][i]);
-}
-
 void launch_prep(const PrepArgs& a, const double* d_hann41n, hipStream_t s) {
   const int64_t n = a.lmax + kPad;
   dim3 grid((unsigned)((n + 255) / 256), 5);
   hipLaunchKernelGGL(k_prep_ms, grid, dim3(256), 0, s, a, d_hann41n);
   hipLaunchKernelGGL(k_prep_norm, grid, dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_prep_prod, dim3(grid.x), dim3(256), 0, s, a);
 }
 
 // hash vote in closed form: feature j "hits" when every audio digit equals
@@ -125,21 +112,14 @@ __device__ inline bool digit_hit(uint32_t a_guarded, uint32_t v_dig, uint32_t v_
 }
 
 // ------------------------------------------------------------------------------------------
-// similarity GEMM, float32 inputs on v_mfma_f32_32x32x2_f32
-//
-// Tile: one wave owns 32 video rows (MFMA A operand, held in 63 VGPRs for the whole launch,
-// pre-scaled by -1/|V|) and streams 32 audio columns at a time (MFMA B operand, straight from
-// L1/L2).  The K index is permuted (lane half h, step s -> k = 21 h + s; k = 41 is the zero pad)
-// so that each lane's operands are 21 consecutive floats.
-// acc = -<A,V>/|V|;  t_j = 1 + acc * (1/|A|_i) = 1 - corr_j;  survivor when t_0 t_1 t_2 <= thr.
+// survivor staging shared by the two similarity GEMMs: one compact 64-bit record per lane with a survivor, through
+// a per-wave LDS buffer, one global atomic per flush
 // ------------------------------------------------------------------------------------------
-constexpr int kWavesPerBlock = 4;
-constexpr int kSurvBuf = 256;          // survivor staging slots per wave (LDS)
 
 struct SurvSink {
   unsigned long long* s_buf;           // this wave's LDS staging
   int count;                           // wave-uniform
-  int cap = kSurvBuf;                  // slots in s_buf
+  int cap;                             // slots in s_buf
 };
 
 __device__ inline void sink_flush(SurvSink& sk, const MatchArgs& a, int lane) {
@@ -152,220 +132,6 @@ __device__ inline void sink_flush(SurvSink& sk, const MatchArgs& a, int lane) {
     if (pos < a.capacity) a.out[pos] = sk.s_buf[t];
   }
   sk.count = 0;
-}
-
-__device__ inline void sink_push(SurvSink& sk, const MatchArgs& a, int lane, bool pass, unsigned long long rec) {
-  const unsigned long long m = __ballot(pass);
-  if (m == 0ull) return;
-  const int n = __popcll(m);
-  if (sk.count + n > sk.cap) sink_flush(sk, a, lane);
-  if (pass) {
-    const int pos = sk.count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    sk.s_buf[pos] = rec;
-  }
-  sk.count += n;
-}
-
-// Software pipeline (one wave per SIMD, 512-VGPR budget): while the 63 MFMAs of tile t run, the
-// operand loads of tile t+1 are in flight and the threshold epilogue of tile t-1 is interleaved
-// between the MFMAs (VALU and matrix pipes overlap).  Two register sets are ping-ponged by
-// unrolling the tile loop by two, so nothing is copied.
-struct TileMeta {
-  float thr;      // threshold of this lane's audio column: thr * |A|_0 |A|_1 |A|_2
-  int32_t ic;
-  bool ok;
-};
-
-// audio frame number of column r of the tile starting at list position `at` (clamped at the end)
-__device__ __forceinline__ int32_t fetch_index(const MatchArgs& a, int64_t at, int64_t a_end, int r) {
-  int64_t ia = at + r;
-  if (ia >= a_end) ia = a_end - 1;
-  return a.alist[ia];
-}
-
-// Issue the operand loads of the tile at list position `at`, whose frame numbers `ic` were fetched
-// one phase earlier (a dependent index->operand load chain at the head of every phase would
-// expose a full memory round trip with no MFMA in flight).
-__device__ __forceinline__ void load_tile_b(const MatchArgs& a, int64_t at, int64_t a_end, int r, int h, int32_t ic,
-                                            float (&b)[3][21], TileMeta& m) {
-  m.ok = (at + r) < a_end;
-  m.ic = ic;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    // K permutation: lanes with h = 0 hold k = s, lanes with h = 1 hold k = 21 + s, so a lane's 21
-    // operands are contiguous: 5 x 16-byte + 1 x 4-byte loads (4-byte aligned) instead of 21 dword
-    // loads -- a wave may only have 63 vector-memory operations in flight (6-bit vmcnt).
-    const float* p = a.ms_a[j] + m.ic + 21 * h;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const f32x4u w = *reinterpret_cast<const f32x4u*>(p + 4 * q);
-      b[j][4 * q + 0] = w[0]; b[j][4 * q + 1] = w[1]; b[j][4 * q + 2] = w[2]; b[j][4 * q + 3] = w[3];
-    }
-    // last K slot: k = 20 for h = 0; for h = 1 it is the spare slot k = 41, which carries the audio
-    // window norm (the A operand holds 1 there), so the accumulator ends as |A| - <A,V>/|V| = |A| (1 - corr)
-    b[j][20] = h ? a.nrm_a[j][m.ic] : p[20];
-  }
-  m.thr = a.thr * a.prod_a[m.ic];
-}
-
-// acc_j = |A|_j (1 - corr_j); survivor when prod_j acc_j <= thr |A|_0 |A|_1 |A|_2 (same test as
-// prod_j (1 - corr_j) <= thr, with the per-column norms folded into the threshold)
-__device__ __forceinline__ uint32_t threshold_row(const f32x16 (&acc)[3], const TileMeta& m, int g, float) {
-  return (acc[0][g] * acc[1][g] * acc[2][g] <= m.thr) ? (1u << g) : 0u;
-}
-
-// Two rows at once: packed products, then for each row  mask = 2*mask + (prod <= thr)  as one
-// compare + one add-with-carry.  Rows must be fed in descending order (row g ends at bit g).
-__device__ __forceinline__ void threshold_rows2(const f32x16 (&acc)[3], float thr, int g_hi, uint32_t& mask) {
-  const f32x2 x0 = {acc[0][g_hi - 1], acc[0][g_hi]};
-  const f32x2 x1 = {acc[1][g_hi - 1], acc[1][g_hi]};
-  const f32x2 x2 = {acc[2][g_hi - 1], acc[2][g_hi]};
-  // two packed multiplies for the two rows (the compiler scalarises the vector expression: the
-  // operands come out of AGPRs, so pairing them costs nothing when asked for explicitly)
-  f32x2 pr;
-  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(pr) : "v"(x0), "v"(x1));
-  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(pr) : "v"(pr), "v"(x2));
-  asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[1]), "v"(thr) : "vcc");
-  asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(pr[0]), "v"(thr) : "vcc");
-}
-
-// Survivors of one tile: mask bit g <-> accumulator register g of this lane.  Each lane that has
-// any stages ONE compact record  [63:41] audio frame | [40:17] video tile | [16] lane half | [15:0] mask
-// (wave-aggregated slot in LDS, no loops here); k_verify expands the bits into (i, v) pairs.
-__device__ __forceinline__ unsigned long long pack_record(int32_t ic, int64_t vtile, int h, uint32_t mask) {
-  return ((unsigned long long)(uint32_t)ic << 41) | ((unsigned long long)vtile << 17) | ((unsigned long long)h << 16) | mask;
-}
-
-__device__ __forceinline__ void emit_tile(SurvSink& sk, const MatchArgs& a, int lane, int h, int64_t vtile, uint32_t mask, int32_t ic) {
-  sink_push(sk, a, lane, mask != 0u, pack_record(ic, vtile, h, mask));
-}
-
-// MFMAs of the current tile into acc, with the threshold epilogue of the PREVIOUS tile (accp/prev)
-// interleaved between them (VALU issues under the matrix pipe), and the previous tile's survivors
-// emitted while the last MFMAs are still in the pipe.
-__device__ __forceinline__ void mfma_tile_f32(const float (&A)[3][21], const float (&b)[3][21], f32x16 (&acc)[3],
-                                              const f32x16 (&accp)[3], const TileMeta& prev, float thr,
-                                              SurvSink& sk, const MatchArgs& a, int lane, int h, int64_t vtile) {
-  uint32_t mask = 0;
-#pragma unroll
-  for (int s = 0; s < 17; ++s) {
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][s], b[0][s], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][s], b[1][s], acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[2][s], b[2][s], acc[2], 0, 0, 0);
-#ifndef DA_DBG_NO_EPILOGUE
-    if (s < 16 && (s & 1) == 0) threshold_rows2(accp, prev.thr, 15 - s, mask);     // rows 15-s, 14-s
-#endif
-    // per MFMA triple: one operand load of the next tile and a slice of the epilogue
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-  }
-#ifdef DA_DBG_NO_EPILOGUE
-  asm volatile("" ::"v"(accp[0][0]), "v"(accp[1][5]), "v"(accp[2][15]));
-#endif
-#ifdef DA_DBG_NO_EMIT
-  asm volatile("" ::"v"(mask));
-#else
-  emit_tile(sk, a, lane, h, vtile, prev.ok ? mask : 0u, prev.ic);
-#endif
-#pragma unroll
-  for (int s = 17; s < 21; ++s) {
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][s], b[0][s], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][s], b[1][s], acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[2][s], b[2][s], acc[2], 0, 0, 0);
-  }
-}
-
-// All operand loads of the tile about to be consumed were issued one phase ago; naming them here
-// makes the compiler retire them (vmcnt) BEFORE the next prefetch batch is issued.  Otherwise its
-// in-order vmcnt bookkeeping (6-bit counter) would make the waits for these operands also wait
-// for part of the fresh batch.
-__device__ __forceinline__ void retire_loads(const float (&b)[3][21], const TileMeta& m) {
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-#pragma unroll
-    for (int s = 0; s < 21; ++s) asm volatile("" ::"v"(b[j][s]));
-  }
-  asm volatile("" ::"v"(m.thr));
-}
-
-__global__ __launch_bounds__(64 * kWavesPerBlock, 1) void k_match_f32(MatchArgs a) {
-  __shared__ unsigned long long s_surv[kWavesPerBlock][kSurvBuf];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int64_t vt0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 32;
-  SurvSink sk{s_surv[wave], 0};
-  const int64_t a_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block * 32;
-  int64_t a_end = a_begin + (int64_t)a.audio_tiles_per_block * 32;
-  if (a_end > a.n_a) a_end = a.n_a;
-  if (vt0 < a.n_v && a_begin < a_end) {
-    // fixed operand: 32 video rows, pre-scaled by -1/|V|
-    const int64_t vr = vt0 + r;
-    const bool vok = vr < a.n_v;
-    const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
-    float A[3][21];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const float sc = vok ? -a.inv_v[j][v] : 0.f;
-      const float* p = a.ms_v[j] + v + 21 * h;
-#pragma unroll
-      for (int s = 0; s < 21; ++s) A[j][s] = (21 * h + s < kWin) ? p[s] * sc : 1.0f;    // k = 21 h + s; k = 41: norm slot
-    }
-    const int64_t vtile = vt0 >> 5;
-    float b0[3][21], b1[3][21];
-    TileMeta m0, m1;
-    f32x16 acc0[3], acc1[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) acc1[j] = f32x16{0};
-    m1.ok = false; m1.ic = 0; m1.thr = 0.f;
-    int64_t at = a_begin;
-    load_tile_b(a, at, a_end, r, h, fetch_index(a, at, a_end, r), b0, m0);
-    int32_t ic_next = fetch_index(a, at + 32, a_end, r);        // frame numbers of tile t+1
-    // The prefetch is unconditional (past the end it re-reads the clamped last row, flagged !ok)
-    // so that loads, epilogue and MFMAs share one basic block and can be interleaved.
-    while (true) {
-      // ---- even phase: MFMAs of (b0, m0) -> acc0; epilogue of (acc1, m1); prefetch into (b1, m1)
-      {
-        const TileMeta prev = m1;
-        retire_loads(b0, m0);
-        asm volatile("" ::"v"(ic_next));
-        load_tile_b(a, at + 32, a_end, r, h, ic_next, b1, m1);
-        ic_next = fetch_index(a, at + 64, a_end, r);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc0[j] = f32x16{0};
-        mfma_tile_f32(A, b0, acc0, acc1, prev, a.thr, sk, a, lane, h, vtile);
-        at += 32;
-        if (at >= a_end) {      // drain: epilogue of the last tile
-          uint32_t m = 0;
-#pragma unroll
-          for (int g = 0; g < 16; ++g) m |= threshold_row(acc0, m0, g, a.thr);
-          emit_tile(sk, a, lane, h, vtile, m0.ok ? m : 0u, m0.ic);
-          break;
-        }
-      }
-      // ---- odd phase: MFMAs of (b1, m1) -> acc1; epilogue of (acc0, m0); prefetch into (b0, m0)
-      {
-        const TileMeta prev = m0;
-        retire_loads(b1, m1);
-        asm volatile("" ::"v"(ic_next));
-        load_tile_b(a, at + 32, a_end, r, h, ic_next, b0, m0);
-        ic_next = fetch_index(a, at + 64, a_end, r);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc1[j] = f32x16{0};
-        mfma_tile_f32(A, b1, acc1, acc0, prev, a.thr, sk, a, lane, h, vtile);
-        at += 32;
-        if (at >= a_end) {
-          uint32_t m = 0;
-#pragma unroll
-          for (int g = 0; g < 16; ++g) m |= threshold_row(acc1, m1, g, a.thr);
-          emit_tile(sk, a, lane, h, vtile, m1.ok ? m : 0u, m1.ic);
-          break;
-        }
-      }
-    }
-  }
-  sink_flush(sk, a, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -690,6 +456,207 @@ __global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
   sink_flush(sk, a, lane);
 }
 
+// ------------------------------------------------------------------------------------------
+// similarity GEMM, float32 inputs on v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s: 1/16 of the bf16 rate).  Version 2 (round 4):
+// the same organisation as k_match_bf16 -- both operands as explicit normalised fragment streams, the two-instruction
+// pattern-sum acceptance test with the threshold folded into the operand scales, stripes sized for L2 -- where version
+// 1 read Hankel windows of the audio rows, carried |A| in a K slot and a per-column threshold in a register and spent
+// 144 non-MFMA instructions per 63 MFMAs, which an f32 MFMA does not hide (it shares the FP32 ALUs with VALU).
+//
+// K = 41 + 1 = 42 = 21 steps of 2; lane half h, step s holds k = 2 s + h.  Fragment q = 21 j + s (feature j, step s) of a
+// lane is one float; a lane's 63 fragments (+ 1 pad) of a tile are 16 x 16 B: a 32-row (32-column) tile is
+// [chunk 16][lane 64] x 16 B = 16 KiB, chunk c holding fragments 4 c .. 4 c + 3.  Video rows carry -c_j ms_v[v + k] / |V|_v
+// and c_j at k = 41, audio columns ms_a[i + k] / |A|_i and 1 at k = 41: the accumulator ends as c_j (1 - corr_j), exact
+// up to the f32 rounding of 42 products (<= 3e-6), which the 1.006 margin on the threshold covers even when the
+// other two factors are 2.  No guard: an accumulator is negative only by that rounding, and then the pair is accepted.
+// MFMA order inside a phase is feature-major (fragments 0 .. 62 in stream order), so chunk c of a tile is needed in front
+// of MFMA 4 c of its first phase; 21 dependent MFMAs back to back on one accumulator cost nothing on this instruction
+// (64-cycle issue = 64-cycle dependent latency).
+// ------------------------------------------------------------------------------------------
+#ifndef DA_FD_ROWTILES
+#define DA_FD_ROWTILES 4
+#endif
+constexpr int kFdRowTiles = DA_FD_ROWTILES;       // even: the two accumulator sets alternate; 4 x 64 = all 256 AGPRs
+constexpr int kFdWaves = 4;
+constexpr int kFdRows = 32 * kFdRowTiles;
+constexpr int kFdRowsPerBlock = kFdRows * kFdWaves;
+constexpr int kFdTileBytes = 16 * 64 * 16;        // 16 KiB per 32 rows / columns
+constexpr int kFdSurv = 128 * kFdRowTiles + 64;
+static_assert(kFdRowTiles % 2 == 0 && kFdRowTiles * 64 <= 256, "row tiling");
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct FdTile { f32x4 chunk[16]; };               // this lane's 63 fragments (+ pad) of one 32-column tile
+
+template <int kC, int kLast>
+__device__ __forceinline__ void fd_issue(FdTile& t, const void* tile, const uint32_t (&off)[4]) {
+  if constexpr (kC < kLast) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(t.chunk[kC]) : "v"(off[kC / 4]), "s"(tile), "n"((kC % 4) * 1024));
+    fd_issue<kC + 1, kLast>(t, tile, off);
+  }
+}
+
+// 63 MFMAs of one (32 rows x 32 columns) phase into `acc`, the epilogue of the previous phase (`accp` -> `codes`) behind
+// MFMA 2 .. 17 (one row = two VALU instructions each: the previous phase's last accumulator has left the pipe by then),
+// `extra(q)` behind MFMA q.  kWait: first phase of a column tile -- chunk c of the tile (requested a whole tile ago) is
+// waited for in front of MFMA 4 c; the next tile's 16 loads are issued behind MFMA 0 .. 15 of this same phase, so the
+// vmcnt allowed there is (15 - c) older chunks of this tile + min(4 c, 16) requests of the next.
+template <int kC> __device__ __forceinline__ void fd_wait() {
+  // vmcnt allowed in front of MFMA 4 kC of a tile's first phase: (15 - kC) younger chunks of this tile + min(4 kC, 16) requests of the next
+  constexpr int n = (15 - kC) + (4 * kC < 16 ? 4 * kC : 16);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n));
+}
+
+// (compile-time recursion over the 63 MFMAs: a run-time loop of this size is not unrolled, and the operands must be
+// named registers, not indexed ones)
+template <bool kWait, int kQ, class Extra>
+__device__ __forceinline__ void fd_steps(const f32x4 (&A)[16], const FdTile& B, f32x16 (&acc)[3], const f32x16 (&accp)[3], uint32_t& codes,
+                                         Extra& extra) {
+  if constexpr (kQ < 63) {
+    constexpr int j = kQ / 21, s = kQ % 21, c = kQ / 4, e = kQ % 4;
+    if constexpr (kWait && e == 0) fd_wait<c>();
+    if constexpr (s == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc[j]) : "a"(A[c][e]), "v"(B.chunk[c][e]));
+    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "a"(A[c][e]), "v"(B.chunk[c][e]));
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef DA_DBG_FD_NOEPI
+    if constexpr (kQ >= 2 && kQ < 18) bf_row(accp, 17 - kQ, codes);              // rows 15 .. 0
+#else
+    codes = kBdAllReject;
+#endif
+    extra(std::integral_constant<int, kQ>{});
+    __builtin_amdgcn_sched_barrier(0);
+    fd_steps<kWait, kQ + 1>(A, B, acc, accp, codes, extra);
+  }
+}
+template <bool kWait, class Extra>
+__device__ __forceinline__ void fd_phase(const f32x4 (&A)[16], const FdTile& B, f32x16 (&acc)[3], const f32x16 (&accp)[3], uint32_t& codes,
+                                         Extra extra) {
+  fd_steps<kWait, 0>(A, B, acc, accp, codes, extra);
+}
+
+// Operand streams, one wavefront per 32-row / 32-column tile (see the section header); rows rotated per feature as in
+// the bf16 kernel (bf_arow: the three accumulators of a video row then sit in three different register banks).
+__global__ __launch_bounds__(64) void k_f32_video_frags(MatchArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t tile = blockIdx.x;
+  float4* out = reinterpret_cast<float4*>(a.bfv_frag) + tile * 16 * 64 + lane;
+  float f[64];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int64_t vr = tile * 32 + bf_arow(r, j);
+    const bool vok = vr < a.n_v;
+    const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
+    const double cj = (double)a.cscale[j];
+    const double sc = vok ? -cj / a.nrmd_v[j][v] : 0.0;
+    const double* p = a.msd_v[j] + v;
+#pragma unroll
+    for (int s = 0; s < 21; ++s) {
+      const int k = 2 * s + h;
+      f[21 * j + s] = k < kWin ? (float)(p[k] * sc) : a.cscale[j];
+    }
+  }
+  f[63] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) out[c * 64] = make_float4(f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]);
+}
+
+__global__ __launch_bounds__(64) void k_f32_audio_frags(MatchArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t tile = blockIdx.x;
+  float4* out = reinterpret_cast<float4*>(a.bfa_frag) + tile * 16 * 64 + lane;
+  const int64_t col = tile * 32 + r;
+  const bool ok = col < a.n_a;
+  const int32_t i = a.alist[ok ? col : (a.n_a > 0 ? a.n_a - 1 : 0)];
+  float f[64];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double sc = ok ? 1.0 / a.nrmd_a[j][i] : 0.0;
+    const double* p = a.msd_a[j] + i;
+#pragma unroll
+    for (int s = 0; s < 21; ++s) {
+      const int k = 2 * s + h;
+      f[21 * j + s] = k < kWin ? (float)(p[k] * sc) : 1.0f;     // columns past the end: zeros and the 1 -> every accumulator c_j, rejected
+    }
+  }
+  f[63] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) out[c * 64] = make_float4(f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]);
+}
+
+__global__ __launch_bounds__(64 * kFdWaves, 1) void k_match_f32(MatchArgs a) {
+  __shared__ unsigned long long s_surv[kFdWaves][kFdSurv + 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t vt0 = ((int64_t)blockIdx.x * kFdWaves + wave) * kFdRows;
+  const int64_t atiles = (a.n_a + 31) >> 5;
+  const int64_t t_begin = (int64_t)blockIdx.y * a.audio_tiles_per_block;
+  int64_t t_end = t_begin + a.audio_tiles_per_block;
+  if (t_end > atiles) t_end = atiles;
+  if (vt0 >= a.n_v || t_begin >= t_end) return;
+  SurvSink sk{s_surv[wave], 0, kFdSurv};
+  const int64_t vtile0 = vt0 >> 5;
+  f32x4 A[kFdRowTiles][16];                                        // resident operand: straight into AGPRs
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.bfv_frag) + vtile0 * 16 * 64 + lane;
+#pragma unroll
+    for (int rt = 0; rt < kFdRowTiles; ++rt)
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(A[rt][c]) : "v"(src + (rt * 16 + c) * 64) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  f32x16 acc0[3], acc1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc1[j][g] = __uint_as_float(kBdIdleBits);     // "nothing owed": reads as 16 rejected rows
+  uint32_t off[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) off[u] = (uint32_t)lane * 16u + 4096u * u;
+  const char* tiles = reinterpret_cast<const char*>(a.bfa_frag);
+  FdTile X, Y;
+  int64_t t = t_begin;
+  fd_issue<0, 16>(X, tiles + t * kFdTileBytes, off);
+  uint32_t acol_prev = 0;
+  auto run_tile = [&](FdTile& CUR, FdTile& NXT) {
+    if (sk.count > kFdSurv - 64 * (kFdRowTiles + 1)) sink_flush(sk, a, lane);   // before the next loads are requested (see k_match_bf16)
+    const void* nxt = tiles + (t + 1) * kFdTileBytes;             // one tile past the stripe at its end: inside the padded buffer, never used
+    const uint32_t acol = (uint32_t)(t << 5) + (uint32_t)r;
+#pragma unroll
+    for (int rt = 0; rt < kFdRowTiles; ++rt) {
+      uint32_t codes = 0;
+      auto extra = [&](auto q) {                                   // one request of the next tile behind each of MFMA 0 .. 15 of the first phase
+        constexpr int kq = decltype(q)::value;
+        if constexpr (kq < 16) { if (rt == 0) fd_issue<kq, kq + 1>(NXT, nxt, off); }
+      };
+      if (rt == 0) fd_phase<true>(A[rt], CUR, acc0, acc1, codes, extra);
+      else if (rt & 1) fd_phase<false>(A[rt], CUR, acc1, acc0, codes, extra);
+      else fd_phase<false>(A[rt], CUR, acc0, acc1, codes, extra);
+      bf_emit(sk, h, vtile0 + (rt == 0 ? kFdRowTiles - 1 : rt - 1), codes, rt == 0 ? acol_prev : acol);
+    }
+    acol_prev = acol;
+    ++t;
+  };
+  while (true) {
+    run_tile(X, Y);
+    if (t >= t_end) break;
+    run_tile(Y, X);
+    if (t >= t_end) break;
+  }
+  {                                                                // drain: the last tile's last row tile
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                 : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t codes = 0;
+#pragma unroll
+    for (int g = 15; g >= 0; --g) bf_row(acc1, g, codes);
+    bf_emit(sk, h, vtile0 + kFdRowTiles - 1, codes, acol_prev);
+  }
+  sink_flush(sk, a, lane);
+}
+
 // Scales c_j for the threshold `thr` (see the header comment of this section): the bound
 // 2^23 (381 + log2(thr c_0 c_1 c_2)) on the pattern sum of an accepted pair must stay below 2^30, so
 // log2(c_0 c_1 c_2) < -253 - log2(thr).  c_0 = c_1 = a power of two, c_2 rounded DOWN to a bf16 number
@@ -704,77 +671,61 @@ void bf16_gemm_scales(double thr, float out[3]) {
   out[2] = (float)std::ldexp(mant, e2);
 }
 
-static dim3 match_grid(const MatchArgs& a) {
-  const int64_t vtiles = (a.n_v + 31) / 32;
-  const int64_t bx = (vtiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int64_t atiles = (a.n_a + 31) / 32;
-  const int64_t by = (atiles + a.audio_tiles_per_block - 1) / a.audio_tiles_per_block;
-  return dim3((unsigned)bx, (unsigned)by);
+// Stripe of audio column tiles per workgroup: every workgroup of a stripe streams all of it, so it is sized for the 4 MiB
+// L2 of an XCD (x runs fastest: a stripe's workgroups are dispatched back to back); the resident operand is loaded once
+// per stripe.  Sweep of the bf16 kernel: profiles/r04_match_bf16_stripes.txt.
+static int64_t stripe_tiles(int64_t atiles, int64_t dflt, const char* env) {
+  int64_t tpb = dflt;
+  if (const char* e = std::getenv(env)) tpb = std::atoll(e);
+  if (tpb < 1) tpb = 1;
+  if ((atiles + tpb - 1) / tpb > 65535) tpb = (atiles + 65534) / 65535;
+  return tpb;
 }
 
 void launch_match_f32(const MatchArgs& a, hipStream_t s) {
   if (a.n_v <= 0 || a.n_a <= 0) return;
-  hipLaunchKernelGGL(k_match_f32, match_grid(a), dim3(64 * kWavesPerBlock), 0, s, a);
+  MatchArgs b = a;
+  const int64_t bx = (a.n_v + kFdRowsPerBlock - 1) / kFdRowsPerBlock;
+  const int64_t atiles = (a.n_a + 31) / 32;
+  const int64_t tpb = stripe_tiles(atiles, 192, "DALIGN_F32_STRIPE_TILES");     // 192 x 16 KiB = 3 MB
+  b.audio_tiles_per_block = (int)tpb;
+  hipLaunchKernelGGL(k_f32_video_frags, dim3((unsigned)b.bfv_tiles), dim3(64), 0, s, b);
+  hipLaunchKernelGGL(k_f32_audio_frags, dim3((unsigned)b.bfa_tiles), dim3(64), 0, s, b);
+  hipLaunchKernelGGL(k_match_f32, dim3((unsigned)bx, (unsigned)((atiles + tpb - 1) / tpb)), dim3(64 * kFdWaves), 0, s, b);
 }
 void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   if (a.n_v <= 0 || a.n_a <= 0) return;
   MatchArgs b = a;
   const int64_t bx = (a.n_v + kBdRowsPerBlock - 1) / kBdRowsPerBlock;
   const int64_t atiles = (a.n_a + 31) / 32;
-  // Stripe of audio column tiles per workgroup.  The streamed operand is 9 KiB per tile and every workgroup of a stripe
-  // reads all of it: a stripe must FIT THE 4 MiB L2 of an XCD, so that whenever a workgroup starts on it, the tiles are
-  // already there (the workgroups of one stripe are dispatched back to back: x runs fastest).  With long stripes
-  // (v8 as first measured: 6 700 tiles = 62 MB) the workgroups of an XCD drift apart and 41 % of the stream misses L2
-  // (FETCH_SIZE 89 GB per launch against 13 GB, +4.5 % time).  Price: the resident operand (55 KB per wave) is loaded
-  // once per stripe instead of once per 12th of the audio side: ~1 % of a 384-tile stripe.  Sweep on a 2 h pair
-  // (profiles/r04_match_bf16_stripes.txt): 96 tiles 27.9 GB, 192: 15.9, 384: 12.8, 768: 9.7, 1536: 9.6, 3072: 20.4,
-  // 6 700: 88.7; kernel time equal within 0.5 % from 192 to 1536 (the MALL catches what a 3.5-7 MB stripe loses in L2).
-  int64_t tpb = 384;
-  if (const char* e = std::getenv("DALIGN_BF16_STRIPE_TILES")) tpb = std::atoll(e);
-  if (tpb < 1) tpb = 1;
-  if ((atiles + tpb - 1) / tpb > 65535) tpb = (atiles + 65534) / 65535;
+  // 384 tiles x 9 KiB = 3.5 MB.  With 6 700-tile stripes (62 MB) the workgroups of an XCD drift apart and 41 % of the stream
+  // misses L2 (FETCH_SIZE 89 GB per launch against 13 GB, +4.5 % time); 96 tiles: 27.9 GB, 192: 15.9, 384: 12.8, 768: 9.7,
+  // 1536: 9.6, 3072: 20.4; kernel time equal within 0.5 % from 192 to 1536 (the MALL catches what a 3.5-7 MB stripe loses in L2).
+  const int64_t tpb = stripe_tiles(atiles, 384, "DALIGN_BF16_STRIPE_TILES");
   b.audio_tiles_per_block = (int)tpb;
   hipLaunchKernelGGL(k_bf16_video_frags, dim3((unsigned)b.bfv_tiles), dim3(64), 0, s, b);
   hipLaunchKernelGGL(k_bf16_audio_frags, dim3((unsigned)b.bfa_tiles), dim3(64), 0, s, b);
   hipLaunchKernelGGL(k_match_bf16, dim3((unsigned)bx, (unsigned)((atiles + tpb - 1) / tpb)), dim3(64 * kBdWaves), 0, s, b);
 }
 
-// diagnostics: the raw MFMA accumulators of ONE (32 video rows x 32 audio columns) tile, formed with
-// the production kernels' operands and instruction sequence (f32: the same operand construction; bf16: the
-// very fragment streams k_match_bf16 read in the last launch): out[j][row][col] = |A|_j(col) (1 - corr_j(row, col))
-// for f32, and (1 - guard - corr_j(row, col)) for bf16 (the accumulator divided by its scale c_j).
-// One wavefront.  The matrix instructions are deterministic, so these are the values the threshold
-// epilogue of k_match_f32 / k_match_bf16 sees for that tile.
+// diagnostics: the raw MFMA accumulators of ONE (32 video rows x 32 audio columns) tile, formed from the very fragment
+// streams the last launch of k_match_f32 / k_match_bf16 read, with its MFMA sequence: out[j][row][col] = the accumulator
+// divided by its scale c_j = 1 - corr_j(row, col) for f32 and 1 - guard - corr_j(row, col) for bf16.  One wavefront.
+// The matrix instructions are deterministic, so these are the values the acceptance test of the epilogue sees.
 __global__ __launch_bounds__(64) void k_dump_tile(MatchArgs a, int64_t vtile, int64_t atile, int bf16, float* __restrict__ out,
                                                   int32_t* __restrict__ vframes, int32_t* __restrict__ aframes) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t at = atile * 32;
-  const int32_t ic = fetch_index(a, at, a.n_a, r);
   f32x16 acc[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) acc[j] = f32x16{0};
   if (!bf16) {
-    const int64_t vr = vtile * 32 + r;
-    const bool vok = vr < a.n_v;
-    const int32_t v = a.vlist[vok ? vr : a.n_v - 1];
-    float A[3][21], b[3][21];
+    const float* va = reinterpret_cast<const float*>(a.bfv_frag) + (vtile * 16 * 64 + lane) * 4;
+    const float* au = reinterpret_cast<const float*>(a.bfa_frag) + (atile * 16 * 64 + lane) * 4;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const float sc = vok ? -a.inv_v[j][v] : 0.f;
-      const float* p = a.ms_v[j] + v + 21 * h;
-#pragma unroll
-      for (int s = 0; s < 21; ++s) A[j][s] = (21 * h + s < kWin) ? p[s] * sc : 1.0f;
-    }
-    TileMeta m;
-    load_tile_b(a, at, a.n_a, r, h, ic, b, m);
-#pragma unroll
-    for (int s = 0; s < 21; ++s)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j][s], b[j][s], acc[j], 0, 0, 0);
-    if (h == 0) { vframes[r] = vok ? v : -1; aframes[r] = (at + r) < a.n_a ? ic : -1; }
+    for (int q = 0; q < 63; ++q)
+      acc[q / 21] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[(q / 4) * 256 + (q % 4)], au[(q / 4) * 256 + (q % 4)], acc[q / 21], 0, 0, 0);
   } else {
-    // the production operands themselves: the fragment streams the last launch built (k_bf16_video_frags / k_bf16_audio_frags)
     const uint4* va = reinterpret_cast<const uint4*>(a.bfv_frag) + vtile * 9 * 64 + lane;
     const uint4* au = reinterpret_cast<const uint4*>(a.bfa_frag) + atile * 9 * 64 + lane;
 #pragma unroll
@@ -784,18 +735,17 @@ __global__ __launch_bounds__(64) void k_dump_tile(MatchArgs a, int64_t vtile, in
         const uint4 x = va[(3 * j + s) * 64], y = au[(3 * j + s) * 64];
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&x), *reinterpret_cast<const bf16x8*>(&y), acc[j], 0, 0, 0);
       }
-    if (h == 0) {
-      const int64_t vr = vtile * 32 + r;
-      vframes[r] = vr < a.n_v ? a.vlist[vr] : -1;
-      aframes[r] = (at + r) < a.n_a ? ic : -1;
-    }
+  }
+  if (h == 0) {
+    const int64_t vr = vtile * 32 + r, ac = atile * 32 + r;
+    vframes[r] = vr < a.n_v ? a.vlist[vr] : -1;
+    aframes[r] = ac < a.n_a ? a.alist[ac] : -1;
   }
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-      out[(j * 32 + row) * 32 + r] = bf16 ? acc[j][bf_rot(g, j)] / a.cscale[j] : acc[j][g];
+    for (int j = 0; j < 3; ++j) out[(j * 32 + row) * 32 + r] = acc[j][bf_rot(g, j)] / a.cscale[j];
   }
 }
 void launch_dump_tile(const MatchArgs& a, int64_t vtile, int64_t atile, int bf16, float* d_out, int32_t* d_vframes, int32_t* d_aframes,
@@ -803,29 +753,24 @@ void launch_dump_tile(const MatchArgs& a, int64_t vtile, int64_t atile, int bf16
   hipLaunchKernelGGL(k_dump_tile, dim3(1), dim3(64), 0, s, a, vtile, atile, bf16, d_out, d_vframes, d_aframes);
 }
 
-// diagnostics: the correlations exactly as the GEMM precision forms them, for explicit pairs.
-// One wave per 32 pairs would be the MFMA way; this path is test-only, so it uses plain FMAs on
-// identically rounded operands (f32: same k-ordered fmaf chain as the MFMA; bf16: same rounding
-// of both operands, f32 accumulation).
+// diagnostics: the correlations as the GEMM precision forms them, for explicit pairs.  One wave per 32 pairs would be
+// the MFMA way; this path is test-only, so it uses plain FMAs on identically rounded operands (the normalised windows
+// in f32, or rounded to bf16, f32 accumulation in k order).
 __global__ void k_corr(CorrArgs c) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= c.n) return;
   const int32_t i = c.pi[p], v = c.pv[p];
   for (int j = 0; j < 3; ++j) {
+    const double sc = -1.0 / c.m.nrmd_v[j][v], sa = 1.0 / c.m.nrmd_a[j][i];
     float acc = 0.f;
-    if (c.precision == 0) {
-      const float sc = -c.m.inv_v[j][v];
-      for (int k = 0; k < kWin; ++k) acc = fmaf(c.m.ms_v[j][v + k] * sc, c.m.ms_a[j][i + k], acc);
-    } else {
-      const double sc = -1.0 / c.m.nrmd_v[j][v], sa = 1.0 / c.m.nrmd_a[j][i];
-      for (int k = 0; k < kWin; ++k) {
-        const uint16_t ab = f32_to_bf16((float)(c.m.msd_v[j][v + k] * sc));
-        const uint16_t bb = f32_to_bf16((float)(c.m.msd_a[j][i + k] * sa));
-        const float af = __uint_as_float((uint32_t)ab << 16), bf = __uint_as_float((uint32_t)bb << 16);
-        acc = fmaf(af, bf, acc);
+    for (int k = 0; k < kWin; ++k) {
+      float af = (float)(c.m.msd_v[j][v + k] * sc), bf = (float)(c.m.msd_a[j][i + k] * sa);
+      if (c.precision != 0) {
+        af = __uint_as_float((uint32_t)f32_to_bf16(af) << 16); bf = __uint_as_float((uint32_t)f32_to_bf16(bf) << 16);
       }
+      acc = fmaf(af, bf, acc);
     }
-    c.corr[3 * p + j] = c.precision == 0 ? -acc * c.m.inv_a[j][i] : -acc;
+    c.corr[3 * p + j] = -acc;
   }
 }
 void launch_corr(const CorrArgs& a, hipStream_t s) {
@@ -895,19 +840,17 @@ __global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyArgs a, unsigne
   for (unsigned long long rnd = 0; rnd < rounds; ++rnd) {
     const unsigned long long p = rnd * stride + (unsigned long long)blockIdx.x * kVerifyThreads + threadIdx.x;
     const unsigned long long rec = (p < n_rec) ? a.surv[p] : 0ull;
-    // f32 GEMM records: audio frame | video tile | lane half | accept bit per accumulator register;
-    // bf16 GEMM records: position in the audio row list | video tile | lane half | REJECT bits in bf_emit's order
-    const bool coded = a.alist != nullptr;
+    // record: position in the audio row list | video tile | lane half | REJECT bits in bf_emit's order
     int32_t i = (int32_t)(rec >> 41);
     const int64_t vtile = (int64_t)((rec >> 17) & 0xFFFFFFull);
     const int h = (int)((rec >> 16) & 1ull);
-    uint32_t mask = (uint32_t)(rec & 0xFFFFull);
-    if (coded) { mask ^= 0xFFFFu; if (i < a.n_a) i = a.alist[i]; else mask = 0u; }
+    uint32_t mask = (uint32_t)(rec & 0xFFFFull) ^ 0xFFFFu;
+    if (i < a.n_a) i = a.alist[i]; else mask = 0u;
     if (p >= n_rec) mask = 0u;
     while (mask != 0u) {                                              // step 1: expand + vote
       const int b = __ffs(mask) - 1;
       mask &= mask - 1u;
-      const int g = coded ? bf_bit_row(b) : b;
+      const int g = bf_bit_row(b);
       const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
       const int64_t vr = vtile * 32 + row;
       if (vr < a.n_v) {

@@ -157,10 +157,10 @@ int da_match_corr(da_ctx* ctx, const int32_t* i, const int32_t* v, int64_t n, fl
 /* The raw matrix-core accumulators of the similarity GEMM for ONE tile of 32 video rows x 32 audio
  * columns of the last da_match (tile indices into its row lists: every 4th non-quiet video frame,
  * the non-quiet audio frames), formed with the production kernel's operands and MFMA sequence in the
- * context's precision.  DA_PREC_F32: acc[j][row][col] = |A|_j(col) (1 - corr_j(row, col)), j = 0..2.
- * DA_PREC_BF16: the operand fragment streams the last launch itself read are multiplied, and
- * acc[j][row][col] = 1 - guard - corr_j(row, col) (guard = 2^-7 + 2^-14, the proven bound on the bf16
- * rounding: never above the exact 1 - corr_j), the accumulator divided by the feature's fixed scale.
+ * context's precision: the operand fragment streams the last launch itself read are multiplied, and
+ * acc[j][row][col] = 1 - corr_j(row, col) (DA_PREC_F32) or 1 - guard - corr_j(row, col) (DA_PREC_BF16;
+ * guard = 2^-7 + 2^-14, the proven bound on the bf16 rounding: never above the exact 1 - corr_j), j = 0..2 --
+ * the accumulator divided by the feature's fixed scale.
  * I.e. exactly what the acceptance test of the epilogue sees.  video_frames[32] / audio_frames[32]
  * receive the frame numbers of the rows / columns (-1 past the end of a list).  Testing /
  * diagnostics ("similarity values within 1e-3 relative", north_star). */
