@@ -187,7 +187,7 @@ class Bench:
     t1 = None
     with quiet:
       if pipe is not None:
-        it = pipe.run((make_job(k) for k in range(total)), timings=tms)
+        it = pipe.run((make_job(k) for k in range(total)), timings=tms, expected=total)
         for k in range(total):
           o = next(it)
           outs.append(o if k == warmup + steps - 1 else None)          # a 2 h pair's path is ~60 MB
@@ -234,6 +234,12 @@ class Bench:
       add("lp_s", tm["lp_s"]); add("match_s", tm["match_s"]); add("chain_s", tm["chain_s"])
       add("n_path1", tm["n_path1"]); add("n_fit_points", tm["n_fit_points"])
       add("align_s", tm["match_s"] + tm["chain_s"] + tm["pass1_host_s"] + tm["lp_s"] + tm["cluster_s"] + tm["refine_s"] + tm["nodes_s"])
+      for name in ("pass1_host_s", "cluster_s", "refine_s", "nodes_s", "worker_s"):
+        add(name, tm.get(name, 0.0))
+      if "t_handoff" in tm and "done_t" in tm:      # where a pair spends its time between the stages (pipelined runs)
+        add("iv_copy", tm["t_copied"] - tm["t_handoff"]); add("iv_wait_for_worker_slot", tm["t_submitted"] - tm["t_copied"])
+        add("iv_in_worker_pool", tm["t_worker_back"] - tm["t_submitted"]); add("iv_wait_for_refine_thread", tm["t_refine_start"] - tm["t_worker_back"])
+        add("iv_refine_and_nodes", tm["done_t"] - tm["t_refine_start"])
     for idx in range(warmup, warmup + steps):
       add("feat_ms", feat[idx][0]); add("feat_bytes", feat[idx][1])
 
@@ -287,7 +293,11 @@ class Bench:
                                                                 "refine_kernel_ms", "refine_dp_ms")},
         "host_s_per_step": {"lp": round(acc["lp_s"] / k, 4), "align_latency_per_pair": round(acc["align_s"] / k, 4),
                             "gpu_match_stage_wall": round(acc["match_s"] / k, 4),
-                            "chain_enqueue_to_collected": round(acc["chain_s"] / k, 4)},
+                            "chain_enqueue_to_collected": round(acc["chain_s"] / k, 4),
+                            "worker_busy": round(acc.get("worker_s", 0.0) / k, 4), "pass1": round(acc.get("pass1_host_s", 0.0) / k, 4),
+                            "cluster": round(acc.get("cluster_s", 0.0) / k, 4), "refine": round(acc.get("refine_s", 0.0) / k, 4),
+                            "nodes": round(acc.get("nodes_s", 0.0) / k, 4),
+                            "intervals": {n[3:]: round(acc[n] / k, 4) for n in sorted(acc) if n.startswith("iv_")}},
         "pipeline": {"lp_worker_processes": workers, "gpu_streams": len(gpu_ctxs), "host_cores": os.cpu_count(),
                      "worker_count_rationale": "1.5 worker processes per L3 domain of the host (align.default_worker_count): one HiGHS solve of a long pair "
                                                "wants a whole L3 slice, so the host's solves/s do not grow beyond one worker per domain (configs[2] sweep, "

@@ -714,6 +714,9 @@ class AlignPipeline:
     self.pace = int(os.environ.get("DALIGN_PIPELINE_PACE", "1")) != 0
     self._work_ema = None  # worker seconds per pair (pass 1 + LP + clustering), exponential average
     self._last_admit = 0.0
+    self._last_lp_start = 0.0
+    self._lp_running = 0   # pairs handed to the worker pool (or about to be) and not yet back
+    self._stagger = False  # set by run(expected=...): long batches only
     self._n_admitted = 0   # pairs whose GPU stage has started / pairs whose worker stage has finished
     self._n_done = 0
     self._queued = {}      # per GPU context: pairs submitted to its thread that have not started yet
@@ -847,6 +850,7 @@ class AlignPipeline:
 
   def _hand_off_copy(self, px, py, vf, af, dims, tm, fname, done):
     try:
+      tm["t_handoff"] = time.perf_counter()           # path collected, copy about to start (interval stamps: where a pair waits)
       n = len(px)
       state = {}
       lay, size = _block_layout(n, *dims)
@@ -869,11 +873,21 @@ class AlignPipeline:
       for dst, src in zip(baf, af):
         dst[:] = src
       mm.flush()
-      mid = self.pool.submit(_proc_mid, state["fname"], fsize, n, *dims)
+      tm["t_copied"] = time.perf_counter()
+      self._stagger_start(n)
+      tm["t_submitted"] = time.perf_counter()
+      try:
+        mid = self.pool.submit(_proc_mid, state["fname"], fsize, n, *dims)
+      except BaseException:
+        with self._lock:
+          self._lp_running -= 1
+        raise
 
       def on_mid(f):
+        tm["t_worker_back"] = time.perf_counter()
         with self._lock:
           self._n_done += 1               # the pair has left the worker stage (whatever the outcome)
+          self._lp_running -= 1
 
         def work():
           try:
@@ -888,7 +902,34 @@ class AlignPipeline:
         self._n_done += 1
       done.set_exception(e)
 
+  def _stagger_start(self, n_path):
+    """Worker-start staggering (long batches only: `run(expected=...)` of at least two generations of solves).
+    The GPU stage delivers a pair every 0.15 s, a 2 h pair's LP takes 6-10 s: left alone, all `depth` workers start
+    their first solve within a few seconds of each other, finish together, take the next queued pairs together --
+    a limit cycle in which results leave the pipeline in bursts of `depth` (20 results within 3 s, then nothing for
+    7 s) and every generation of solves hits the host's caches at once.  Consecutive solve STARTS are therefore kept
+    `worker seconds per pair / depth` apart, and a pair is only handed to the pool when a worker is free for it: the
+    phases of the workers end up evenly spread over one solve time and stay so; in steady state the spacing equals the
+    pool's natural rate, so it costs nothing.  Before the first solve has come back its duration is estimated from the
+    path length (fit points ~ n / 14; HiGHS' dual simplex on this LP: ~0.6 s at 2 400 points, growing like n^1.8)."""
+    while True:
+      with self._lock:
+        if not (self.pace and self._stagger):
+          self._lp_running += 1
+          return
+        ema = self._work_ema
+        if ema is None:
+          ema = 0.6 * (max(1.0, n_path / 14.0) / 2400.0) ** 1.8
+        now = time.perf_counter()
+        wait = self._last_lp_start + 0.97 * ema / self.depth - now
+        if self._lp_running < self.depth and wait <= 0:
+          self._lp_running += 1
+          self._last_lp_start = now
+          return
+      time.sleep(min(max(wait, 0.002), 0.02))
+
   def _refine_stage(self, mid_result, state, dims, tm):
+    tm["t_refine_start"] = time.perf_counter()
     clusters, med, wtm = mid_result
     busy = wtm.get("worker_s")
     if busy is not None:
@@ -908,10 +949,13 @@ class AlignPipeline:
       self._free.append((state["fname"], state["fsize"]))
     return out
 
-  def run(self, jobs, timings=None, window=None):
+  def run(self, jobs, timings=None, window=None, expected=None):
     """Yields the results in submission order.  `window` = pairs admitted before the oldest result
     is waited for (default 2 x workers + 4 per GPU, or DALIGN_PIPELINE_WINDOW): callers that hold
-    per-pair host memory until a pair's result arrives (combine --stretch_audio) narrow it."""
+    per-pair host memory until a pair's result arrives (combine --stretch_audio) narrow it.
+    `expected` = number of pairs the caller is going to submit, when it knows: from two generations of solves
+    on, the workers' solve starts are staggered (_stagger_start)."""
+    self._stagger = expected is not None and expected >= 2 * self.depth
     import concurrent.futures as cf
     import os
     pending = []          # (future of the pair's result, tm) in submission order

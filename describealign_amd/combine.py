@@ -434,7 +434,7 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
   with AlignPipeline(ctx, lp_workers=workers) as pipe:
     if len(work) >= 8:
       pipe.warm()
-    it = pipe.run((make_job(k) for k in range(len(work))), window=(max_held if stretch_audio else None))
+    it = pipe.run((make_job(k) for k in range(len(work))), window=(max_held if stretch_audio else None), expected=len(work))
     for k in range(len(work)):
       with quiet:
         outputs = next(it)

@@ -56,6 +56,7 @@ struct ChainSlot {
   DevBuf rank, flags, rows, pred, tree, ids, out_iv, small, temp;
   // column-pipelined DP: row ordinals, partition keys / ids, column-major matches, per-row records, control words
   DevBuf rowid, ckey, cval, c_row, c_lr, c_q, c_gid, col_start, msg, ctl;
+  DevBuf seg;                     // back-track: entry id and output offset of every pred[] segment
   unsigned launches = 0;          // column DPs that have written `msg` since it was last zeroed (tag salt)
   int64_t rows_hint = 0;          // audio rows of the match that filled this slot (upper bound on the rows with matches), 0 = unknown
   int mode = 0;                   // how the DP in flight was launched: 0 = columns, 1 / 4 = one workgroup of 1 / 4 wavefronts
@@ -67,7 +68,7 @@ struct ChainSlot {
   long long* h_small = nullptr;   // pinned copy of `small`: [0] rows | err << 32, [1] best id, [2] path length
   void release() {
     for (DevBuf* b : {&keys, &q, &rank, &flags, &rows, &pred, &tree, &ids, &out_iv, &small, &temp,
-                      &rowid, &ckey, &cval, &c_row, &c_lr, &c_q, &c_gid, &col_start, &msg, &ctl}) b->release();
+                      &rowid, &ckey, &cval, &c_row, &c_lr, &c_q, &c_gid, &col_start, &msg, &ctl, &seg}) b->release();
     if (stream) (void)hipStreamDestroy(stream);
     for (hipEvent_t e : {e0, e1, ready}) if (e) (void)hipEventDestroy(e);
     if (h_small) (void)hipHostFree(h_small);
@@ -821,7 +822,7 @@ extern "C" int da_trim(da_ctx* c) {
   for (ChainSlot* sl : c->slots)
     if (sl->state == 0)
       for (DevBuf* b : {&sl->keys, &sl->q, &sl->rank, &sl->flags, &sl->rows, &sl->pred, &sl->tree, &sl->ids, &sl->out_iv, &sl->temp,
-                        &sl->rowid, &sl->ckey, &sl->cval, &sl->c_row, &sl->c_lr, &sl->c_q, &sl->c_gid, &sl->col_start, &sl->msg, &sl->ctl}) b->release();
+                        &sl->rowid, &sl->ckey, &sl->cval, &sl->c_row, &sl->c_lr, &sl->c_q, &sl->c_gid, &sl->col_start, &sl->msg, &sl->ctl, &sl->seg}) b->release();
   return DA_OK;
 }
 
@@ -939,6 +940,9 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
   }
   HIP_TRY(c, sl.pred.ensure(sizeof(int32_t) * nn));
   HIP_TRY(c, sl.ids.ensure(sizeof(int32_t) * nn)); HIP_TRY(c, sl.out_iv.ensure(sizeof(int32_t) * 2 * nn));
+  // back-track scratch: the column-major quality array (8 B per match) is free once the forward pass is over
+  HIP_TRY(c, sl.c_q.ensure(sizeof(double) * nn));
+  HIP_TRY(c, sl.seg.ensure(sizeof(int32_t) * 2 * (size_t)std::max<int64_t>(1, da::chain_backtrack_segments(n))));
   HIP_TRY(c, sl.small.ensure(128));
   const size_t tb = sl.mode == 0 ? 0 : da::chain_rows_temp_bytes(n);
   if (sl.mode != 0) {                                                       // the one-workgroup kernels' row starts and tree
@@ -954,6 +958,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
   L.row_start = sl.rows.as<int32_t>(); L.d_nrows = sl.small.as<int32_t>(); L.err = sl.small.as<int32_t>() + 1;
   L.temp = sl.temp.p; L.temp_bytes = tb;
   L.tree_lo = sl.tree.p; L.pred = sl.pred.as<int32_t>(); L.path_ids = sl.ids.as<int32_t>();
+  L.bt_ec = sl.c_q.as<unsigned long long>(); L.bt_seg = sl.seg.as<int32_t>();
   L.xcd = (int)(c->next_ticket % 8);       // successive DPs go to successive XCDs
   L.meta = sl.small.as<int64_t>() + 1; L.out_i = sl.out_iv.as<int32_t>(); L.out_v = sl.out_iv.as<int32_t>() + nn;
   if (rank_from_vlist) {

@@ -442,71 +442,97 @@ __global__ __launch_bounds__(64 * kW4) void k_chain_forward_w4(ChainArgs a) {
   if (tid == 0) { a.meta[0] = (int64_t)s_best_i - 1; a.meta[1] = 0; }
 }
 
-// Back-track from the heaviest point through pred[] (:690-697).  The chain's ids decrease and a
-// predecessor is rarely more than a few rows back, so pred[] is pulled through LDS in fixed blocks of
-// kBackBlock ids (16-byte loads, 1024 threads) and chased there by one lane; the block below is
-// requested into registers before the chase starts, so its trip from HBM hides behind the chase;
-// ids are staged and written out coalesced.
-constexpr int kBackBlock = 16384;
-constexpr int kBackStage = 2048;
-constexpr int kBackThreads = 1024;
+// Back-track from the heaviest point through pred[] (:690-697), in three steps (round 4; rounds 2-3: ONE workgroup that
+// pulled all of pred[] through LDS and chased there -- 17 ms per 2 h pair, 26 % of the DP, bound by that workgroup's
+// 17 GB/s).  The ids of a chain decrease, so pred[] is cut into segments of kSegIds ids:
+//   1. k_bt_exits (one workgroup per segment, all in parallel): for EVERY id k of the segment, where the chain through k
+//      leaves the segment (exit = its first ancestor below the segment) and how many of its nodes lie inside it --
+//      pointer jumping in LDS on 64-bit (count, next) words, in place: a reader sees the old or the new word of another
+//      id, both of which are true statements ("count nodes further on comes `next`"), so no double buffer and no
+//      per-round barrier pair are needed, only the convergence vote.
+//   2. k_bt_walk (one lane): from the heaviest point, hop from segment to segment over the exits -- n / kSegIds dependent
+//      loads instead of one per path point -- recording every visited segment's entry id and output offset.
+//   3. k_bt_fill (one lane per segment, all in parallel): the few path points inside the segment, from its entry.
+// The path comes out as before: ids in descending order.
+constexpr int kSegIds = 8192;
+constexpr int kSegThreads = 256;
+constexpr uint32_t kSegTerm = 0x80000000u;
 
-__global__ __launch_bounds__(kBackThreads) void k_chain_backtrack(const int32_t* __restrict__ pred, int64_t n, int32_t* __restrict__ path_ids,
-                                                                  int64_t* __restrict__ meta, const uint32_t* __restrict__ ctl) {
-  __shared__ int32_t s_pred[2][kBackBlock];
-  __shared__ int32_t s_out[kBackStage];
-  __shared__ int32_t s_cur, s_nout;
-  constexpr int kPer = kBackBlock / kBackThreads;            // ids per thread and block (16): four 16-byte loads
+__global__ __launch_bounds__(kSegThreads) void k_bt_exits(const int32_t* __restrict__ pred, int64_t n, unsigned long long* __restrict__ ec) {
+  __shared__ unsigned long long s_w[kSegIds];                 // (count << 32) | next: local index, or kSegTerm | (exit id + 1)
   const int tid = threadIdx.x;
-  int64_t total = 0;
+  const int64_t lo = (int64_t)blockIdx.x * kSegIds;
+  const int m = (int)((n - lo) < kSegIds ? (n - lo) : kSegIds);
+  for (int k = tid; k < m; k += kSegThreads) {
+    int32_t p = pred[lo + k];
+    if ((int64_t)p >= lo + k) p = -1;                         // predecessors have smaller ids: anything else ends the chain
+    const uint32_t nxt = (int64_t)p >= lo ? (uint32_t)(p - lo) : (kSegTerm | (uint32_t)(p + 1));
+    s_w[k] = (1ull << 32) | nxt;
+  }
+  __syncthreads();
+  while (true) {
+    int changed = 0;
+    for (int k = tid; k < m; k += kSegThreads) {
+      const unsigned long long w = s_w[k];
+      const uint32_t nxt = (uint32_t)w;
+      if (!(nxt & kSegTerm)) {
+        const unsigned long long wj = s_w[nxt];               // nxt < k: another thread's word, read whole (8-byte LDS access)
+        s_w[k] = (((w >> 32) + (wj >> 32)) << 32) | (uint32_t)wj;
+        changed = 1;
+      }
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+  for (int k = tid; k < m; k += kSegThreads) {
+    const unsigned long long w = s_w[k];
+    ec[lo + k] = (w & 0xFFFFFFFF00000000ull) | (uint32_t)(((uint32_t)w & ~kSegTerm) - 1u);    // exit id (0xFFFFFFFF: none)
+  }
+}
+
+__global__ __launch_bounds__(64) void k_bt_walk(const unsigned long long* __restrict__ ec, int64_t n, int32_t* __restrict__ seg_entry,
+                                                int32_t* __restrict__ seg_base, int64_t* __restrict__ meta, const uint32_t* __restrict__ ctl) {
+  if (threadIdx.x != 0) return;
   int32_t cur = (int32_t)meta[0];
   // a column pipeline that gave up (ctl[1], the 20 s neighbour time-out) has left pred[] / meta[0] unwritten: no path
   if ((ctl && ctl[1] != 0u) || (int64_t)cur >= n) cur = -1;
-  int sel = 0;
-  bool have = false;                                         // s_pred[sel] already holds the block of `cur`
-  int4 pre[kPer / 4];
-  auto request = [&](int32_t kb) {                           // block kb -> registers (ids past n read as -1)
-    const int64_t base = (int64_t)kb * kBackBlock + (int64_t)tid * 4;
-#pragma unroll
-    for (int u = 0; u < kPer / 4; ++u) {
-      const int64_t at = base + (int64_t)u * kBackThreads * 4;
-      if (at + 3 < n) pre[u] = *reinterpret_cast<const int4*>(pred + at);
-      else pre[u] = int4{at < n ? pred[at] : -1, at + 1 < n ? pred[at + 1] : -1, at + 2 < n ? pred[at + 2] : -1, -1};
-    }
-  };
-  auto deposit = [&](int into) {
-#pragma unroll
-    for (int u = 0; u < kPer / 4; ++u) *reinterpret_cast<int4*>(&s_pred[into][tid * 4 + u * kBackThreads * 4]) = pre[u];
-  };
+  int64_t total = 0;
   while (cur >= 0) {
-    const int32_t kb = cur / kBackBlock;
-    const int32_t lo = kb * kBackBlock;
-    if (!have) { request(kb); deposit(sel); }
-    __syncthreads();
-    if (kb > 0) request(kb - 1);                             // in flight during the chase
-    while (true) {                                           // chase inside the block, flushing the stage when it fills
-      if (tid == 0) {
-        int32_t m = 0, p = cur;
-        while (p >= lo && m < kBackStage) {
-          s_out[m++] = p;
-          const int32_t np = s_pred[sel][p - lo];
-          p = np < p ? np : -1;                               // predecessors have smaller ids: anything else ends the walk (never a cycle, never more than n ids)
-        }
-        s_cur = p; s_nout = m;
-      }
-      __syncthreads();
-      const int32_t m = s_nout;
-      cur = s_cur;
-      for (int32_t t = tid; t < m; t += kBackThreads) path_ids[total + t] = s_out[t];
-      total += m;
-      __syncthreads();
-      if (cur < lo || m < kBackStage) break;
-    }
-    // cur < lo here (or the chain ended).  Usually it lies in the block just below: the one in the registers.
-    have = false;
-    if (cur >= 0 && kb > 0 && cur / kBackBlock == kb - 1) { sel ^= 1; deposit(sel); have = true; }
+    const unsigned long long w = ec[cur];
+    const int32_t s = cur / kSegIds;
+    seg_entry[s] = cur; seg_base[s] = (int32_t)total;
+    total += (int64_t)(w >> 32);
+    const int32_t nxt = (int32_t)(uint32_t)w;
+    cur = nxt < s * kSegIds ? nxt : -1;                       // an exit lies below its segment: never a cycle, never more than n ids
   }
-  if (tid == 0) meta[1] = total;
+  meta[1] = total;
+}
+
+__global__ __launch_bounds__(64) void k_bt_fill(const int32_t* __restrict__ pred, const int32_t* __restrict__ seg_entry,
+                                                const int32_t* __restrict__ seg_base, int64_t n_seg, int32_t* __restrict__ path_ids) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seg) return;
+  int32_t cur = seg_entry[s];
+  if (cur < 0) return;
+  const int32_t lo = (int32_t)(s * kSegIds);
+  int32_t pos = seg_base[s];
+  while (cur >= lo) {
+    path_ids[pos++] = cur;
+    const int32_t p = pred[cur];
+    cur = p < cur ? p : -1;
+  }
+}
+
+int64_t chain_backtrack_segments(int64_t n) { return (n + kSegIds - 1) / kSegIds; }
+
+// ec: [n] 64-bit words (the column-major quality array is free by now), seg: [2 * segments] int32
+static int launch_backtrack(const int32_t* pred, int64_t n, int32_t* path_ids, int64_t* meta, const uint32_t* ctl,
+                            unsigned long long* ec, int32_t* seg, hipStream_t s) {
+  const int64_t n_seg = chain_backtrack_segments(n);
+  if (hipMemsetAsync(seg, 0xFF, sizeof(int32_t) * (size_t)n_seg, s) != hipSuccess) return -1;
+  hipLaunchKernelGGL(k_bt_exits, dim3((unsigned)n_seg), dim3(kSegThreads), 0, s, pred, n, ec);
+  hipLaunchKernelGGL(k_bt_walk, dim3(1), dim3(64), 0, s, (const unsigned long long*)ec, n, seg, seg + n_seg, meta, ctl);
+  hipLaunchKernelGGL(k_bt_fill, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, s, pred, (const int32_t*)seg, (const int32_t*)(seg + n_seg), n_seg, path_ids);
+  return 0;
 }
 
 // ascending (audio frame, video frame) arrays from the descending id list
@@ -904,7 +930,11 @@ int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream
   a.d_nrows = cc.rowid1 + (c.n - 1);
   a.n_cols = cc.n_cols; a.width = cc.width; a.msg = cc.msg; a.msg_stride = cc.msg_stride; a.ctl = cc.ctl; a.salt = cc.salt;
   a.pred = c.pred; a.meta = c.meta;
-  a.spin_limit = 100000000ull * 20ull;                                 // 20 s
+  {                                                                    // 20 s of the 100 MHz wall clock (DALIGN_CHAIN_SPIN_SECONDS: stress runs with thousands of forced columns beside a GEMM that never lets go of the CUs)
+    unsigned long long secs = 20ull;
+    if (const char* e = std::getenv("DALIGN_CHAIN_SPIN_SECONDS")) secs = (unsigned long long)std::max(1ll, std::atoll(e));
+    a.spin_limit = 100000000ull * secs;
+  }
   a.stamps = reinterpret_cast<unsigned long long*>(cc.ctl + kChainCtlHead + ((cc.n_cols + 1) & ~1));
   const size_t lds = chain_columns_lds_bytes(cc.width);
   const int lv = bit_length(cc.width);
@@ -918,7 +948,7 @@ int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream
   else if (lv <= 11) go(k_chain_columns<11>);
   else if (lv <= 12) go(k_chain_columns<12>);
   else go(k_chain_columns<13>);
-  hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(kBackThreads), 0, s, c.pred, c.n, c.path_ids, c.meta, (const uint32_t*)cc.ctl);
+  if (launch_backtrack(c.pred, c.n, c.path_ids, c.meta, (const uint32_t*)cc.ctl, c.bt_ec, c.bt_seg, s) != 0) return -1;
   hipLaunchKernelGGL(k_chain_gather, dim3(256), dim3(256), 0, s, c.keys, c.path_ids, c.meta, c.out_i, c.out_v);
   return 0;
 }
@@ -984,7 +1014,7 @@ int launch_chain_dp(const ChainLaunch& c, hipStream_t s) {
   DA_CHAIN_CASE(8, 10) DA_CHAIN_CASE(8, 13) DA_CHAIN_CASE(8, 16)
 #undef DA_CHAIN_CASE
   }
-  hipLaunchKernelGGL(k_chain_backtrack, dim3(1), dim3(kBackThreads), 0, s, c.pred, c.n, c.path_ids, c.meta, (const uint32_t*)nullptr);
+  if (launch_backtrack(c.pred, c.n, c.path_ids, c.meta, nullptr, c.bt_ec, c.bt_seg, s) != 0) return -1;
   hipLaunchKernelGGL(k_chain_gather, dim3(256), dim3(256), 0, s, c.keys, c.path_ids, c.meta, c.out_i, c.out_v);
   return 0;
 }

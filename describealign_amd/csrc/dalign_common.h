@@ -172,6 +172,7 @@ struct ChainLaunch {
   int32_t* rank; uint8_t* flags; int32_t* row_start; int32_t* d_nrows; int32_t* err;
   void* temp; size_t temp_bytes;                                // hipCUB select scratch (chain_rows_temp_bytes)
   void* tree_lo; int32_t* pred; int32_t* path_ids; int64_t* meta;
+  unsigned long long* bt_ec; int32_t* bt_seg;                   // back-track scratch: [n] 64-bit (count, exit) words, [2 * chain_backtrack_segments(n)] ints
   int32_t* out_i; int32_t* out_v;                               // the path, ascending
   int xcd;                                                      // XCD the persistent DP workgroup should sit on (-1: any)
   int wide;                                                     // 1: four wavefronts per row super-step (rows of > ~100 matches)
@@ -202,6 +203,7 @@ int chain_columns_batch_rows();
 int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream_t s);
 
 int chain_tree_shift(int64_t n_ranks);
+int64_t chain_backtrack_segments(int64_t n);
 size_t chain_rows_temp_bytes(int64_t n);
 // prep = per-match ranks / row-head flags / validation; dp = row starts, forward DP, back-track, gather.
 // Both return -1 when the input is out of the kernels' range.

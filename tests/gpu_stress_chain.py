@@ -18,6 +18,10 @@ def inst(rng, n, rows, cols, step, quals):
 
 def main():
   budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+  # 4096 forced columns on a 2e5-match instance is nothing the column plan would choose (it gives 8 there): with every CU
+  # held by f32 GEMM workgroups of 1.5 ms each, such a pipeline advances a dozen columns at a time and has been seen to take
+  # 6-25 s (idle chip: 0.15-0.7 s) -- slow, not stuck.  The production limit of 20 s per neighbour wait stays; this run widens it.
+  os.environ.setdefault("DALIGN_CHAIN_SPIN_SECONDS", "600")
   ctx = _native.Context(0, _native.PREC_F32)
   load = _native.Context(0, _native.PREC_F32)
   pair = synth.make_pair(23, 400.0, n_jumps=3, first_gap=40.0)
@@ -42,7 +46,12 @@ def main():
       else: os.environ.pop("DALIGN_CHAIN_COLS", None)
       (busy.set if done % 2 else busy.clear)()
       wi, wv = _native.chain_host(i, v, q)
-      gi, gv = ctx.chain(i, v, q)
+      try:
+        gi, gv = ctx.chain(i, v, q)
+      except Exception:
+        print("FAILED on instance", done, "matches", len(i), "rows", rows, "cols", cols, "step", step, quals, "forced columns", ncol,
+              "under GEMM load" if done % 2 else "idle chip", flush=True)
+        raise
       ok = len(gi) == len(wi) and np.array_equal(gi, wi) and np.array_equal(gv, wv)
       done += 1; tot += len(i)
       if not ok:
