@@ -926,6 +926,52 @@ def test_streaming_ingest_pipe_to_hbm_equals_blocking_upload(ctx, native, tmp_pa
   stream.close()
 
 
+def test_combine_default_path_through_decoder_probe_and_mux_doubles(ctx, tmp_path, monkeypatch):
+  """The reference's default mode (describealign.py:1162-1169: no --stretch_audio) end to end with the external
+  binaries replaced by test doubles (tests/doubles/fake_decoder.py; this image has no ffmpeg): both inputs are decoded
+  through the pipe into HBM, aligned, the key frames around the audio start are asked of ffprobe
+  (get_closest_key_frame_time :451-458), and ffmpeg is run with the re-timing command line of :489-510 -- the argv it
+  RECEIVED is compared with the one built from the alignment; a second call skips the finished output (:1087-1089)."""
+  import json
+  from describealign_amd import combine, media, report
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "doubles"))
+  import fake_decoder
+  bindir = tmp_path / "bin"; bindir.mkdir()
+  fake_decoder.install(bindir)
+  monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ.get("PATH", ""))
+  pair = cases.align_case("e180")
+  media.write_wav(str(tmp_path / "show.wav"), pair.video[None, :] if pair.video.ndim == 1 else pair.video)
+  media.write_wav(str(tmp_path / "ad.wav"), pair.audio[None, :] if pair.audio.ndim == 1 else pair.audio)
+  os.rename(tmp_path / "show.wav", tmp_path / "show.mkv"); os.rename(tmp_path / "ad.wav", tmp_path / "ad.mka")
+  out_dir, plot_dir = str(tmp_path / "out"), str(tmp_path / "plots")
+  os.makedirs(out_dir); os.makedirs(plot_dir)
+  res = combine.process_pair(str(tmp_path / "show.mkv"), str(tmp_path / "ad.mka"), False, ctx, output_dir=out_dir, alignment_dir=plot_dir)
+  g = np.load(os.path.join(GOLD, "align_e180.npz"))
+  assert np.max(np.abs(res["audio_desc_times"] - g["x"])) < HOP_S and np.max(np.abs(res["video_times"] - g["y"])) < HOP_S
+  got = json.loads(open(os.path.join(out_dir, "ad_show.mkv")).read().split("\n")[0])["argv"]
+  x, y = res["audio_desc_times"], res["video_times"]
+  offset = y[0] - x[0]
+  keys = np.arange(0.0, max(60, offset + 40) + 1e-9, fake_decoder.KEY_FRAME_STEP)
+  after = combine.closest_key_frame_time(keys, offset)
+  want = combine._mux_command(str(bindir / "ffmpeg"), str(tmp_path / "show.mkv"), str(tmp_path / "ad.mka"), os.path.join(out_dir, "ad_show.mkv"),
+                              report.encode_fit_as_ffmpeg_expr(x, y, offset), offset, after, res["median_slope"])
+  assert got == want[1:], (got, want[1:])
+  assert "-acodec" in got and got[got.index("-acodec") + 1] == "copy"          # not a .wav description: stream copy (:499)
+  assert res["setts"] in " ".join(got) and os.path.exists(res["report"])
+  assert "FFmpeg command:" in open(res["report"]).read()
+  # skip-existing rule
+  assert combine.process_pair(str(tmp_path / "show.mkv"), str(tmp_path / "ad.mka"), False, ctx, output_dir=out_dir, alignment_dir=plot_dir) is None
+  # --stretch_audio mux: the track goes in through the pipe; a video whose first audio track already is a description
+  os.rename(tmp_path / "show.mkv", tmp_path / "described_show.mkv")
+  res2 = combine.process_pair(str(tmp_path / "described_show.mkv"), str(tmp_path / "ad.mka"), False, ctx, stretch_audio=True,
+                              output_dir=out_dir, alignment_dir=plot_dir)
+  rec = json.loads(open(os.path.join(out_dir, "ad_described_show.mkv")).read().split("\n")[0])
+  assert rec["argv"][:10] == ["-f", "s16le", "-acodec", "pcm_s16le", "-ac", "2", "-ar", "44100", "-i", "pipe:"]
+  assert "visual_impaired+descriptions" in rec["argv"][rec["argv"].index("-disposition:a:1") + 1]
+  assert rec["stdin_bytes"] == 4 * len(pair.video if pair.video.ndim == 1 else pair.video[0])    # stereo s16le frames of the video's length
+  assert res2 is not None
+
+
 def test_bench_launch_contract_two_ranks(tmp_path):
   """The driver launches bench.py under torch.distributed.run, one rank per GPU.  With only one
   GPU here both ranks share it (gloo instead of RCCL, which refuses two ranks on one device): rank 0
