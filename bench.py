@@ -323,6 +323,9 @@ class Bench:
       res["lp_solves_per_s_rank"] = round(lp_rate, 3)                               # this rank's worker processes
       res["lp_solves_per_s_host"] = round(lp_rate * world, 3)                       # all ranks of the node share the host: rank 0's rate x ranks
       res["measured_pairs_per_s"] = round(world * steps / elapsed, 3)
+      if workers > 0 and acc.get("worker_s"):
+        # share of the timed region this rank's worker processes spent inside pass 1 + LP + clustering
+        res["lp_worker_utilisation"] = round((steps / elapsed) * (acc["worker_s"] / k) / workers, 3)
       res["bound"] = "host_lp" if lp_rate < 0.9 * min(gpu_rate, gpu_rate_wall) else "gpu"
       res["bound_note"] = (f"GPU stage {gpu_stage_ms:.1f} ms of kernels per pair ({gpu_rate:.2f} pairs/s; {gpu_rate_wall:.2f} pairs/s by the feeding "
                            f"thread's wall clock); host LP {acc['lp_s'] / k:.2f} s per solve x {max(1, workers)} worker processes = {lp_rate:.2f} solves/s on "

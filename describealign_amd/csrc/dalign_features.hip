@@ -326,7 +326,7 @@ __global__ __launch_bounds__(FeatCfg<C>::kThreads, DA_FEAT_MIN_WAVES) void k_fea
     const int wave = tid >> 6, ml = tid & 63;
     const int64_t mfr = f0 + ml;
     const int g = ml + Cfg::kHalo;
-    if (ml < Cfg::kOut && Cfg::kThreads == 192) {
+    if (ml < Cfg::kOut && wave < 3) {
       if (wave == 0) {
         if (mfr < a.len_other) {
           double b3 = 0.0;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(FeatCfg<C>::kThreads, DA_FEAT_MIN_WAVES) void k_fea
       }
     }
   }
-  static_assert(Cfg::kThreads == 192 && Cfg::kOut <= 64, "stage 4 deals the rows over three waves");
+  static_assert(Cfg::kThreads >= 192 && Cfg::kOut <= 64, "stage 4 deals the rows over three waves");
 }
 
 template <int C> static void launch_one(const FeatArgs& a, const FeatTables* d_tables, hipStream_t s) {

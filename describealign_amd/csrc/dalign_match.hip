@@ -482,7 +482,7 @@ constexpr int kFdRows = 32 * kFdRowTiles;
 constexpr int kFdRowsPerBlock = kFdRows * kFdWaves;
 constexpr int kFdTileBytes = 16 * 64 * 16;        // 16 KiB per 32 rows / columns
 constexpr int kFdSurv = 128 * kFdRowTiles + 64;
-static_assert(kFdRowTiles % 2 == 0 && kFdRowTiles * 64 <= 256, "row tiling");
+static_assert(kFdRowTiles % 2 == 0 && kFdRowTiles * 64 <= 256 && kBfVideoTileGroup % (kFdRowTiles * kFdWaves) == 0, "row tiling");
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct FdTile { f32x4 chunk[16]; };               // this lane's 63 fragments (+ pad) of one 32-column tile
@@ -825,7 +825,8 @@ __device__ inline bool correlate_pair(const VerifyArgs& a, int32_t i, int32_t v,
 // ~90 atomics/us, and there are up to 1e9 pairs).
 constexpr int kVerifyThreads = 256;
 constexpr int kVerifyStage = 1024;
-constexpr int kVerifyCand = kVerifyThreads * 16 + kVerifyThreads;     // a round adds at most 16 pairs per thread to fewer than 256 left over
+constexpr int kVerifyPush = 2;                                        // pairs a thread may add per step-1 pass (a record has 1.03 row bits on average)
+constexpr int kVerifyCand = kVerifyThreads * kVerifyPush + kVerifyThreads;   // a pass adds at most kVerifyPush pairs per thread to fewer than 256 left over
 
 __global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyArgs a, unsigned long long n_rec) {
   __shared__ unsigned long long s_key[kVerifyStage];
@@ -847,46 +848,56 @@ __global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyArgs a, unsigne
     uint32_t mask = (uint32_t)(rec & 0xFFFFull) ^ 0xFFFFu;
     if (i < a.n_a) i = a.alist[i]; else mask = 0u;
     if (p >= n_rec) mask = 0u;
-    while (mask != 0u) {                                              // step 1: expand + vote
-      const int b = __ffs(mask) - 1;
-      mask &= mask - 1u;
-      const int g = bf_bit_row(b);
-      const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
-      const int64_t vr = vtile * 32 + row;
-      if (vr < a.n_v) {
-        const int32_t v = a.vlist[vr];
-        if (vote_pair(a, i, v)) s_cand[atomicAdd(&s_nc, 1u)] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v;
-      }
-    }
-    __syncthreads();
-    const bool last = (rnd + 1 == rounds);
-    while (true) {                                                    // step 2: full batches (any remainder in the last round)
-      const unsigned int nc = s_nc;                                   // uniform: read behind a barrier
-      if (nc < (unsigned)kVerifyThreads && !(last && nc > 0)) break;
-      const unsigned int take = nc < (unsigned)kVerifyThreads ? nc : (unsigned)kVerifyThreads;
-      const unsigned int base = nc - take;
-      if (threadIdx.x < take) {
-        const unsigned long long key = s_cand[base + threadIdx.x];
-        double q;
-        if (correlate_pair(a, (int32_t)(key >> 32), (int32_t)(key & 0xffffffffu), q)) {
-          const unsigned int pos = atomicAdd(&s_n, 1u);               // at most 512 + 256 <= kVerifyStage
-          s_key[pos] = key; s_q[pos] = q;
+    const bool last_round = (rnd + 1 == rounds);
+    while (true) {
+      // step 1: expand + vote, at most kVerifyPush pairs per thread and pass (records with more row bits take another
+      // pass: the candidate buffer stays at 6 KB instead of 35 KB, which doubles the workgroups a CU holds -- this kernel
+      // waits for its gathers, so it lives on occupancy)
+#pragma unroll
+      for (int u = 0; u < kVerifyPush; ++u) {
+        if (mask != 0u) {
+          const int b = __ffs(mask) - 1;
+          mask &= mask - 1u;
+          const int g = bf_bit_row(b);
+          const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
+          const int64_t vr = vtile * 32 + row;
+          if (vr < a.n_v) {
+            const int32_t v = a.vlist[vr];
+            if (vote_pair(a, i, v)) s_cand[atomicAdd(&s_nc, 1u)] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v;
+          }
         }
       }
-      __syncthreads();
-      if (threadIdx.x == 0) s_nc = base;
-      const unsigned int n = s_n;
-      if (n > (unsigned)(kVerifyStage / 2)) {                         // the next batch could overflow the stage
-        if (threadIdx.x == 0) s_base = atomicAdd(a.n_out, (unsigned long long)n);
-        __syncthreads();
-        for (unsigned int t = threadIdx.x; t < n; t += kVerifyThreads) {
-          const unsigned long long gp = s_base + t;
-          if (gp < a.out_capacity) { a.keys[gp] = s_key[t]; a.quals[gp] = s_q[t]; }
+      const bool more = __syncthreads_or(mask != 0u) != 0;            // (also the barrier behind step 1)
+      const bool last = last_round && !more;
+      while (true) {                                                  // step 2: full batches (any remainder at the very end)
+        const unsigned int nc = s_nc;                                 // uniform: read behind a barrier
+        if (nc < (unsigned)kVerifyThreads && !(last && nc > 0)) break;
+        const unsigned int take = nc < (unsigned)kVerifyThreads ? nc : (unsigned)kVerifyThreads;
+        const unsigned int base = nc - take;
+        if (threadIdx.x < take) {
+          const unsigned long long key = s_cand[base + threadIdx.x];
+          double q;
+          if (correlate_pair(a, (int32_t)(key >> 32), (int32_t)(key & 0xffffffffu), q)) {
+            const unsigned int pos = atomicAdd(&s_n, 1u);             // at most 512 + 256 <= kVerifyStage
+            s_key[pos] = key; s_q[pos] = q;
+          }
         }
         __syncthreads();
-        if (threadIdx.x == 0) s_n = 0;
+        if (threadIdx.x == 0) s_nc = base;
+        const unsigned int n = s_n;
+        if (n > (unsigned)(kVerifyStage / 2)) {                       // the next batch could overflow the stage
+          if (threadIdx.x == 0) s_base = atomicAdd(a.n_out, (unsigned long long)n);
+          __syncthreads();
+          for (unsigned int t = threadIdx.x; t < n; t += kVerifyThreads) {
+            const unsigned long long gp = s_base + t;
+            if (gp < a.out_capacity) { a.keys[gp] = s_key[t]; a.quals[gp] = s_q[t]; }
+          }
+          __syncthreads();
+          if (threadIdx.x == 0) s_n = 0;
+        }
+        __syncthreads();
       }
-      __syncthreads();
+      if (!more) break;
     }
   }
   const unsigned int n = s_n;                                         // what is left in the stage

@@ -10,6 +10,7 @@ values are recorded.  Intermediates are read from the live `align` frame with a
 
   python tests/golden/make_golden.py [case ...]
 
+`matches:<case>` records the stage-2 matches of every 64th audio frame of a config-sized pair (MatchSampleProbe).
 `stretch:<case>` records replace_aligned_segments (describealign.py:230-416) on the
 STRETCH_CASES inputs: the float16 bits of every replaced interval and each jump schedule.
 
@@ -190,6 +191,54 @@ def gen_align(name: str, deep: bool):
   return meta, cap
 
 
+class MatchSampleProbe:
+  """Stage-2 matches of every `every`-th audio frame of the reference's align() (line hook at describealign.py:674, where
+  `match_points` of audio frame i is complete), plus the total number of matches: a config-sized stage-2 fixture that stays
+  small (the full list of a 22-minute pair is 2e6 matches)."""
+
+  def __init__(self, every):
+    self.every = every
+    self.keys, self.quals, self.total, self.rows = [], [], 0, 0
+
+  def _global(self, frame, event, arg):
+    if event == "call" and frame.f_code.co_name == "align" and frame.f_code.co_filename == REF_FILE:
+      return self._local
+    return None
+
+  def _local(self, frame, event, arg):
+    if event == "line" and frame.f_lineno == 674:
+      L = frame.f_locals
+      i = L["i"]; mp = L["match_points"]
+      self.total += len(mp); self.rows += 1
+      if i % self.every == 0:
+        for v, q in sorted(mp):
+          self.keys.append((int(i) << 32) | int(v)); self.quals.append(float(q))
+    return self._local
+
+  def run(self, vf, af):
+    sys.settrace(self._global)
+    try:
+      res = ref.align(vf, af, vf[0], af[0])
+    finally:
+      sys.settrace(None)
+    return res
+
+
+def gen_match_sample(name: str, every: int = 64):
+  """`matches:<case>`: sampled stage-2 matches of a config-sized pair (see MatchSampleProbe)."""
+  t0 = time.time()
+  pair = cases.align_case(name)
+  vf, af = ref_features(pair.video), ref_features(pair.audio)
+  probe = MatchSampleProbe(every)
+  x, y, sim, path, med = probe.run(vf, af)
+  np.savez_compressed(os.path.join(HERE, f"matches_{name}.npz"), keys=np.array(probe.keys, dtype=np.int64),
+                      quals=np.array(probe.quals, dtype=np.float64), total=np.int64(probe.total), rows=np.int64(probe.rows),
+                      every=np.int64(every), x=x, y=y)
+  print(f"[matches:{name}] {probe.total} matches over {probe.rows} audio frames, {len(probe.keys)} recorded (every {every}th frame), "
+        f"{time.time() - t0:.0f} s")
+  return dict(sha1=pair.sha1(), total=int(probe.total), recorded=len(probe.keys), every=every)
+
+
 class StretchProbe:
   """Records the jump schedule of every call of the reference's nested `stretch`
   (describealign.py:298-385) from its frame at return."""
@@ -321,6 +370,8 @@ def main(argv):
       index.setdefault("combine_stretch", {})[name[16:]] = gen_combine_stretch(name[16:])
     elif name.startswith("stretch:"):
       index.setdefault("stretch", {})[name[8:]] = gen_stretch(name[8:])
+    elif name.startswith("matches:"):
+      index.setdefault("matches", {})[name[8:]] = gen_match_sample(name[8:])
     else:
       meta, _ = gen_align(name, deep=(name == "a40"))
       index.setdefault("align", {})[name] = meta
