@@ -234,7 +234,7 @@ class Bench:
       add("lp_s", tm["lp_s"]); add("match_s", tm["match_s"]); add("chain_s", tm["chain_s"])
       add("n_path1", tm["n_path1"]); add("n_fit_points", tm["n_fit_points"])
       add("align_s", tm["match_s"] + tm["chain_s"] + tm["pass1_host_s"] + tm["lp_s"] + tm["cluster_s"] + tm["refine_s"] + tm["nodes_s"])
-      for name in ("pass1_host_s", "cluster_s", "refine_s", "nodes_s", "worker_s"):
+      for name in ("pass1_host_s", "cluster_s", "refine_s", "nodes_s", "worker_s", "features_s", "pace_s", "chain_begin_s"):
         add(name, tm.get(name, 0.0))
       if "t_handoff" in tm and "done_t" in tm:      # where a pair spends its time between the stages (pipelined runs)
         add("iv_copy", tm["t_copied"] - tm["t_handoff"]); add("iv_wait_for_worker_slot", tm["t_submitted"] - tm["t_copied"])
@@ -297,6 +297,8 @@ class Bench:
                             "worker_busy": round(acc.get("worker_s", 0.0) / k, 4), "pass1": round(acc.get("pass1_host_s", 0.0) / k, 4),
                             "cluster": round(acc.get("cluster_s", 0.0) / k, 4), "refine": round(acc.get("refine_s", 0.0) / k, 4),
                             "nodes": round(acc.get("nodes_s", 0.0) / k, 4),
+                            "gpu_thread": {"pace_wait": round(acc.get("pace_s", 0.0) / k, 4), "features_incl_download": round(acc.get("features_s", 0.0) / k, 4),
+                                           "match_begin_to_finish": round(acc["match_s"] / k, 4), "chain_begin": round(acc.get("chain_begin_s", 0.0) / k, 4)},
                             "intervals": {n[3:]: round(acc[n] / k, 4) for n in sorted(acc) if n.startswith("iv_")}},
         "pipeline": {"lp_worker_processes": workers, "gpu_streams": len(gpu_ctxs), "host_cores": os.cpu_count(),
                      "worker_count_rationale": "1.5 worker processes per L3 domain of the host (align.default_worker_count): one HiGHS solve of a long pair "

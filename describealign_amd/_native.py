@@ -233,6 +233,7 @@ class Context:
     self._channels = {}
     self._rows = {}
     self._inflight = {}
+    self._pool = []      # recycled result buffers (see _recycled)
 
   def close(self):
     if getattr(self, "_h", None) is not None and self._h:
@@ -326,12 +327,29 @@ class Context:
       self._inflight.pop(side, None)
       return None
     le = ((self._n[side] // 105) + 1) // 2
-    out = np.empty((5, max(le, 1)), dtype=np.float32)
+    self._rows.pop(side, None)                   # the previous rows of this side: free for recycling once the caller drops them
+    out = self._recycled((5, max(le, 1)), np.float32)
     self._check(self._lib.da_features_resident(self._h, side, _ptr(out), out.shape[1], lengths))
     self._inflight.pop(side, None)               # the asynchronous upload (if any) has been consumed
     le, lo = lengths[0], lengths[1]
     self._rows[side] = (out, le, lo)           # match_begin recognises these rows and skips their upload
     return [out[0, :le]] + [out[k, :lo] for k in range(1, 5)]      # row views of one buffer
+
+  def _recycled(self, shape, dtype):
+    """A result buffer of this shape that nobody holds any more, else a new one.  The rows handed out are VIEWS of their
+    buffer, so CPython's reference count says exactly when the caller (and whoever it passed them to) is done with it.
+    Why: a 2 h side's rows are 30 MB; allocated afresh per pair they arrive as new mmap'd pages, zeroed and faulted in
+    under the process-wide address-space lock that every other thread of a batch pipeline needs for its own buffers."""
+    import sys
+    pool = self._pool
+    for k, buf in enumerate(pool):
+      if buf.shape == tuple(shape) and buf.dtype == dtype and sys.getrefcount(buf) == 3:     # the pool, `buf`, getrefcount's argument
+        return buf
+    buf = np.empty(shape, dtype=dtype)
+    pool.append(buf)
+    if len(pool) > 24:                           # shapes that no longer occur
+      pool[:] = [b for b in pool if sys.getrefcount(b) > 3][-16:] + [buf]
+    return buf
 
   def features(self, pcm: np.ndarray, side: int = SIDE_VIDEO):
     """Upload + feature kernel: the five feature rows as a list of float32 arrays."""
@@ -490,8 +508,10 @@ class Context:
     off = np.ascontiguousarray(cl_offset, dtype=np.float64); sl = np.ascontiguousarray(cl_slope, dtype=np.float64)
     cap = len(a) + len(v) + 16
     for _ in range(2):
-      path = np.empty((cap, 5), dtype=np.float64)
-      rows = C.c_int64(cap); npts = C.c_int64(0)
+      path = getattr(self, "_refine_buf", None)    # the capacity buffer is this context's own and is never handed out
+      if path is None or len(path) < cap:
+        path = self._refine_buf = np.empty((cap, 5), dtype=np.float64)
+      rows = C.c_int64(len(path)); npts = C.c_int64(0)
       rc = self._lib.da_refine(self._h, _ptr(a), len(a), _ptr(v), len(v), _ptr(x0), _ptr(x1), _ptr(off),
                                _ptr(sl), len(x0), float(min_len), _ptr(path), C.byref(rows), C.byref(npts))
       if rc == ERR_CAPACITY:

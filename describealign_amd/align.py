@@ -772,8 +772,10 @@ class AlignPipeline:
     try:
       with self._lock:
         self._queued[id(ctx)] = self._queued.get(id(ctx), 0) - 1
+      tp = time.perf_counter()
       self._pace(ctx)
       t0 = time.perf_counter()
+      tm["pace_s"] = t0 - tp
       vf, af = job(ctx) if callable(job) else job
       tm["features_s"] = time.perf_counter() - t0
       t1 = time.perf_counter()
@@ -783,7 +785,10 @@ class AlignPipeline:
       tm["device"] = ctx.stats()
       tm["match_s"] = time.perf_counter() - t1
       tm["n_matches"] = n
+      t2 = time.perf_counter()
       ticket = ctx.chain_begin()
+      tm["chain_begin_s"] = time.perf_counter() - t2
+      tm["t_gpu_stage_end"] = time.perf_counter()
       self._chains.setdefault(id(ctx), []).append((ticket, vf, af, tm, fname, done, time.perf_counter()))
     except BaseException as e:
       with self._lock:
@@ -799,6 +804,7 @@ class AlignPipeline:
     at the GPU's rate followed by a stall.  No effect while the GPU stage is the slower one."""
     if not self.pace:
       return
+    waited = False
     while True:
       with self._lock:
         ema, in_flight = self._work_ema, self._n_admitted - self._n_done
@@ -809,8 +815,14 @@ class AlignPipeline:
         wait = self._last_admit + 0.97 * ema / (self.depth * max(1, len(self.gpu_ctxs))) - time.perf_counter()
       if wait <= 0:
         break
+      waited = True
       self._collect_chains(ctx)                          # finished DPs are still handed on while waiting
       time.sleep(min(wait, 0.004))
+    if waited:
+      # host-bound: the GPU has time to spare, so the chain DPs still in flight (57 ms each) are let finish before the next
+      # similarity GEMM starts -- beside a DP the GEMM loses the CUs its columns sit on (a column wave's 152 registers and a
+      # GEMM wave's 428 do not fit one SIMD); when the GPU stage is the slower one nothing is waited for and they overlap
+      self._collect_chains(ctx, block_above=0)
     with self._lock:
       self._n_admitted += 1
     self._last_admit = time.perf_counter()

@@ -26,9 +26,18 @@ struct DevBuf {
   size_t cap = 0;
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    static const bool dbg = std::getenv("DALIGN_DEBUG_TIMES") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t had = cap;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    const auto t1 = std::chrono::steady_clock::now();
     size_t want = bytes + bytes / 8 + 4096;
     hipError_t e = hipMalloc(&p, want);
+    if (dbg) {
+      const auto t2 = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[DevBuf] %zu -> %zu bytes: hipFree %.3f ms, hipMalloc %.3f ms\n", had, want,
+                   std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
     if (e != hipSuccess) { p = nullptr; return e; }
     cap = want;
     return hipSuccess;
@@ -77,6 +86,33 @@ struct ChainSlot {
 };
 constexpr int kMaxChainSlots = 16;
 
+// The column DP's per-(column, row) hand-over records are its largest buffer by far (2 h pair at 1 024 columns: 16 GB, 8 h
+// pair: 60 GB).  They belong to the context, not to a slot: a slot takes one for the DP it launches and gives it back when the
+// DP is collected, so the context holds as many as DPs were ever in flight together (two or three), not one per slot touched,
+// and a pair does not pay a 16 GB hipMalloc + memset (measured: 0.3 ms most of the time, 2-5 s every ~15th call, with the
+// GPU-feeding thread stalled inside it).  `launches` travels with the buffer (the tag salt of its next DP).
+struct HandoverBuf { DevBuf buf; unsigned launches = 0; };
+constexpr size_t kHandoverKeep = 3;
+
+// ---- pass 2 on the host: points of the banded extension, state of the second DP
+struct BandPoint { double j; int32_t i; int32_t cl; double q; };
+struct DpEntry { double j; int32_t i; int32_t cl; double q; double cum; int32_t id; uint32_t gen; };
+// Host arrays of da_refine, kept between calls.  A 2 h pair needs ~270 MB of them (1.8e6 points, one cache slot per video
+// frame, back-pointers, the path): allocated afresh per call they arrive as new mmap'd pages -- zeroed and faulted in under the
+// process-wide address-space lock, which also the GPU-feeding thread, the hand-off threads and the other refine threads of a
+// pipeline take for their own buffers: measured, da_refine took 0.6 s per 2 h pair of which the DP itself is 0.085 s, and the
+// pipeline delivered 2.0 pairs/s with its LP workers 56 % busy.  The cache slots carry a generation number instead of being
+// cleared (60 MB) per call.
+struct RefineScratch {
+  std::vector<double> hj, hq, fmin, pred_cum, out;
+  std::vector<int32_t> hi, hcl, pred;
+  std::vector<BandPoint> pts;
+  std::vector<int64_t> row_start;
+  std::vector<DpEntry> cache, frontier, cl_best;
+  std::vector<std::pair<int32_t, double>> rev;
+  uint32_t gen = 0;
+};
+
 double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -94,12 +130,14 @@ struct da_ctx {
   DevBuf tables, hann41;
   DevBuf vlist, alist, surv, counters, keys0, q0, sort_tmp, rankmap, rowscratch, bfv, bfa;
   std::vector<ChainSlot*> slots;  // sorted match lists live in slots (see ChainSlot)
+  std::vector<HandoverBuf> handover_free;   // hand-over buffers not in use by a DP (see HandoverBuf)
   int res_slot = -1;              // slot holding the results of the last finished match
   int import_slot = -1;           // slot reserved by da_match_import_reserve (state 3) until da_match_import_commit
   unsigned long long next_ticket = 1;
   int64_t res_lv = 0;             // video frames of the last match (rank map size)
   DevBuf pair_i, pair_v, pair_c;
   DevBuf ascaled, vscaled, band_y, band_q, band_part, band_tab, band_cl, band_keys, band_ids, band_head, band_out, band_tmp;
+  RefineScratch refine;
   bool match_ready = false;
   unsigned long long n_match_resident = 0;
   // state carried from da_match_begin to da_match_finish
@@ -131,6 +169,19 @@ int fail(da_ctx* c, int code, const char* fmt, ...) {
     if (e_ != hipSuccess)                                                                       \
       return fail((c), DA_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
+
+// a slot's hand-over buffer returns to the context (see HandoverBuf); beyond kHandoverKeep the smallest one is freed
+void give_back_handover(da_ctx* c, ChainSlot& sl) {
+  if (!sl.msg.p) return;
+  c->handover_free.push_back(HandoverBuf{sl.msg, sl.launches});
+  sl.msg = DevBuf{}; sl.launches = 0;
+  if (c->handover_free.size() > kHandoverKeep) {
+    size_t small = 0;
+    for (size_t k = 1; k < c->handover_free.size(); ++k) if (c->handover_free[k].buf.cap < c->handover_free[small].buf.cap) small = k;
+    c->handover_free[small].buf.release();
+    c->handover_free.erase(c->handover_free.begin() + (long)small);
+  }
+}
 
 // a free chain slot (creating one if needed); -1 when all kMaxChainSlots are in flight
 int acquire_slot(da_ctx* c) {
@@ -238,6 +289,7 @@ void da_destroy(da_ctx* c) {
                    &c->band_out, &c->band_tmp};
   for (DevBuf* b : all) b->release();
   for (ChainSlot* sl : c->slots) { if (sl->stream) (void)hipStreamSynchronize(sl->stream); sl->release(); delete sl; }
+  for (HandoverBuf& h : c->handover_free) h.buf.release();
   c->slots.clear();
   c->st_video.release(); c->st_audio.release(); c->st_out.release();
   da::stretch_destroy(c->stretch); c->stretch = nullptr;
@@ -810,6 +862,7 @@ extern "C" int da_trim(da_ctx* c) {
   for (DevBuf* b : {&c->surv, &c->bfv, &c->bfa, &c->q0, &c->sort_tmp, &c->rowscratch, &c->rankmap, &c->band_y, &c->band_q, &c->band_part, &c->band_cl,
                     &c->band_keys, &c->band_ids, &c->band_head, &c->band_out, &c->band_tmp, &c->pair_i, &c->pair_v, &c->pair_c})
     b->release();
+  { RefineScratch none; std::swap(c->refine, none); }       // host arrays of da_refine
   // keys0 holds the unpacked (i, v) of the resident matches for da_match_fetch: shrink it to what they need
   c->keys0.release();
   if (c->fetch_ready && c->res_slot >= 0 && c->n_match_resident > 0) {
@@ -819,6 +872,8 @@ extern "C" int da_trim(da_ctx* c) {
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
+  for (HandoverBuf& h : c->handover_free) h.buf.release();
+  c->handover_free.clear();
   for (ChainSlot* sl : c->slots)
     if (sl->state == 0)
       for (DevBuf* b : {&sl->keys, &sl->q, &sl->rank, &sl->flags, &sl->rows, &sl->pred, &sl->tree, &sl->ids, &sl->out_iv, &sl->temp,
@@ -926,7 +981,16 @@ int chain_host(da_ctx* c, const int32_t* pi, const int32_t* pv, const double* pq
 
 // enqueue the device DP of slot `sl` (sorted keys / q resident).  The per-match ranks come either
 // from the video row list of the match (rank_from_vlist) or have been uploaded into sl.rank.
+// DALIGN_DEBUG_TIMES=1: wall-clock stamps of the host side of chain_enqueue on stderr (where does the calling thread wait?)
+struct DbgTimes {
+  bool on; double t0, last; const char* who;
+  explicit DbgTimes(const char* w) : on(std::getenv("DALIGN_DEBUG_TIMES") != nullptr), t0(now_ms()), last(t0), who(w) {}
+  void at(const char* what) { if (on) { const double t = now_ms(); std::fprintf(stderr, "[%s] %-28s +%8.3f ms\n", who, what, t - last); last = t; } }
+  ~DbgTimes() { if (on) std::fprintf(stderr, "[%s] total %8.3f ms\n", who, now_ms() - t0); }
+};
+
 int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
+  DbgTimes dbg("chain_enqueue");
   const int64_t n = sl.n;
   const size_t nn = (size_t)std::max<int64_t>(1, n);
   HIP_TRY(c, sl.rank.ensure(sizeof(int32_t) * nn)); HIP_TRY(c, sl.flags.ensure(nn));
@@ -950,6 +1014,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     HIP_TRY(c, sl.tree.ensure(16 * ((size_t)sl.n_ranks + 2 + 256)));       // + one scrap record per thread
     HIP_TRY(c, sl.temp.ensure(tb + 256));
   }
+  dbg.at("ensure (common)");
   hipStream_t st = sl.stream;
   // `small`: int32 [0] rows, [1] err; int64 [1] best id, [2] path length
   ChainLaunch L{};
@@ -970,6 +1035,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     L.rankmap = c->rankmap.as<int32_t>(); L.rankmap_len = c->res_lv;
   }
   HIP_TRY(c, hipMemsetAsync(sl.small.p, 0, 128, c->stream));
+  dbg.at("rank map");
   L.wide = sl.mode == 4;
   da::ChainColumns K{};
   if (sl.mode == 0 && n > 0) {
@@ -987,8 +1053,24 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     {
       // granule tags must never match what an earlier launch left behind: fresh memory and every 4095th
       // launch are zeroed, in between the salt distinguishes the launches
+      const size_t need = 24 * (size_t)K.msg_stride * (size_t)K.n_cols;
+      if (sl.msg.cap < need) {
+        give_back_handover(c, sl);
+        size_t best = c->handover_free.size();
+        for (size_t k = 0; k < c->handover_free.size(); ++k)
+          if (c->handover_free[k].buf.cap >= need && (best == c->handover_free.size() || c->handover_free[k].buf.cap < c->handover_free[best].buf.cap)) best = k;
+        if (best != c->handover_free.size()) {
+          sl.msg = c->handover_free[best].buf; sl.launches = c->handover_free[best].launches;
+          c->handover_free.erase(c->handover_free.begin() + (long)best);
+        } else if (!c->handover_free.empty()) {            // none fits: the largest one is regrown rather than kept beside a new one
+          size_t big = 0;
+          for (size_t k = 1; k < c->handover_free.size(); ++k) if (c->handover_free[k].buf.cap > c->handover_free[big].buf.cap) big = k;
+          c->handover_free[big].buf.release();
+          c->handover_free.erase(c->handover_free.begin() + (long)big);
+        }
+      }
       const size_t cap_before = sl.msg.cap;
-      HIP_TRY(c, sl.msg.ensure(24 * (size_t)K.msg_stride * (size_t)K.n_cols));
+      HIP_TRY(c, sl.msg.ensure(need));
       if (sl.msg.cap != cap_before || sl.launches >= 4095) {
         HIP_TRY(c, hipMemsetAsync(sl.msg.p, 0, sl.msg.cap, c->stream));
         sl.launches = 0;
@@ -1005,23 +1087,28 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     K.temp = sl.temp.p; K.temp_bytes = ctb;
     L.temp = sl.temp.p;
     c->st.chain_columns = (double)K.n_cols; c->st.chain_column_width = (double)K.width;
+    dbg.at("ensure (columns) + msg");
   } else {
     if (sl.mode != 0) HIP_TRY(c, hipMemsetAsync(sl.tree.p, 0, 16 * ((size_t)sl.n_ranks + 2), c->stream));
     c->st.chain_columns = 0; c->st.chain_column_width = 0;
   }
   if (da::launch_chain_prep(L, c->stream, sl.mode == 0) != 0) return fail(c, DA_ERR_ARG, "da_chain: %lld matches / %lld video rows exceed the kernel's range", (long long)n, (long long)sl.n_ranks);
   HIP_TRY(c, hipGetLastError());
+  dbg.at("prep launch");
   HIP_TRY(c, hipEventRecord(sl.ready, c->stream));
   HIP_TRY(c, hipStreamWaitEvent(st, sl.ready, 0));
   HIP_TRY(c, hipEventRecord(sl.e0, st));
+  dbg.at("events");
   if (sl.mode == 0) {
     if (da::launch_chain_columns(L, K, st) != 0) return fail(c, DA_ERR_DEVICE, "da_chain: launch failed");
   } else if (da::launch_chain_dp(L, st) != 0) return fail(c, DA_ERR_DEVICE, "da_chain: launch failed");
   HIP_TRY(c, hipGetLastError());
+  dbg.at("DP launches");
   HIP_TRY(c, hipEventRecord(sl.e1, st));
   HIP_TRY(c, hipMemcpyAsync(sl.h_small, sl.small.p, 32, hipMemcpyDeviceToHost, st));
   sl.h_small[4] = 0;
   if (sl.mode == 0 && n > 0) HIP_TRY(c, hipMemcpyAsync(sl.h_small + 4, sl.ctl.p, 8, hipMemcpyDeviceToHost, st));   // [1] = abort flag
+  dbg.at("result copies");
   sl.state = 2;
   sl.ticket = c->next_ticket++;
   return DA_OK;
@@ -1031,9 +1118,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
 int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
   HIP_TRY(c, hipStreamSynchronize(sl.stream));
   float ms = 0.f; (void)hipEventElapsedTime(&ms, sl.e0, sl.e1); c->st.chain_ms = ms;
-  // the per-(column, row) hand-over records are the DP's largest buffer (2 h pair: 2.6 GB, 8 h pair at 1 024 columns: 28 GB):
-  // a long pair's copy is given back at once instead of sitting in the slot until da_trim (up to 16 slots per context)
-  if (sl.msg.cap > ((size_t)6 << 30)) { sl.msg.release(); sl.launches = 0; }
+  give_back_handover(c, sl);
   if (std::getenv("DALIGN_DEBUG_STAMPS") && sl.mode == 0 && sl.n > 0) {   // diagnostic builds (-DDA_CHAIN_STAMPS) only
     const int nc = (int)c->st.chain_columns;
     std::vector<unsigned long long> st((size_t)nc * 8);
@@ -1178,8 +1263,6 @@ extern "C" int da_chain_resident(da_ctx* c, double min_len, int32_t* path_i, int
 // ------------------------------------------------------------------------------------- refine
 namespace {
 
-struct BandPoint { double j; int32_t i; int32_t cl; double q; };
-
 void x_limits(double x_first, double x_last, double offset, double slope, int64_t La, int64_t Lv, int64_t extend,
               int64_t& lo, int64_t& hi) {                       // describealign.py:895-900
   const int64_t margin = 4;
@@ -1190,22 +1273,28 @@ void x_limits(double x_first, double x_last, double offset, double slope, int64_
 }
 
 // Second DP (describealign.py:946-990) over points sorted by (i, j, cluster, qual).
-// Returns rows (j, i, cluster, qual, cum-as-used-by-the-successor).
-void second_dp(const std::vector<BandPoint>& pts, const std::vector<int64_t>& row_start, int64_t La, int64_t Lv,
-               int n_clusters, std::vector<double>& path_rows) {
-  struct Entry { double j; int32_t i; int32_t cl; double q; double cum; int32_t id; };
-  const double NEG = -std::numeric_limits<double>::infinity();
-  std::vector<Entry> frontier;                       // sorted by j, cum strictly increasing
-  frontier.push_back(Entry{0.0, 0, -1, 0.0, 0.0, -1});
-  std::vector<Entry> cl_best((size_t)n_clusters, Entry{0.0, 0, 0, 0.0, -1000.0, -1});
-  std::vector<Entry> cache((size_t)Lv, Entry{NEG, 0, 0, NEG, NEG, -2});     // id -2: empty slot
-  std::vector<double> cache_i((size_t)Lv, NEG);
-  cache[0] = Entry{0.0, 0, -1, 0.0, 0.0, -1}; cache_i[0] = 0.0;
+// Returns rows (j, i, cluster, qual, cum-as-used-by-the-successor) in S.out.
+void second_dp(RefineScratch& S, int64_t La, int64_t Lv, int n_clusters) {
+  using Entry = DpEntry;
+  const std::vector<BandPoint>& pts = S.pts;
+  const std::vector<int64_t>& row_start = S.row_start;
+  std::vector<double>& path_rows = S.out;
+  if (++S.gen == 0u) { S.cache.clear(); S.gen = 1u; }           // generation wrap: forget every slot
+  const uint32_t gen = S.gen;
+  std::vector<Entry>& frontier = S.frontier;                    // sorted by j, cum strictly increasing
+  frontier.clear();
+  frontier.push_back(Entry{0.0, 0, -1, 0.0, 0.0, -1, gen});
+  std::vector<Entry>& cl_best = S.cl_best;
+  cl_best.assign((size_t)n_clusters, Entry{0.0, 0, 0, 0.0, -1000.0, -1, gen});
+  std::vector<Entry>& cache = S.cache;                          // one slot per video frame; a slot of another generation is empty
+  if (cache.size() < (size_t)Lv) cache.resize((size_t)Lv, Entry{0.0, 0, 0, 0.0, 0.0, -2, 0u});
+  cache[0] = Entry{0.0, 0, -1, 0.0, 0.0, -1, gen};
   const size_t np = pts.size();
-  std::vector<int32_t> pred(np, -1);
-  std::vector<double> pred_cum(np, 0.0);
+  std::vector<int32_t>& pred = S.pred; pred.assign(np, -1);
+  std::vector<double>& pred_cum = S.pred_cum; pred_cum.assign(np, 0.0);
   // forward_min[i]: smallest j among rows >= i
-  std::vector<double> fmin((size_t)La + 1, std::numeric_limits<double>::infinity());
+  std::vector<double>& fmin = S.fmin;
+  fmin.assign((size_t)La + 1, std::numeric_limits<double>::infinity());
   for (int64_t i = La - 1; i >= 0; --i) {
     double m = fmin[i + 1];
     if (row_start[i + 1] > row_start[i]) m = std::min(m, pts[row_start[i]].j);
@@ -1225,7 +1314,7 @@ void second_dp(const std::vector<BandPoint>& pts, const std::vector<int64_t>& ro
       const int64_t jj = (int64_t)j;
       for (int64_t t = std::max<int64_t>(0, jj - 2); t <= jj; ++t) {
         const Entry& nd = cache[t];
-        if (nd.id == -2) continue;                   // -inf slot: every comparison is false
+        if (nd.gen != gen) continue;                 // -inf slot: every comparison is false
         double cum = nd.cum;
         if (pt.cl != nd.cl) {
           const double skew = (j - nd.j) - ((double)i - (double)nd.i);
@@ -1234,23 +1323,24 @@ void second_dp(const std::vector<BandPoint>& pts, const std::vector<int64_t>& ro
         if ((double)nd.i >= (double)(i - 2) && nd.j <= j && cum >= best) { pid = nd.id; best = cum; }
       }
       const double cum = best + pt.q;
-      cache[jj] = Entry{j, (int32_t)i, pt.cl, pt.q, cum, (int32_t)p};
+      cache[jj] = Entry{j, (int32_t)i, pt.cl, pt.q, cum, (int32_t)p, gen};
       const double cjump = cum - 1000.0;
       if (frontier[pos - 1].cum < cjump) {
         size_t end = pos;
         while (end < frontier.size() && frontier[end].cum <= cjump) ++end;
         frontier.erase(frontier.begin() + pos, frontier.begin() + end);
-        frontier.insert(frontier.begin() + pos, Entry{j, (int32_t)i, pt.cl, pt.q, cjump, (int32_t)p});
+        frontier.insert(frontier.begin() + pos, Entry{j, (int32_t)i, pt.cl, pt.q, cjump, (int32_t)p, gen});
       }
       if (fmin[i] == j && pos > 1) frontier.erase(frontier.begin(), frontier.begin() + (pos - 1));
       const double ccl = cum - 50.0;
-      if (last.cum < ccl) cl_best[pt.cl] = Entry{j, (int32_t)i, pt.cl, pt.q, ccl, (int32_t)p};
+      if (last.cum < ccl) cl_best[pt.cl] = Entry{j, (int32_t)i, pt.cl, pt.q, ccl, (int32_t)p, gen};
       pred[p] = pid; pred_cum[p] = best;
     }
   }
   // backtrack from the last frontier entry (:985-989)
   path_rows.clear();
-  std::vector<std::pair<int32_t, double>> rev;       // (point id, cum as recorded)
+  std::vector<std::pair<int32_t, double>>& rev = S.rev;         // (point id, cum as recorded)
+  rev.clear();
   const Entry& lastf = frontier.back();
   if (lastf.id >= 0) {
     rev.emplace_back(lastf.id, lastf.cum);
@@ -1347,7 +1437,9 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
   }
   // ---- quality of every banded point, de-duplication on (audio frame, int(video position)) keeping
   // the first cluster's point (:937-941), in (audio frame, video position) order -- all on the device
-  std::vector<BandPoint> pts;
+  RefineScratch& S = c->refine;
+  std::vector<BandPoint>& pts = S.pts;
+  pts.clear();
   int64_t total_points = 0;
   if (n_all > 0x7fffffffLL) return fail(c, DA_ERR_ARG, "da_refine: %lld banded points exceed the kernels' range", (long long)n_all);
   if (n_all > 0) {
@@ -1385,8 +1477,9 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); kernel_ms += ms;
     total_points = n_kept;
-    std::vector<double> hj((size_t)n_kept), hq((size_t)n_kept);
-    std::vector<int32_t> hi_((size_t)n_kept), hcl((size_t)n_kept);
+    std::vector<double>& hj = S.hj; std::vector<double>& hq = S.hq;
+    std::vector<int32_t>& hi_ = S.hi; std::vector<int32_t>& hcl = S.hcl;
+    hj.resize((size_t)n_kept); hq.resize((size_t)n_kept); hi_.resize((size_t)n_kept); hcl.resize((size_t)n_kept);
     if (n_kept > 0) {
       HIP_TRY(c, hipMemcpyAsync(hj.data(), o_j, sizeof(double) * n_kept, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipMemcpyAsync(hq.data(), o_q, sizeof(double) * n_kept, hipMemcpyDeviceToHost, c->stream));
@@ -1401,7 +1494,8 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
   c->st.refine_points = (double)total_points;
   if (n_points) *n_points = total_points;
   const double t0 = now_ms();
-  std::vector<int64_t> row_start((size_t)La + 1, 0);
+  std::vector<int64_t>& row_start = S.row_start;
+  row_start.assign((size_t)La + 1, 0);
   {
     size_t p = 0;
     for (int64_t i = 0; i <= La; ++i) {
@@ -1409,8 +1503,8 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
       row_start[i] = (int64_t)p;
     }
   }
-  std::vector<double> out;
-  second_dp(pts, row_start, La, Lv, n_clusters, out);
+  second_dp(S, La, Lv, n_clusters);
+  std::vector<double>& out = S.out;
   c->st.refine_dp_ms = now_ms() - t0;
   const int64_t rows_out = (int64_t)(out.size() / 5);
   const int64_t capacity = *n_rows;
