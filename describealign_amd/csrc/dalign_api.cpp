@@ -64,7 +64,7 @@ struct ChainSlot {
   DevBuf keys, q;                 // matches sorted by (i, v): packed keys and qualities
   DevBuf rank, flags, rows, pred, tree, ids, out_iv, small, temp;
   // column-pipelined DP: row ordinals, partition keys / ids, column-major matches, per-row records, control words
-  DevBuf rowid, ckey, cval, c_row, c_lr, c_q, c_gid, col_start, msg, ctl;
+  DevBuf rowid, ckey, cval, c_row, c_lr, c_q, c_gid, col_start, rank_cum, msg, ctl;
   DevBuf seg;                     // back-track: entry id and output offset of every pred[] segment
   unsigned launches = 0;          // column DPs that have written `msg` since it was last zeroed (tag salt)
   int64_t rows_hint = 0;          // audio rows of the match that filled this slot (upper bound on the rows with matches), 0 = unknown
@@ -77,7 +77,7 @@ struct ChainSlot {
   long long* h_small = nullptr;   // pinned copy of `small`: [0] rows | err << 32, [1] best id, [2] path length
   void release() {
     for (DevBuf* b : {&keys, &q, &rank, &flags, &rows, &pred, &tree, &ids, &out_iv, &small, &temp,
-                      &rowid, &ckey, &cval, &c_row, &c_lr, &c_q, &c_gid, &col_start, &msg, &ctl, &seg}) b->release();
+                      &rowid, &ckey, &cval, &c_row, &c_lr, &c_q, &c_gid, &col_start, &rank_cum, &msg, &ctl, &seg}) b->release();
     if (stream) (void)hipStreamDestroy(stream);
     for (hipEvent_t e : {e0, e1, ready}) if (e) (void)hipEventDestroy(e);
     if (h_small) (void)hipHostFree(h_small);
@@ -877,7 +877,7 @@ extern "C" int da_trim(da_ctx* c) {
   for (ChainSlot* sl : c->slots)
     if (sl->state == 0)
       for (DevBuf* b : {&sl->keys, &sl->q, &sl->rank, &sl->flags, &sl->rows, &sl->pred, &sl->tree, &sl->ids, &sl->out_iv, &sl->temp,
-                        &sl->rowid, &sl->ckey, &sl->cval, &sl->c_row, &sl->c_lr, &sl->c_q, &sl->c_gid, &sl->col_start, &sl->msg, &sl->ctl, &sl->seg}) b->release();
+                        &sl->rowid, &sl->ckey, &sl->cval, &sl->c_row, &sl->c_lr, &sl->c_q, &sl->c_gid, &sl->col_start, &sl->rank_cum, &sl->msg, &sl->ctl, &sl->seg}) b->release();
   return DA_OK;
 }
 
@@ -1044,12 +1044,13 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     K.n_cols = plan.n_cols; K.width = plan.width;
     const int64_t br = da::chain_columns_batch_rows();
     K.msg_stride = (rows_bound + br - 1) / br * br;
-    const size_t ctb = da::chain_columns_temp_bytes(n);
+    const size_t ctb = da::chain_columns_temp_bytes(n, sl.n_ranks);
     HIP_TRY(c, sl.rowid.ensure(sizeof(int32_t) * nn));
     HIP_TRY(c, sl.ckey.ensure(sizeof(uint16_t) * 2 * nn)); HIP_TRY(c, sl.cval.ensure(sizeof(uint32_t) * 2 * nn));
     HIP_TRY(c, sl.c_row.ensure(sizeof(uint32_t) * nn)); HIP_TRY(c, sl.c_lr.ensure(sizeof(uint16_t) * nn));
     HIP_TRY(c, sl.c_q.ensure(sizeof(double) * nn)); HIP_TRY(c, sl.c_gid.ensure(sizeof(uint32_t) * nn));
-    HIP_TRY(c, sl.col_start.ensure(sizeof(int32_t) * ((size_t)K.n_cols + 1)));
+    HIP_TRY(c, sl.col_start.ensure(sizeof(int32_t) * 2 * ((size_t)K.n_cols + 1)));      // + the columns' first ranks
+    HIP_TRY(c, sl.rank_cum.ensure(sizeof(int32_t) * 2 * ((size_t)sl.n_ranks + 2)));
     {
       // granule tags must never match what an earlier launch left behind: fresh memory and every 4095th
       // launch are zeroed, in between the salt distinguishes the launches
@@ -1077,12 +1078,13 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
       }
       K.salt = ++sl.launches;
     }
-    HIP_TRY(c, sl.ctl.ensure(sizeof(uint32_t) * ((size_t)da::kChainCtlHead + (size_t)K.n_cols + 2) + 64 * (size_t)K.n_cols));   // + diagnostic stamps
+    HIP_TRY(c, sl.ctl.ensure(sizeof(uint32_t) * ((size_t)da::kChainCtlHead + (size_t)K.n_cols + 2) + 8 * (size_t)da::kChainStampWords * (size_t)K.n_cols));   // + diagnostic stamps
     HIP_TRY(c, sl.temp.ensure(std::max(tb, ctb) + 256));
     K.rowid1 = sl.rowid.as<int32_t>();
     K.key_in = sl.ckey.as<uint16_t>(); K.key_out = sl.ckey.as<uint16_t>() + nn;
     K.val_in = sl.cval.as<uint32_t>(); K.val_out = sl.cval.as<uint32_t>() + nn;
     K.c_row = sl.c_row.as<uint32_t>(); K.c_lr = sl.c_lr.as<uint16_t>(); K.c_q = sl.c_q.as<double>(); K.c_gid = sl.c_gid.as<uint32_t>();
+    K.col_rank0 = sl.col_start.as<int32_t>() + (K.n_cols + 1); K.rank_cum = sl.rank_cum.as<int32_t>();
     K.col_start = sl.col_start.as<int32_t>(); K.msg = sl.msg.as<unsigned long long>(); K.ctl = sl.ctl.as<uint32_t>();
     K.temp = sl.temp.p; K.temp_bytes = ctb;
     L.temp = sl.temp.p;
@@ -1121,11 +1123,25 @@ int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int
   give_back_handover(c, sl);
   if (std::getenv("DALIGN_DEBUG_STAMPS") && sl.mode == 0 && sl.n > 0) {   // diagnostic builds (-DDA_CHAIN_STAMPS) only
     const int nc = (int)c->st.chain_columns;
-    std::vector<unsigned long long> st((size_t)nc * 8);
+    constexpr int W = da::kChainStampWords;
+    std::vector<unsigned long long> st((size_t)nc * W);
     const uint32_t* base = sl.ctl.as<uint32_t>() + da::kChainCtlHead + ((nc + 1) & ~1);
     if (hipMemcpy(st.data(), base, st.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
       double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int k = 0; k < nc; ++k) for (int j = 0; j < 8; ++j) sum[j] += (double)st[(size_t)k * 8 + j];
+      for (int k = 0; k < nc; ++k) for (int j = 0; j < 8; ++j) sum[j] += (double)st[(size_t)k * W + j];
+      const char* path = std::getenv("DALIGN_DEBUG_STAMPS");
+      if (path[0] == '/' || path[0] == '.') {             // a file name: the timeline, one line per column (us since the first column's start)
+        if (FILE* f = std::fopen(path, "w")) {
+          const unsigned long long t0 = st[8 + 31];
+          for (int k = 0; k < nc; ++k) {
+            std::fprintf(f, "%d %.2f", k, (double)(st[(size_t)k * W + 8 + 31] - t0) * 1e-2);
+            for (int j = 0; j < 31; ++j) std::fprintf(f, " %.2f", st[(size_t)k * W + 8 + j] ? (double)(st[(size_t)k * W + 8 + j] - t0) * 1e-2 : -1.0);
+            for (int j = 0; j < 8; ++j) std::fprintf(f, " %.2f", (double)st[(size_t)k * W + j] * 1e-2);
+            std::fprintf(f, "\n");
+          }
+          std::fclose(f);
+        }
+      }
       const char* names[7] = {"publish-drain", "input-wait", "window-pre+query", "sweep", "finals+update", "window-scan", "batch-end"};
       std::fprintf(stderr, "chain column stamps (mean per column, ms; %d columns, %.0f windows per column, kernel+rest %.2f ms):", nc, sum[7] / nc, ms);
       for (int j = 0; j < 7; ++j) std::fprintf(stderr, " %s %.2f", names[j], sum[j] / nc * 1e-5);

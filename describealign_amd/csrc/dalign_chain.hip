@@ -454,12 +454,12 @@ __global__ __launch_bounds__(64 * kW4) void k_chain_forward_w4(ChainArgs a) {
 //      loads instead of one per path point -- recording every visited segment's entry id and output offset.
 //   3. k_bt_fill (one lane per segment, all in parallel): the few path points inside the segment, from its entry.
 // The path comes out as before: ids in descending order.
-constexpr int kSegIds = 8192;
-constexpr int kSegThreads = 256;
+constexpr int kSegIds = 16384;        // 128 KiB of LDS: the walk of step 2 is n / kSegIds dependent loads of ~0.3 us
+constexpr int kSegThreads = 512;
 constexpr uint32_t kSegTerm = 0x80000000u;
 
 __global__ __launch_bounds__(kSegThreads) void k_bt_exits(const int32_t* __restrict__ pred, int64_t n, unsigned long long* __restrict__ ec) {
-  __shared__ unsigned long long s_w[kSegIds];                 // (count << 32) | next: local index, or kSegTerm | (exit id + 1)
+  extern __shared__ unsigned long long s_w[];                 // [kSegIds] (count << 32) | next: local index, or kSegTerm | (exit id + 1)
   const int tid = threadIdx.x;
   const int64_t lo = (int64_t)blockIdx.x * kSegIds;
   const int m = (int)((n - lo) < kSegIds ? (n - lo) : kSegIds);
@@ -529,7 +529,8 @@ static int launch_backtrack(const int32_t* pred, int64_t n, int32_t* path_ids, i
                             unsigned long long* ec, int32_t* seg, hipStream_t s) {
   const int64_t n_seg = chain_backtrack_segments(n);
   if (hipMemsetAsync(seg, 0xFF, sizeof(int32_t) * (size_t)n_seg, s) != hipSuccess) return -1;
-  hipLaunchKernelGGL(k_bt_exits, dim3((unsigned)n_seg), dim3(kSegThreads), 0, s, pred, n, ec);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_exits), hipFuncAttributeMaxDynamicSharedMemorySize, kSegIds * 8);
+  hipLaunchKernelGGL(k_bt_exits, dim3((unsigned)n_seg), dim3(kSegThreads), kSegIds * 8, s, pred, n, ec);
   hipLaunchKernelGGL(k_bt_walk, dim3(1), dim3(64), 0, s, (const unsigned long long*)ec, n, seg, seg + n_seg, meta, ctl);
   hipLaunchKernelGGL(k_bt_fill, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, s, pred, (const int32_t*)seg, (const int32_t*)(seg + n_seg), n_seg, path_ids);
   return 0;
@@ -581,7 +582,8 @@ constexpr int kGranules = 3 * kRowsPerLane;          // per lane and batch
 struct ColArgs {
   const uint32_t* c_row; const uint16_t* c_lr; const double* c_q; const uint32_t* c_gid;
   const int32_t* col_start; const int32_t* d_nrows;   // *d_nrows = number of audio rows (device)
-  int n_cols, width;
+  const int32_t* col_rank0;                            // [n_cols + 1] first rank of every column
+  int n_cols, width;                                   // width: the widest column the launch is sized for
   unsigned long long* msg; int64_t msg_stride;        // [n_cols][msg_stride rows][3] granules
   uint32_t* ctl;
   int32_t* pred; int64_t* meta;
@@ -626,15 +628,19 @@ template <int LV>      // LV = longest Fenwick path: width < 2^LV
 __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
   extern __shared__ uint4 s_tree[];                  // [0] empty record, [1 .. width] nodes, [width + 1] overflow dummy; then the batch's incoming records and its per-row maxima
   const int lane = threadIdx.x;
-  const int w = a.width;
-  uint4* s_in = s_tree + (w + 2);                    // [256] records from the left, by row of the batch
+  uint4* s_in = s_tree + (a.width + 2);              // [256] records from the left, by row of the batch
   uint4* s_rowmax = s_in + kBatchRows;               // [256] the column's running maximum after each row
-  for (int h = lane; h < w + 2 + 2 * kBatchRows; h += 64) s_tree[h] = uint4{0u, 0u, 0u, 0u};
+  for (int h = lane; h < a.width + 2 + 2 * kBatchRows; h += 64) s_tree[h] = uint4{0u, 0u, 0u, 0u};
   uint32_t col = 0;
   if (lane == 0) col = __hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int C = (int)__builtin_amdgcn_readfirstlane(col);
   __syncthreads();
   if (C >= a.n_cols) return;
+  const int w = a.col_rank0[C + 1] - a.col_rank0[C];     // this column's ranks (<= a.width, the bound LDS is sized for)
+  if (w > a.width) {                                     // cannot happen (k_rank_cols); never index LDS past its end
+    if (lane == 0) __hip_atomic_store(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   const int32_t n_rows = *a.d_nrows;
   const int32_t n_batches = (n_rows + kBatchRows - 1) / kBatchRows;
   int64_t cursor = a.col_start[C];
@@ -647,6 +653,9 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
 #ifdef DA_CHAIN_STAMPS
   unsigned long long cst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long cst_t = wall_clock64();
+  // timeline: the 100 MHz wall clock at the column's start ([8 + 31]) and at the end of every `tl_step`-th batch ([8 + k])
+  const int32_t tl_step = n_batches > 31 ? (n_batches + 30) / 31 : 1;
+  if (lane == 0) a.stamps[(size_t)C * kChainStampWords + 8 + 31] = cst_t;
 #endif
 
   // the window at `cursor`, prefetched: one match per lane
@@ -658,12 +667,17 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
   };
   fetch(cursor);
 
-  // this lane's granules of a batch: rows 4 * lane .. 4 * lane + 3, three granules each, contiguous
+  // A batch's 768 granules travel coalesced: lane l moves granules 64 g + l (twelve 512-byte accesses per batch; a lane moving
+  // its own four rows' twelve granules touched 48 cache lines per instruction and the hand-over took 2.5-4 us of every batch).
+  // Granule G is word G % 3 of row G / 3's 16-byte record in LDS, where the lane that owns the row picks it up / puts it down.
   unsigned long long gr[kGranules];
-  auto request = [&](int32_t b) {
-    const unsigned long long* p = in8 + ((int64_t)kBatchRows * b + kRowsPerLane * lane) * 3;
+  uint32_t goff[kGranules];
 #pragma unroll
-    for (int g = 0; g < kGranules; ++g) gr[g] = __hip_atomic_load(p + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int g = 0; g < kGranules; ++g) { const uint32_t G = 64u * (uint32_t)g + (uint32_t)lane; goff[g] = (G / 3u) * 4u + G % 3u; }
+  auto request = [&](int32_t b) {
+    const unsigned long long* p = in8 + (int64_t)kBatchRows * b * 3 + lane;
+#pragma unroll
+    for (int g = 0; g < kGranules; ++g) gr[g] = __hip_atomic_load(p + 64 * g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto complete = [&](uint32_t tag) -> bool {
     bool ok = true;
@@ -693,15 +707,17 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
         request(b);
       }
     }
+    if (C > 0) {
+      uint32_t* w_in = reinterpret_cast<uint32_t*>(s_in);      // the records' fourth words stay zero
+#pragma unroll
+      for (int g = 0; g < kGranules; ++g) w_in[goff[g]] = (uint32_t)gr[g];
+      __syncthreads();
+    }
     double Bf[kRowsPerLane]; uint32_t Bid[kRowsPerLane];
 #pragma unroll
     for (int r = 0; r < kRowsPerLane; ++r) {
-      Bf[r] = 0.0; Bid[r] = 0u;
-      if (C > 0) {
-        Bf[r] = __hiloint2double((int)(uint32_t)gr[3 * r + 1], (int)(uint32_t)gr[3 * r]);
-        Bid[r] = (uint32_t)gr[3 * r + 2];
-      }
-      s_in[kRowsPerLane * lane + r] = make_node(Bf[r], Bid[r]);
+      const uint4 rec = s_in[kRowsPerLane * lane + r];          // column 0: zeros, the empty record
+      Bf[r] = node_cum(rec); Bid[r] = rec.z;
       s_rowmax[kRowsPerLane * lane + r] = uint4{0u, 0u, 0u, 0u};
     }
     if (C > 0 && b + 1 < n_batches) request(b + 1);       // the next batch, behind this one's work
@@ -809,25 +825,29 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
       double ef; uint32_t ei;
       dpp_fetch<0x138, 0xf>(tf, ti, ef, ei);          // wave_shr:1 -> exclusive (lane 0 reads the identity)
       lexmax_into(ef, ei, Mstart_f, Mstart_id);
-      const uint32_t tagw = tag;
-      unsigned long long* p = out8 + ((int64_t)kBatchRows * b + kRowsPerLane * lane) * 3;
 #pragma unroll
       for (int r = 0; r < kRowsPerLane; ++r) {
         lexmax_into(rf[r], ri[r], ef, ei);
         lexmax_into(rf[r], ri[r], Bf[r], Bid[r]);
-        if (has_right) {
-          const unsigned long long hi = (unsigned long long)tagw << 32;
-          __hip_atomic_store(p + 3 * r, hi | (uint32_t)__double2loint(rf[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(p + 3 * r + 1, hi | (uint32_t)__double2hiint(rf[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(p + 3 * r + 2, hi | ri[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (has_right) s_rowmax[kRowsPerLane * lane + r] = make_node(rf[r], ri[r]);    // staged for the coalesced stores
+      }
+      if (has_right) {
+        __syncthreads();
+        const uint32_t* w_out = reinterpret_cast<const uint32_t*>(s_rowmax);
+        const unsigned long long hi = (unsigned long long)tag << 32;
+        unsigned long long* p = out8 + (int64_t)kBatchRows * b * 3 + lane;
+#pragma unroll
+        for (int g = 0; g < kGranules; ++g) __hip_atomic_store(p + 64 * g, hi | w_out[goff[g]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       last_id = ri[kRowsPerLane - 1];
     }
+#ifdef DA_CHAIN_STAMPS
+    if (lane == 0 && b % tl_step == 0 && b / tl_step < 31) a.stamps[(size_t)C * kChainStampWords + 8 + b / tl_step] = wall_clock64();
+#endif
   }
 #ifdef DA_CHAIN_STAMPS
   DA_CSTAMP(6)
-  if (lane == 0) for (int k = 0; k < 8; ++k) a.stamps[(size_t)C * 8 + k] = cst[k];
+  if (lane == 0) for (int k = 0; k < 8; ++k) a.stamps[(size_t)C * kChainStampWords + k] = cst[k];
 #endif
   // the last column's record of the last row is the heaviest match overall (rows past the end repeat it)
   if (C + 1 == a.n_cols && lane == 63) { a.meta[0] = (int64_t)last_id - 1; a.meta[1] = 0; }
@@ -836,20 +856,57 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
 // ---- preparation of the column-major arrays
 struct U8ToI32 { __device__ int32_t operator()(const uint8_t& x) const { return (int32_t)x; } };
 
-__global__ __launch_bounds__(256) void k_col_keys(const int32_t* __restrict__ rank, int64_t n, int width, int n_cols, uint16_t* __restrict__ key,
-                                                  uint32_t* __restrict__ val) {
+// ---- columns of equal WEIGHT instead of equal width.  The pipeline finishes when its slowest column does, and a column's
+// time goes with its matches: measured on the 2 h pair with equal widths the columns' busy time ran from 10 to 33 ms around a
+// mean of 21.5, and the pipeline (50 ms) was the heaviest early column plus the drain behind it.  A rank weighs its matches
+// plus the average number of matches per rank, so a column holds at most twice the average number of ranks (the LDS tree is
+// sized for that) and about 1 / n_cols of the weight.  hist -> exclusive sums -> column of every rank -> first rank of
+// every column; all on the device, nothing comes back to the host.
+// (every `stride`-th match only: the weights steer a partition, they are not part of the result, and 7.2e7 device-scope
+// atomics took 3.5 ms)
+__global__ __launch_bounds__(256) void k_rank_hist(const int32_t* __restrict__ rank, int64_t n, int64_t stride, int32_t* __restrict__ hist) {
+  const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * stride;
+  if (k < n) atomicAdd(&hist[rank[k]], 1);            // ranks are 1 .. n_ranks (k_chain_prep clamps what the rank map does not know)
+}
+
+// excl[r] = matches with rank < r  ->  col[r] in place; col[0] = -1, col[n_ranks + 1] = n_cols
+__global__ __launch_bounds__(256) void k_rank_cols(int32_t* __restrict__ excl, int64_t n_ranks, int64_t n, int n_cols) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n_ranks + 1) return;
+  int32_t c;
+  if (r == 0) c = -1;
+  else if (r == n_ranks + 1) c = n_cols;
+  else {
+    // weight in front of rank r, in units of 1 / n_ranks matches: its predecessors' matches + (r - 1) average shares
+    const double wfront = (double)excl[r] * (double)n_ranks + (double)(r - 1) * (double)n;
+    const double wtotal = 2.0 * (double)n * (double)n_ranks;
+    c = (int32_t)(wfront / wtotal * (double)n_cols);  // monotone in r: the columns are contiguous rank ranges
+    c = c < 0 ? 0 : (c >= n_cols ? n_cols - 1 : c);
+  }
+  excl[r] = c;
+}
+
+__global__ __launch_bounds__(256) void k_col_bounds(const int32_t* __restrict__ rcol, int64_t n_ranks, int32_t* __restrict__ col_rank0) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+  if (r > n_ranks + 1) return;
+  for (int c = rcol[r - 1] + 1; c <= rcol[r]; ++c) col_rank0[c] = (int32_t)r;   // first rank of every column (empty ones: width 0)
+}
+
+__global__ __launch_bounds__(256) void k_col_keys(const int32_t* __restrict__ rank, int64_t n, const int32_t* __restrict__ rcol, int n_cols,
+                                                  uint16_t* __restrict__ key, uint32_t* __restrict__ val) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  uint32_t col = (uint32_t)(rank[k] - 1) / (uint32_t)width;           // ranks are 1 .. n_ranks (k_chain_prep clamps what the rank map does not know)
+  uint32_t col = (uint32_t)rcol[rank[k]];
   if (col >= (uint32_t)n_cols) col = (uint32_t)n_cols - 1u;          // belt and braces: k_col_gather indexes col_start[] by this
   key[k] = (uint16_t)col;
   val[k] = (uint32_t)k;
 }
 
-__global__ __launch_bounds__(256) void k_col_gather(const uint16_t* __restrict__ key, const uint32_t* __restrict__ val, int64_t n, int width,
-                                                    int n_cols, const int32_t* __restrict__ rank, const double* __restrict__ q,
-                                                    const int32_t* __restrict__ rowid1, uint32_t* __restrict__ c_row, uint16_t* __restrict__ c_lr,
-                                                    double* __restrict__ c_q, uint32_t* __restrict__ c_gid, int32_t* __restrict__ col_start) {
+__global__ __launch_bounds__(256) void k_col_gather(const uint16_t* __restrict__ key, const uint32_t* __restrict__ val, int64_t n,
+                                                    const int32_t* __restrict__ col_rank0, int n_cols, const int32_t* __restrict__ rank,
+                                                    const double* __restrict__ q, const int32_t* __restrict__ rowid1, uint32_t* __restrict__ c_row,
+                                                    uint16_t* __restrict__ c_lr, double* __restrict__ c_q, uint32_t* __restrict__ c_gid,
+                                                    int32_t* __restrict__ col_start) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j > n) return;
   const int prev = j > 0 ? (int)key[j - 1] : -1;
@@ -858,7 +915,7 @@ __global__ __launch_bounds__(256) void k_col_gather(const uint16_t* __restrict__
   if (j == n) return;
   const uint32_t g = val[j];
   c_row[j] = (uint32_t)(rowid1[g] - 1);
-  c_lr[j] = (uint16_t)((uint32_t)(rank[g] - 1) % (uint32_t)width + 1u);
+  c_lr[j] = (uint16_t)(rank[g] - col_rank0[cur] + 1);
   c_q[j] = q[g];
   c_gid[j] = g;
 }
@@ -871,32 +928,32 @@ constexpr int kColMaxCols = 4096;
 }  // namespace
 
 ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint) {
-  // More columns = more wavefronts working, but every column walks all the batches, the pipeline takes
-  // n_cols batch times to fill, and the matches along the true alignment -- a few per audio row, all in
-  // the one column the diagonal is crossing -- are a serial chain that no column count shortens.
-  // Measured (MI355X): 2 h pair, 7.2e7 matches: 64 columns 156 ms, 128: 97, 256: 74, 512: 72, 1024: 93;
+  // More columns = more wavefronts working, but every column walks all the batches and the pipeline takes
+  // n_cols x (batch time + hand-over latency) to fill and to drain.
+  // Measured (MI355X, equal-width columns): 2 h pair, 7.2e7 matches: 64 columns 156 ms, 128: 97, 256: 74, 512: 72, 1024: 93;
   // 22 min pair, 3.1e6 matches: 32: 15.5, 64: 11.1, 128: 9.6, 256: 10.9, 512: 14.2.  About 25 k matches
   // per column, at most 384 columns (1 024 beyond 3e8 matches: 8 h pair, 1.12e9 matches, 384 columns 950 ms,
-  // 1 024: 850 ms); a column is at least 64 ranks wide and must fit LDS.
+  // 1 024: 850 ms).  `width` is the bound the launch is sized for: a column holds at most twice the average
+  // number of ranks (see k_rank_cols), at least 64, and must fit LDS.
   (void)rows_hint;
   if (n_ranks < 1) n_ranks = 1;
   int64_t nc = n / 24576;
   if (const char* e = std::getenv("DALIGN_CHAIN_COLS")) nc = std::atoll(e);
-  else nc = std::min<int64_t>(nc, n >= 300000000LL ? 1024 : 384);
+  else nc = std::min<int64_t>(nc, n >= 300000000LL ? 1024 : 512);
   nc = std::min<int64_t>(nc, (n_ranks + 63) / 64);
-  nc = std::max<int64_t>(nc, (n_ranks + kColMaxWidth - 1) / kColMaxWidth);
+  nc = std::max<int64_t>(nc, (2 * n_ranks + kColMaxWidth - 3) / (kColMaxWidth - 2));
   nc = std::max<int64_t>(1, std::min<int64_t>(nc, kColMaxCols));
-  int64_t width = (n_ranks + nc - 1) / nc;
-  nc = (n_ranks + width - 1) / width;
+  const int64_t avg = (n_ranks + nc - 1) / nc;
+  const int64_t width = nc == 1 ? n_ranks : std::min<int64_t>(n_ranks, 2 * avg + 2);   // + 1 for the rounding of k_rank_cols' quotient
   return ChainColumnPlan{(int)nc, (int)width};
 }
 
 size_t chain_columns_lds_bytes(int width) { return (size_t)(width + 2 + 2 * kBatchRows) * 16; }
 int chain_columns_batch_rows() { return kBatchRows; }
 
-size_t chain_columns_temp_bytes(int64_t n) {
+size_t chain_columns_temp_bytes(int64_t n, int64_t n_ranks) {
   size_t b1 = 0, b2 = 0;
-  const int m = (int)std::max<int64_t>(1, n);
+  const int m = (int)std::max<int64_t>(std::max<int64_t>(1, n), n_ranks + 2);
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b1, (const uint16_t*)nullptr, (uint16_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, m, 0, 16);
   hipcub::TransformInputIterator<int32_t, U8ToI32, const uint8_t*> it((const uint8_t*)nullptr, U8ToI32{});
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, b2, it, (int32_t*)nullptr, m);
@@ -906,7 +963,7 @@ size_t chain_columns_temp_bytes(int64_t n) {
 int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream_t s) {
   if (c.n <= 0) return 0;
   if (c.n > 0x7fffffffLL || cc.n_cols < 1 || cc.n_cols > kColMaxCols || cc.width < 1 || cc.width > kColMaxWidth ||
-      (int64_t)cc.n_cols * cc.width < c.n_ranks) return -1;
+      (int64_t)cc.n_cols * cc.width < c.n_ranks || c.n_ranks + 2 > 0x7fffffffLL) return -1;
   const int n = (int)c.n;
   const unsigned blocks = (unsigned)((c.n + 256) / 256);               // covers j = n as well
   // dense row ordinals: inclusive scan of the row-head flags
@@ -915,19 +972,35 @@ int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream
     hipcub::TransformInputIterator<int32_t, U8ToI32, const uint8_t*> it(c.flags, U8ToI32{});
     if (hipcub::DeviceScan::InclusiveSum(cc.temp, bytes, it, cc.rowid1, n, s) != hipSuccess) return -1;
   }
+  // the columns' rank ranges: equal weight (matches + an average share per rank)
+  {
+    const int64_t m = c.n_ranks + 2;
+    int32_t* hist = cc.rank_cum; int32_t* rcol = cc.rank_cum + m;
+    if (hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)m, s) != hipSuccess) return -1;
+    const int64_t stride = std::max<int64_t>(1, c.n >> 22);          // ~4e6 samples
+    const int64_t n_samples = (c.n + stride - 1) / stride;
+    hipLaunchKernelGGL(k_rank_hist, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, s, c.rank, c.n, stride, hist);
+    size_t bytes = cc.temp_bytes;
+    if (hipcub::DeviceScan::ExclusiveSum(cc.temp, bytes, hist, rcol, (int)m, s) != hipSuccess) return -1;
+    const unsigned rb = (unsigned)((m + 255) / 256);
+    hipLaunchKernelGGL(k_rank_cols, dim3(rb), dim3(256), 0, s, rcol, c.n_ranks, n_samples, cc.n_cols);
+    hipLaunchKernelGGL(k_col_bounds, dim3(rb), dim3(256), 0, s, rcol, c.n_ranks, cc.col_rank0);
+  }
+  const int32_t* rcol = cc.rank_cum + (c.n_ranks + 2);
   // stable partition of the match ids by column
-  hipLaunchKernelGGL(k_col_keys, dim3(blocks), dim3(256), 0, s, c.rank, c.n, cc.width, cc.n_cols, cc.key_in, cc.val_in);
+  hipLaunchKernelGGL(k_col_keys, dim3(blocks), dim3(256), 0, s, c.rank, c.n, rcol, cc.n_cols, cc.key_in, cc.val_in);
   {
     size_t bytes = cc.temp_bytes;
     if (hipcub::DeviceRadixSort::SortPairs(cc.temp, bytes, (const uint16_t*)cc.key_in, cc.key_out, (const uint32_t*)cc.val_in, cc.val_out, n, 0,
                                            col_bits(cc.n_cols), s) != hipSuccess) return -1;
   }
-  hipLaunchKernelGGL(k_col_gather, dim3(blocks), dim3(256), 0, s, cc.key_out, cc.val_out, c.n, cc.width, cc.n_cols, c.rank, c.q, cc.rowid1,
+  hipLaunchKernelGGL(k_col_gather, dim3(blocks), dim3(256), 0, s, cc.key_out, cc.val_out, c.n, cc.col_rank0, cc.n_cols, c.rank, c.q, cc.rowid1,
                      cc.c_row, cc.c_lr, cc.c_q, cc.c_gid, cc.col_start);
   if (hipMemsetAsync(cc.ctl, 0, sizeof(uint32_t) * (size_t)(kChainCtlHead + cc.n_cols), s) != hipSuccess) return -1;
   ColArgs a{};
   a.c_row = cc.c_row; a.c_lr = cc.c_lr; a.c_q = cc.c_q; a.c_gid = cc.c_gid; a.col_start = cc.col_start;
   a.d_nrows = cc.rowid1 + (c.n - 1);
+  a.col_rank0 = cc.col_rank0;
   a.n_cols = cc.n_cols; a.width = cc.width; a.msg = cc.msg; a.msg_stride = cc.msg_stride; a.ctl = cc.ctl; a.salt = cc.salt;
   a.pred = c.pred; a.meta = c.meta;
   {                                                                    // 20 s of the 100 MHz wall clock (DALIGN_CHAIN_SPIN_SECONDS: stress runs with thousands of forced columns beside a GEMM that never lets go of the CUs)

@@ -181,7 +181,9 @@ struct ChainLaunch {
 // `width` ranks, one single-wavefront workgroup per column with its Fenwick tree in LDS; the columns form a
 // pipeline over the audio rows, handing one (sum, id) record per row to the right through global memory.
 struct ChainColumns {
-  int n_cols, width;                       // ranks [c * width + 1, (c + 1) * width] belong to column c
+  int n_cols, width;                       // columns are contiguous rank ranges of about equal weight, none wider than `width`
+  int32_t* rank_cum;                       // [2 * (n_ranks + 2)] matches per rank; then their exclusive sums, overwritten by the column of every rank
+  int32_t* col_rank0;                      // [n_cols + 1] first rank of every column
   int32_t* rowid1;                         // [n] 1-based dense row ordinal of every match (inclusive scan of the row heads)
   uint16_t* key_in; uint16_t* key_out;     // [n] column of every match, before / after the stable partition
   uint32_t* val_in; uint32_t* val_out;     // [n] match ids, before / after
@@ -193,10 +195,11 @@ struct ChainColumns {
   void* temp; size_t temp_bytes;           // hipCUB scratch (chain_columns_temp_bytes)
 };
 constexpr int kChainCtlHead = 16;
+constexpr int kChainStampWords = 40;   // diagnostic builds: 8 tick counters + 32 timeline stamps (8 bytes each) per column, behind the control words
 struct ChainColumnPlan { int n_cols, width; };
 // rows_hint: (an estimate of) the number of distinct audio rows, 0 if unknown
 ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint);
-size_t chain_columns_temp_bytes(int64_t n);
+size_t chain_columns_temp_bytes(int64_t n, int64_t n_ranks);
 size_t chain_columns_lds_bytes(int width);
 int chain_columns_batch_rows();
 // partition + forward DP + back-track + gather, all on stream s (prep has run); -1 = out of range
