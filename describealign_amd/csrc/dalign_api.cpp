@@ -86,10 +86,10 @@ struct ChainSlot {
 };
 constexpr int kMaxChainSlots = 16;
 
-// The column DP's per-(column, row) hand-over records are its largest buffer by far (2 h pair at 1 024 columns: 16 GB, 8 h
-// pair: 60 GB).  They belong to the context, not to a slot: a slot takes one for the DP it launches and gives it back when the
+// The column DP's per-(column, row) hand-over records are its largest buffer by far (24 bytes x rows with a match x columns:
+// 2 h pair, 2.8e5 rows, 1 024 columns: 7 GB; 8 h pair: ~30 GB).  They belong to the context, not to a slot: a slot takes one for the DP it launches and gives it back when the
 // DP is collected, so the context holds as many as DPs were ever in flight together (two or three), not one per slot touched,
-// and a pair does not pay a 16 GB hipMalloc + memset (measured: 0.3 ms most of the time, 2-5 s every ~15th call, with the
+// and a pair does not pay a multi-GB hipMalloc + memset (measured: 0.3 ms most of the time, 2-5 s every ~15th call, with the
 // GPU-feeding thread stalled inside it).  `launches` travels with the buffer (the tag salt of its next DP).
 struct HandoverBuf { DevBuf buf; unsigned launches = 0; };
 constexpr size_t kHandoverKeep = 3;
@@ -720,8 +720,16 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
                          c->keys0.as<int32_t>() + n_match, c->stream);
       HIP_TRY(c, hipGetLastError());
     }
+    // the audio rows that have a match (a 2 h pair: 2.8e5 of 1.56e6 listed): the column DP sizes its per-(column, row)
+    // hand-over records by it -- counted here, behind the sort, and read back with the synchronisation that follows anyway
+    unsigned long long n_rows = 0;
+    unsigned long long* d_rows = c->counters.as<unsigned long long>() + 7;    // bytes 56..63 of `counters`
+    HIP_TRY(c, hipMemsetAsync(d_rows, 0, sizeof n_rows, c->stream));
+    if (n_match > 0) da::launch_count_rows(sl.keys.as<unsigned long long>(), (int64_t)n_match, d_rows, c->stream);
+    HIP_TRY(c, hipMemcpyAsync(&n_rows, d_rows, sizeof n_rows, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    sl.rows_hint = (int64_t)n_rows;
     float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.verify_ms = ms;
   }
   c->st.matches = (double)n_match;

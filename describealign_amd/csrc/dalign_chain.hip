@@ -554,8 +554,10 @@ __global__ __launch_bounds__(256) void k_chain_gather(const unsigned long long* 
 // so a column needs from the columns to its left ONE (sum, id) record per audio row -- B_i(C), the
 // lexicographic maximum over their matches in rows <= i -- and hands B_i(C + 1) = max(B_i(C), its own matches
 // in rows <= i) to the right.  One single-wavefront workgroup per column; its Fenwick tree covers only the
-// column's `width` ranks and lives entirely in LDS; the columns form a pipeline over the rows, 256 rows
-// ("batch") at a time.  Inside a column the matches are taken 64 at a time, one per lane ("window"):
+// column's ranks and lives entirely in LDS; the columns form a pipeline over the rows, 256 rows ("batch")
+// at a time.  The columns are contiguous rank ranges of about equal WEIGHT (k_rank_cols below), not equal
+// width: the pipeline ends when its slowest column does.  Inside a column the matches are taken 64 at a
+// time, one per lane ("window"):
 //   * prefix maxima from the tree as it stood before the window (all lanes at once, LDS only);
 //   * dominance among the window's own matches by a sequential sweep -- match j's final sum is broadcast
 //     (v_readlane) and taken by the later lanes with rank >= rank_j whose best is not larger; later ids win
@@ -569,8 +571,9 @@ __global__ __launch_bounds__(256) void k_chain_gather(const unsigned long long* 
 // row's record travels as three 8-byte granules {tag, value} -- sum low word, sum high word, id -- each
 // written by ONE write-through (sc1) store and read by L1-bypassing (sc1) loads, as relaxed agent-scope
 // atomics; the tag (launch salt | batch + 1) IS the ready flag, so there is no counter to poll, no release
-// fence and no store drain: the right neighbour re-reads a batch until every tag matches.  The next
-// batch's granules are requested while the current batch is processed.  Column numbers are taken from a
+// fence and no store drain: the right neighbour re-reads a batch until every tag matches.  A batch's 768
+// granules move as twelve coalesced 512-byte accesses and change hands with the lanes that own the rows in
+// LDS.  The next batch's granules are requested while the current batch is processed.  Column numbers are taken from a
 // ticket counter, so a workgroup only ever waits for workgroups that are already running, and every column
 // writes to a buffer of its own (no back-pressure): the pipeline cannot deadlock however many columns are
 // resident.  tests/chain_col_model.cpp is the CPU model of exactly this decomposition.
@@ -783,16 +786,21 @@ __global__ __launch_bounds__(64) void k_chain_columns(ColArgs a) {
         const unsigned long long Fb = (unsigned long long)__double_as_longlong(F);
         uint32_t x = lr;
         uint32_t path[LV];
+        // lanes whose path has left the column (and idle lanes: rank 0) sit the level out -- sent to a dummy node instead they
+        // all hit ONE LDS address and the atomic unit takes them one after the other
+        if (!inb) x = (uint32_t)w + 1u;
 #pragma unroll
         for (int l = 0; l < LV; ++l) {
-          path[l] = x <= (uint32_t)w ? x : (uint32_t)w + 1u;
-          atomicMax(reinterpret_cast<unsigned long long*>(&s_tree[path[l]]), Fb);
+          path[l] = x <= (uint32_t)w ? x : 0u;
+          if (path[l] != 0u) atomicMax(reinterpret_cast<unsigned long long*>(&s_tree[path[l]]), Fb);
           x += x & (0u - x);
         }
 #pragma unroll
         for (int l = 0; l < LV; ++l) {
-          const unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&s_tree[path[l]]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (cur == Fb) atomicMax(reinterpret_cast<unsigned int*>(&s_tree[path[l]]) + 2, id1);
+          if (path[l] != 0u) {
+            const unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&s_tree[path[l]]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (cur == Fb) atomicMax(reinterpret_cast<unsigned int*>(&s_tree[path[l]]) + 2, id1);
+          }
         }
       }
       DA_CSTAMP(4)
@@ -928,18 +936,18 @@ constexpr int kColMaxCols = 4096;
 }  // namespace
 
 ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint) {
-  // More columns = more wavefronts working, but every column walks all the batches and the pipeline takes
-  // n_cols x (batch time + hand-over latency) to fill and to drain.
-  // Measured (MI355X, equal-width columns): 2 h pair, 7.2e7 matches: 64 columns 156 ms, 128: 97, 256: 74, 512: 72, 1024: 93;
-  // 22 min pair, 3.1e6 matches: 32: 15.5, 64: 11.1, 128: 9.6, 256: 10.9, 512: 14.2.  About 25 k matches
-  // per column, at most 384 columns (1 024 beyond 3e8 matches: 8 h pair, 1.12e9 matches, 384 columns 950 ms,
-  // 1 024: 850 ms).  `width` is the bound the launch is sized for: a column holds at most twice the average
-  // number of ranks (see k_rank_cols), at least 64, and must fit LDS.
+  // More columns = more wavefronts working and a shorter serial sweep per column, but every column walks all the batches
+  // and the pipeline takes n_cols x (batch time + hand-over latency) to fill and to drain (a cell waits for its left
+  // neighbour and its predecessor in the column: the DP's time is the longest dependent path through the (column, batch)
+  // grid, profiles/tools/chain_cells.py).  Measured (MI355X, round 4 kernel): 2 h pair, 7.2e7 matches: 448 columns 42.4 ms,
+  // 512: 41.3, 640: 39.8, 768: 38.4, 1024: 37.7, 1280: 37.8, 1536: 38.9; 22 min pair, 3.1e6 matches: 96: 7.4, 127: 6.8,
+  // 192: 6.3, 256: 6.2, 320: 6.5.  About 12 k matches per column, at most 1 024.  `width` is the bound the launch is sized
+  // for: a column holds at most twice the average number of ranks (see k_rank_cols) and must fit LDS.
   (void)rows_hint;
   if (n_ranks < 1) n_ranks = 1;
-  int64_t nc = n / 24576;
+  int64_t nc = n / 12288;
   if (const char* e = std::getenv("DALIGN_CHAIN_COLS")) nc = std::atoll(e);
-  else nc = std::min<int64_t>(nc, n >= 300000000LL ? 1024 : 512);
+  else nc = std::min<int64_t>(nc, 1024);
   nc = std::min<int64_t>(nc, (n_ranks + 63) / 64);
   nc = std::max<int64_t>(nc, (2 * n_ranks + kColMaxWidth - 3) / (kColMaxWidth - 2));
   nc = std::max<int64_t>(1, std::min<int64_t>(nc, kColMaxCols));

@@ -6,7 +6,9 @@
 //
 // Recurrence (describealign.py:654-656, :674-697): over matches sorted by (audio frame i, video frame v)
 //     f[k] = q[k] + max{ f[k'] : k' < k, v[k'] <= v[k] },  ties on f resolved to the larger k'.
-// Decomposition: video ranks are cut into columns of `w` ranks.  For a point k of column C in row i
+// Decomposition: video ranks are cut into columns -- `w` > 0: columns of w ranks; `w` < 0: -w columns of about equal
+// weight, by the kernel's own formula (k_rank_cols: a rank weighs its points + the average number of points per rank,
+// the column of a rank is floor(weight in front of it / total weight * columns)).  For a point k of column C in row i
 //     {k' < k, v' <= v} = {points of columns < C in rows <= i}  u  {points k' < k of column C with rank' <= rank}
 // so column C needs from the columns to its left ONE (sum, id) record per audio row -- B_i(C), the
 // lexicographic maximum over their points in rows <= i -- and hands B_i(C+1) = max(B_i(C), its own points
@@ -42,16 +44,39 @@ extern "C" int chain_col_model(const int32_t* pi, const int32_t* pv, const doubl
   std::vector<int32_t> rowid((size_t)n);
   int32_t n_rows = 0;
   for (int64_t k = 0; k < n; ++k) { if (k == 0 || pi[k] != pi[k - 1]) ++n_rows; rowid[k] = n_rows - 1; }
-  const int NC = (n_ranks + w - 1) / w;
+  // column of every rank (1-based ranks) and first rank of every column
+  std::vector<int32_t> rcol((size_t)n_ranks + 2, 0);
+  int NC;
+  if (w > 0) {
+    NC = (n_ranks + w - 1) / w;
+    for (int32_t r = 1; r <= n_ranks; ++r) rcol[r] = (r - 1) / w;
+  } else {
+    NC = -w;
+    std::vector<int64_t> hist((size_t)n_ranks + 2, 0);
+    for (int64_t k = 0; k < n; ++k) ++hist[rk[pv[k]]];
+    int64_t front = 0;
+    for (int32_t r = 1; r <= n_ranks; ++r) {
+      const double wfront = (double)front * (double)n_ranks + (double)(r - 1) * (double)n;
+      const double wtotal = 2.0 * (double)n * (double)n_ranks;
+      rcol[r] = std::max(0, std::min(NC - 1, (int)(wfront / wtotal * (double)NC)));
+      front += hist[r];
+    }
+  }
+  std::vector<int32_t> rank0((size_t)NC + 1, n_ranks + 1);
+  for (int32_t r = n_ranks; r >= 1; --r) rank0[rcol[r]] = r;
+  for (int c = NC - 1; c >= 0; --c) if (rank0[c] > rank0[c + 1]) rank0[c] = rank0[c + 1];   // empty columns: width 0
+  int wmax = 1;
+  for (int c = 0; c < NC; ++c) wmax = std::max(wmax, rank0[c + 1] - rank0[c]);
   const int n_batches = (n_rows + kBatchRows - 1) / kBatchRows;
   // stable partition by column
   std::vector<std::vector<int32_t>> cols((size_t)NC);
-  for (int64_t k = 0; k < n; ++k) cols[(rk[pv[k]] - 1) / w].push_back((int32_t)k);
+  for (int64_t k = 0; k < n; ++k) cols[rcol[rk[pv[k]]]].push_back((int32_t)k);
   std::vector<Rec> Bin((size_t)n_batches * kBatchRows, Rec{0.0, 0u}), Bout((size_t)n_batches * kBatchRows);
-  int LV = 1; while ((1 << LV) <= w) ++LV;                     // longest Fenwick path
+  int LV = 1; while ((1 << LV) <= wmax) ++LV;                  // longest Fenwick path (the launch is sized for the widest column)
   for (int C = 0; C < NC; ++C) {
     const std::vector<int32_t>& P = cols[C];
-    std::vector<Rec> tree((size_t)w + 2, Rec{0.0, 0u});        // [0] empty record, [w + 1] overflow dummy
+    const int w = rank0[C + 1] - rank0[C];                     // this column's ranks (shadows the argument)
+    std::vector<Rec> tree((size_t)w + 2, Rec{0.0, 0u});        // [0] empty record
     Rec M{0.0, 0u};
     size_t cursor = 0;
     for (int b = 0; b < n_batches; ++b) {
@@ -64,7 +89,7 @@ extern "C" int chain_col_model(const int32_t* pi, const int32_t* pv, const doubl
         if (cnt == 0) break;
         int32_t row[64], lr[64], gid[64]; double q[64]; Rec B[64];
         for (int p = 0; p < cnt; ++p) {
-          gid[p] = P[cursor + p]; row[p] = rowid[gid[p]] - kBatchRows * b; lr[p] = (rk[pv[gid[p]]] - 1) % w + 1; q[p] = pq[gid[p]];
+          gid[p] = P[cursor + p]; row[p] = rowid[gid[p]] - kBatchRows * b; lr[p] = rk[pv[gid[p]]] - rank0[C] + 1; q[p] = pq[gid[p]];
           B[p] = Bin[(size_t)kBatchRows * b + row[p]];
         }
         // tree query (state before the window)
@@ -92,11 +117,11 @@ extern "C" int chain_col_model(const int32_t* pi, const int32_t* pv, const doubl
         // two-phase tree update: max on the sums, then the ids where the sum is ours
         for (int p = 0; p < cnt; ++p) {
           int x = lr[p];
-          for (int l = 0; l < LV; ++l) { const int idx = std::min(x, w + 1); if (me[p].f > tree[idx].f) tree[idx].f = me[p].f; x += x & -x; }
+          for (int l = 0; l < LV && x <= w; ++l) { if (me[p].f > tree[x].f) tree[x].f = me[p].f; x += x & -x; }   // past the column's end: done
         }
         for (int p = 0; p < cnt; ++p) {
           int x = lr[p];
-          for (int l = 0; l < LV; ++l) { const int idx = std::min(x, w + 1); if (tree[idx].f == me[p].f && me[p].id1 > tree[idx].id1) tree[idx].id1 = me[p].id1; x += x & -x; }
+          for (int l = 0; l < LV && x <= w; ++l) { if (tree[x].f == me[p].f && me[p].id1 > tree[x].id1) tree[x].id1 = me[p].id1; x += x & -x; }
         }
         // running maximum per row
         Rec run = M;

@@ -63,8 +63,8 @@ def test_column_decomposition_of_the_chain_dp_equals_the_recurrence(lib, tmp_pat
   audio row to the right, takes matches 64 at a time and updates its tree in two phases.
   tests/chain_col_model.cpp restates exactly that decomposition on the CPU; here it is compiled and
   checked against the host utility (plain Fenwick recurrence) on random instances with many equal sums,
-  for column widths from 1 rank to wider than the input, rows wider than a window and more than one
-  256-row batch.  (The kernel itself is checked against the same utility in the GPU tests.)"""
+  for column widths from 1 rank to wider than the input and for weight-balanced columns (the kernel's
+  formula), rows wider than a window and more than one 256-row batch.  (The kernel itself is checked against the same utility in the GPU tests.)"""
   import ctypes as C
   from describealign_amd import _native
   so = str(tmp_path / "chain_col_model.so")
@@ -82,9 +82,10 @@ def test_column_decomposition_of_the_chain_dp_equals_the_recurrence(lib, tmp_pat
     return i[ids], v[ids]
 
   rng = np.random.default_rng(21)
-  for trial in range(24):
+  for trial in range(36):
     n = int(rng.integers(1, 30000)); rows = int(rng.integers(1, 3000)); cols = int(rng.integers(1, 4000))
-    w = int(rng.choice([1, 2, 3, 7, 64, 100, 256, 1000, 4096]))
+    # positive: columns of w ranks; negative: -w weight-balanced columns (what the kernel launches)
+    w = int(rng.choice([1, 2, 3, 7, 64, 100, 256, 1000, 4096, -1, -2, -5, -17, -128, -1000]))
     key = np.unique(rng.integers(0, rows, n).astype(np.int64) << 32 | rng.integers(0, cols, n) * 4)
     i = (key >> 32).astype(np.int32); v = (key & 0xffffffff).astype(np.int32)
     q = rng.choice([50.0, 50.0, 12.5, 3.25, 0.75], len(i)) if trial % 3 else rng.uniform(0.001, 50, len(i))
