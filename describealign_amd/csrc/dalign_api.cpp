@@ -66,6 +66,7 @@ struct ChainSlot {
   // column-pipelined DP: row ordinals, partition keys / ids, column-major matches, per-row records, control words
   DevBuf rowid, ckey, cval, c_row, c_lr, c_q, c_gid, col_start, rank_cum, msg, ctl;
   DevBuf seg;                     // back-track: entry id and output offset of every pred[] segment
+  DevBuf dense; int64_t dense_len = 0;   // [2][dense_len + 1] ints: frames with a match (flags), then their exclusive sums (rank - 1 of a frame)
   unsigned launches = 0;          // column DPs that have written `msg` since it was last zeroed (tag salt)
   int64_t rows_hint = 0;          // audio rows of the match that filled this slot (upper bound on the rows with matches), 0 = unknown
   int mode = 0;                   // how the DP in flight was launched: 0 = columns, 1 / 4 = one workgroup of 1 / 4 wavefronts
@@ -77,7 +78,7 @@ struct ChainSlot {
   long long* h_small = nullptr;   // pinned copy of `small`: [0] rows | err << 32, [1] best id, [2] path length
   void release() {
     for (DevBuf* b : {&keys, &q, &rank, &flags, &rows, &pred, &tree, &ids, &out_iv, &small, &temp,
-                      &rowid, &ckey, &cval, &c_row, &c_lr, &c_q, &c_gid, &col_start, &rank_cum, &msg, &ctl, &seg}) b->release();
+                      &rowid, &ckey, &cval, &c_row, &c_lr, &c_q, &c_gid, &col_start, &rank_cum, &msg, &ctl, &seg, &dense}) b->release();
     if (stream) (void)hipStreamDestroy(stream);
     for (hipEvent_t e : {e0, e1, ready}) if (e) (void)hipEventDestroy(e);
     if (h_small) (void)hipHostFree(h_small);
@@ -181,6 +182,21 @@ void give_back_handover(da_ctx* c, ChainSlot& sl) {
     c->handover_free[small].buf.release();
     c->handover_free.erase(c->handover_free.begin() + (long)small);
   }
+}
+
+// the slot's sorted match list -> dense ranks of its video frames (enqueued on the main stream; *h_total is valid after
+// the caller's synchronisation)
+int enqueue_dense_ranks(da_ctx* c, ChainSlot& sl, int64_t n, int64_t lv, int32_t* h_total) {
+  const size_t m = (size_t)std::max<int64_t>(0, lv) + 1;
+  HIP_TRY(c, sl.dense.ensure(sizeof(int32_t) * 2 * m));
+  const size_t tb = da::dense_ranks_temp_bytes(lv);
+  HIP_TRY(c, c->sort_tmp.ensure(tb + 256));
+  if (da::launch_dense_ranks(sl.keys.as<unsigned long long>(), n, lv, sl.dense.as<int32_t>(), sl.dense.as<int32_t>() + m, c->sort_tmp.p, tb, c->stream) != 0)
+    return fail(c, DA_ERR_DEVICE, "da_match: ranking the matched video frames failed");
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(h_total, sl.dense.as<int32_t>() + m + (m - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  sl.dense_len = (int64_t)m - 1;
+  return DA_OK;
 }
 
 // a free chain slot (creating one if needed); -1 when all kMaxChainSlots are in flight
@@ -727,9 +743,12 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
     HIP_TRY(c, hipMemsetAsync(d_rows, 0, sizeof n_rows, c->stream));
     if (n_match > 0) da::launch_count_rows(sl.keys.as<unsigned long long>(), (int64_t)n_match, d_rows, c->stream);
     HIP_TRY(c, hipMemcpyAsync(&n_rows, d_rows, sizeof n_rows, hipMemcpyDeviceToHost, c->stream));
+    int32_t n_used = 0;                                    // ... and the video frames that have one: the DP's ranks
+    if (int rc = enqueue_dense_ranks(c, sl, (int64_t)n_match, c->res_lv, &n_used)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     sl.rows_hint = (int64_t)n_rows;
+    sl.n_ranks = n_used;
     float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.verify_ms = ms;
   }
   c->st.matches = (double)n_match;
@@ -834,8 +853,10 @@ extern "C" int da_match_import_commit(da_ctx* c, int64_t n) {
   HIP_TRY(c, hipMemsetAsync(d_rows, 0, sizeof n_rows, c->stream));
   if (n > 0) da::launch_count_rows(sl.keys.as<unsigned long long>(), n, d_rows, c->stream);
   HIP_TRY(c, hipMemcpyAsync(&n_rows, d_rows, sizeof n_rows, hipMemcpyDeviceToHost, c->stream));
+  int32_t n_used = 0;
+  if (int rc = enqueue_dense_ranks(c, sl, n, c->res_lv, &n_used)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  sl.n = n; sl.n_ranks = c->pend_nv; sl.state = 1;
+  sl.n = n; sl.n_ranks = n_used; sl.state = 1;
   sl.rows_hint = (int64_t)n_rows;
   c->res_slot = c->import_slot; c->import_slot = -1;
   c->n_match_resident = (unsigned long long)n;
@@ -885,7 +906,7 @@ extern "C" int da_trim(da_ctx* c) {
   for (ChainSlot* sl : c->slots)
     if (sl->state == 0)
       for (DevBuf* b : {&sl->keys, &sl->q, &sl->rank, &sl->flags, &sl->rows, &sl->pred, &sl->tree, &sl->ids, &sl->out_iv, &sl->temp,
-                        &sl->rowid, &sl->ckey, &sl->cval, &sl->c_row, &sl->c_lr, &sl->c_q, &sl->c_gid, &sl->col_start, &sl->rank_cum, &sl->msg, &sl->ctl, &sl->seg}) b->release();
+                        &sl->rowid, &sl->ckey, &sl->cval, &sl->c_row, &sl->c_lr, &sl->c_q, &sl->c_gid, &sl->col_start, &sl->rank_cum, &sl->msg, &sl->ctl, &sl->seg, &sl->dense}) b->release();
   return DA_OK;
 }
 
@@ -1039,8 +1060,10 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     // da_match_begin overwrites that list); the slot's stream waits for it
     HIP_TRY(c, c->rankmap.ensure(sizeof(int32_t) * (size_t)std::max<int64_t>(1, c->res_lv)));
     HIP_TRY(c, hipMemsetAsync(c->rankmap.p, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(1, c->res_lv), c->stream));
-    da::launch_rankmap(c->vlist.as<int32_t>(), sl.n_ranks, c->rankmap.as<int32_t>(), c->stream);
+    da::launch_rankmap(c->vlist.as<int32_t>(), c->pend_nv, c->rankmap.as<int32_t>(), c->stream);
     L.rankmap = c->rankmap.as<int32_t>(); L.rankmap_len = c->res_lv;
+    // the row list only says which frames a match may name; the DP's ranks are the frames that do have one (da_match_finish)
+    if (sl.dense.p && sl.dense_len == c->res_lv) L.dense = sl.dense.as<int32_t>() + (sl.dense_len + 1);
   }
   HIP_TRY(c, hipMemsetAsync(sl.small.p, 0, 128, c->stream));
   dbg.at("rank map");

@@ -62,8 +62,8 @@ __device__ __forceinline__ double read_lane(double x, int l) {
 // per match: video rank (1-based), row-head flag, input validation
 __global__ __launch_bounds__(256) void k_chain_prep(const unsigned long long* __restrict__ keys, const double* __restrict__ q,
                                                     int64_t n, const int32_t* __restrict__ rankmap, int64_t rankmap_len,
-                                                    int32_t* __restrict__ rank, uint8_t* __restrict__ flags,
-                                                    int32_t* __restrict__ err) {
+                                                    const int32_t* __restrict__ dense, int32_t* __restrict__ rank,
+                                                    uint8_t* __restrict__ flags, int32_t* __restrict__ err) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const unsigned long long key = keys[k];
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void k_chain_prep(const unsigned long long* __
     int32_t r = 0;
     if ((int64_t)v < rankmap_len) r = rankmap[v];
     if (r <= 0) { atomicOr(err, 4); r = 1; }            // video frame is not one of the matched rows: reported by the host; rank 1 keeps every later kernel inside its arrays
+    else if (dense) r = dense[v] + 1;                   // rank among the frames that HAVE a match (launch_dense_ranks): the columns' trees cover only those
     rank[k] = r;
   }
   // the reference's qualities are in (0, 50] (:672).  Tested on the bit pattern: this file is compiled with
@@ -947,7 +948,7 @@ ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint
   if (n_ranks < 1) n_ranks = 1;
   int64_t nc = n / 12288;
   if (const char* e = std::getenv("DALIGN_CHAIN_COLS")) nc = std::atoll(e);
-  else nc = std::min<int64_t>(nc, 1024);
+  else nc = std::min<int64_t>(nc, n >= 300000000LL ? 2048 : 1024);   // 8 h pair, 1.12e9 matches, 2.5e6 ranks: 1 024 columns 907 ms (86 KB of LDS each: one per CU, four rounds), 2 048: 363 ms
   nc = std::min<int64_t>(nc, (n_ranks + 63) / 64);
   nc = std::max<int64_t>(nc, (2 * n_ranks + kColMaxWidth - 3) / (kColMaxWidth - 2));
   nc = std::max<int64_t>(1, std::min<int64_t>(nc, kColMaxCols));
@@ -1055,7 +1056,7 @@ int launch_chain_prep(const ChainLaunch& c, hipStream_t s, bool columns) {
   if (!columns && ((c.n_ranks >> S) + 2 + kScrap) * 16 > 150 * 1024) return -1;    // the one-workgroup kernels keep the upper tree levels in LDS
   if (c.n <= 0) return 0;
   const unsigned blocks = (unsigned)((c.n + 255) / 256);
-  hipLaunchKernelGGL(k_chain_prep, dim3(blocks), dim3(256), 0, s, c.keys, c.q, c.n, c.rankmap, c.rankmap_len, c.rank, c.flags, c.err);
+  hipLaunchKernelGGL(k_chain_prep, dim3(blocks), dim3(256), 0, s, c.keys, c.q, c.n, c.rankmap, c.rankmap_len, c.dense, c.rank, c.flags, c.err);
   return 0;
 }
 
@@ -1116,6 +1117,30 @@ void launch_count_rows(const unsigned long long* keys, int64_t n, unsigned long 
   if (n <= 0) return;
   const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(k_count_rows, dim3(blocks), dim3(256), 0, s, keys, n, d_count);
+}
+
+// ---- dense ranks: the video frames that occur in a sorted match list, numbered in order.  The row list of the match
+// stage names every non-quiet frame (2 h pair: 3.6e5), matches exist for fewer than half of them (1.6e5): trees, LDS and
+// the number of columns an 8 h pair needs (6e6 listed frames do not fit the chip's LDS at once) go with the smaller number.
+__global__ __launch_bounds__(256) void k_mark_used(const unsigned long long* __restrict__ keys, int64_t n, int64_t lv, int32_t* __restrict__ used) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t v = (uint32_t)keys[k];
+  if ((int64_t)v < lv) used[v] = 1;                       // every writer stores the same value
+}
+size_t dense_ranks_temp_bytes(int64_t lv) {
+  size_t b = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(lv + 1));
+  return b;
+}
+// used / excl: [lv + 1] each; excl[v] = frames < v that have a match, excl[lv] = their number
+int launch_dense_ranks(const unsigned long long* keys, int64_t n, int64_t lv, int32_t* used, int32_t* excl, void* temp, size_t temp_bytes, hipStream_t s) {
+  if (lv + 1 > 0x7fffffffLL) return -1;
+  if (hipMemsetAsync(used, 0, sizeof(int32_t) * (size_t)(lv + 1), s) != hipSuccess) return -1;
+  if (n > 0) hipLaunchKernelGGL(k_mark_used, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, n, lv, used);
+  size_t bytes = temp_bytes;
+  if (hipcub::DeviceScan::ExclusiveSum(temp, bytes, (const int32_t*)used, excl, (int)(lv + 1), s) != hipSuccess) return -1;
+  return 0;
 }
 
 void launch_rankmap(const int32_t* vlist, int64_t n_v, int32_t* rankmap, hipStream_t s) {

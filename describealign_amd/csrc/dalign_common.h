@@ -167,7 +167,8 @@ struct ChainArgs {                         // k_chain_forward
 };
 struct ChainLaunch {
   const unsigned long long* keys; const double* q; int64_t n;   // sorted (i << 32 | v), qualities
-  const int32_t* rankmap; int64_t rankmap_len;                  // video frame -> 1-based rank, or NULL when `rank` is filled in
+  const int32_t* rankmap; int64_t rankmap_len;                  // video frame -> 1-based position in the match stage's row list (0: not listed), or NULL when `rank` is filled in
+  const int32_t* dense;                                         // with rankmap: [rankmap_len] frames below v that have a match (the rank is that + 1); NULL: the row-list position is the rank
   int64_t n_ranks;
   int32_t* rank; uint8_t* flags; int32_t* row_start; int32_t* d_nrows; int32_t* err;
   void* temp; size_t temp_bytes;                                // hipCUB select scratch (chain_rows_temp_bytes)
@@ -213,6 +214,9 @@ size_t chain_rows_temp_bytes(int64_t n);
 int launch_chain_prep(const ChainLaunch& c, hipStream_t s, bool columns);
 int launch_chain_dp(const ChainLaunch& c, hipStream_t s);
 void launch_rankmap(const int32_t* vlist, int64_t n_v, int32_t* rankmap, hipStream_t s);
+// dense ranks of the video frames that occur in a sorted match list (see dalign_chain.hip); -1 = out of range
+size_t dense_ranks_temp_bytes(int64_t lv);
+int launch_dense_ranks(const unsigned long long* keys, int64_t n, int64_t lv, int32_t* used, int32_t* excl, void* temp, size_t temp_bytes, hipStream_t s);
 // distinct audio rows of a sorted key list, ADDED to *d_count (zero it first)
 void launch_count_rows(const unsigned long long* keys, int64_t n, unsigned long long* d_count, hipStream_t s);
 
