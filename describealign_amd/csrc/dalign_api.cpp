@@ -1071,10 +1071,23 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
   da::ChainColumns K{};
   if (sl.mode == 0 && n > 0) {
     const int64_t rows_bound = std::min<int64_t>(n, sl.rows_hint > 0 ? sl.rows_hint : n);
-    const da::ChainColumnPlan plan = da::chain_columns_plan(n, sl.n_ranks, rows_bound);
-    K.n_cols = plan.n_cols; K.width = plan.width;
     const int64_t br = da::chain_columns_batch_rows();
     K.msg_stride = (rows_bound + br - 1) / br * br;
+    // the hand-over records (24 bytes x rows x columns) may take half of what is free on the device (counting a buffer this
+    // context already holds): an 8 h pair at 2 048 columns wants 61 GB, which a device shared with other contexts may not have --
+    // fewer columns are slower, never wrong
+    int64_t max_cols = 0;
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        size_t held = sl.msg.cap;
+        for (const HandoverBuf& h : c->handover_free) held = std::max(held, h.buf.cap);
+        const double per_col = 24.0 * (double)K.msg_stride * 1.125 + 4096.0;
+        max_cols = std::max<int64_t>(1, (int64_t)(0.5 * (double)(free_b + held) / per_col));
+      }
+    }
+    const da::ChainColumnPlan plan = da::chain_columns_plan(n, sl.n_ranks, max_cols);
+    K.n_cols = plan.n_cols; K.width = plan.width;
     const size_t ctb = da::chain_columns_temp_bytes(n, sl.n_ranks);
     HIP_TRY(c, sl.rowid.ensure(sizeof(int32_t) * nn));
     HIP_TRY(c, sl.ckey.ensure(sizeof(uint16_t) * 2 * nn)); HIP_TRY(c, sl.cval.ensure(sizeof(uint32_t) * 2 * nn));

@@ -936,7 +936,7 @@ constexpr int kColMaxWidth = 8191;      // LV 13: 128 KiB of tree
 constexpr int kColMaxCols = 4096;
 }  // namespace
 
-ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint) {
+ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t max_cols) {
   // More columns = more wavefronts working and a shorter serial sweep per column, but every column walks all the batches
   // and the pipeline takes n_cols x (batch time + hand-over latency) to fill and to drain (a cell waits for its left
   // neighbour and its predecessor in the column: the DP's time is the longest dependent path through the (column, batch)
@@ -944,11 +944,11 @@ ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint
   // 512: 41.3, 640: 39.8, 768: 38.4, 1024: 37.7, 1280: 37.8, 1536: 38.9; 22 min pair, 3.1e6 matches: 96: 7.4, 127: 6.8,
   // 192: 6.3, 256: 6.2, 320: 6.5.  About 12 k matches per column, at most 1 024.  `width` is the bound the launch is sized
   // for: a column holds at most twice the average number of ranks (see k_rank_cols) and must fit LDS.
-  (void)rows_hint;
   if (n_ranks < 1) n_ranks = 1;
   int64_t nc = n / 12288;
   if (const char* e = std::getenv("DALIGN_CHAIN_COLS")) nc = std::atoll(e);
   else nc = std::min<int64_t>(nc, n >= 300000000LL ? 2048 : 1024);   // 8 h pair, 1.12e9 matches, 2.5e6 ranks: 1 024 columns 907 ms (86 KB of LDS each: one per CU, four rounds), 2 048: 363 ms
+  if (max_cols > 0) nc = std::min<int64_t>(nc, max_cols);             // the caller's memory budget for the hand-over records
   nc = std::min<int64_t>(nc, (n_ranks + 63) / 64);
   nc = std::max<int64_t>(nc, (2 * n_ranks + kColMaxWidth - 3) / (kColMaxWidth - 2));
   nc = std::max<int64_t>(1, std::min<int64_t>(nc, kColMaxCols));

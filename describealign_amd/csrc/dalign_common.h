@@ -198,8 +198,9 @@ struct ChainColumns {
 constexpr int kChainCtlHead = 16;
 constexpr int kChainStampWords = 40;   // diagnostic builds: 8 tick counters + 32 timeline stamps (8 bytes each) per column, behind the control words
 struct ChainColumnPlan { int n_cols, width; };
-// rows_hint: (an estimate of) the number of distinct audio rows, 0 if unknown
-ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t rows_hint);
+// max_cols: upper limit from the caller's memory budget (24 bytes x rows x columns of hand-over records), 0 = none;
+// the LDS limit on a column's width still sets a minimum
+ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t max_cols);
 size_t chain_columns_temp_bytes(int64_t n, int64_t n_ranks);
 size_t chain_columns_lds_bytes(int width);
 int chain_columns_batch_rows();
