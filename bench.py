@@ -347,6 +347,11 @@ class Bench:
             alg = 12.0 * acc["matches"] / k
             res["roofline"]["algorithmic_bytes_per_launch"] = alg
             res["roofline"]["traffic_over_algorithmic"] = round(res["roofline"]["traffic"] / alg, 2) if alg > 0 else None
+            res["roofline"]["traffic_note"] = (
+                "requests of the L2s to the fabric (mostly served by the 256 MB MALL), per launch: the survivor records of the prefilter "
+                "(8 B each, 11 per verified match) and the two explicit operand streams where they miss an XCD's 4 MB L2 (the streamed "
+                "side once per XCD and stripe); traffic / launch time = ~0.3 TB/s of 8 TB/s -- the kernel is bound by the matrix cores and "
+                "board power, and the stripe length was chosen by a FETCH_SIZE sweep (profiles/r04_match_bf16_stripes.txt)")
             break
         except Exception:
           pass

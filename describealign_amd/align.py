@@ -567,7 +567,8 @@ def _pin_worker(slot_counter, lock, first_slot, order):
 def default_worker_count(local_world: int = 1) -> int:
   """LP worker processes per rank, from the host's cache topology.  One HiGHS solve of a long pair
   wants a whole L3 slice: on the GPU box's host (2 x 64 cores, 16 L3 domains) the 2 h pairs' LP runs
-  at 2.4 solves/s whether 16, 24 or 32 workers share the domains (time per solve grows in proportion),
+  at 2.5-2.7 solves/s whether 16, 24, 32 or 48 workers share the domains (time per solve grows in proportion:
+  6.3, 9.4, 13.9, 21.8 s -- profiles/r04_worker_sweep_cfg2.jsonl),
   and the 22 min pairs' LP peaks between 32 and 48 workers (30-31 solves/s; 128 workers: 26).  So: 1.5
   workers per L3 domain for a rank on its own (24 there), 3 per domain split between ranks that share
   a host (48 there), never more than one per physical core."""
