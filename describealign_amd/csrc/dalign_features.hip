@@ -180,37 +180,54 @@ __global__ __launch_bounds__(FeatCfg<C>::kThreads, DA_FEAT_MIN_WAVES) void k_fea
     uint32_t w[41];                     // one set of packed words for both channels (see M below)
     float e0 = 0.f, e1 = 0.f;
     int z0 = 0, z1 = 0;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const uint32_t* xp = s_xw + c * (Cfg::kTot / 2) + 35 * k + 1;
+    // energy and sign changes of one channel's words; own samples: half-words 6..75 of the read = dwords 3..37; group 0 = half-words 6..40
+    auto energy_flips = [&](int d, uint32_t cur, uint32_t before) {
+      const half2_t hv = *reinterpret_cast<const half2_t*>(&cur);
+      const uint32_t flips = (cur ^ __builtin_amdgcn_alignbit(cur, before, 16)) & 0x80008000u;
+      if (d < 20) {
+        e0 = __builtin_amdgcn_fdot2(hv, hv, e0, false);
+        z0 += __builtin_popcount(flips);
+      } else if (d > 20) {
+        e1 = __builtin_amdgcn_fdot2(hv, hv, e1, false);
+        z1 += __builtin_popcount(flips);
+      } else {
+        const float lo = (float)hv[0], hi = (float)hv[1];
+        e0 = fmaf(lo, lo, e0); e1 = fmaf(hi, hi, e1);
+        z0 += (int)((flips >> 15) & 1u); z1 += (int)(flips >> 31);
+      }
+    };
+    {
+      const uint32_t* xp = s_xw + 35 * k + 1;
 #pragma unroll
       for (int d = 0; d < 41; ++d) w[d] = xp[d];
-      // own samples: half-words 6..75 of the read = dwords 3..37; group 0 = half-words 6..40
 #pragma unroll
-      for (int d = 3; d <= 37; ++d) {
-        const half2_t hv = *reinterpret_cast<const half2_t*>(&w[d]);
-        const uint32_t flips = (w[d] ^ __builtin_amdgcn_alignbit(w[d], w[d - 1], 16)) & 0x80008000u;
-        if (d < 20) {
-          e0 = __builtin_amdgcn_fdot2(hv, hv, e0, false);
-          z0 += __builtin_popcount(flips);
-        } else if (d > 20) {
-          e1 = __builtin_amdgcn_fdot2(hv, hv, e1, false);
-          z1 += __builtin_popcount(flips);
-        } else {
-          const float lo = (float)hv[0], hi = (float)hv[1];
-          e0 = fmaf(lo, lo, e0); e1 = fmaf(hi, hi, e1);
-          z0 += (int)((flips >> 15) & 1u); z1 += (int)(flips >> 31);
-        }
-      }
-      // float32 window for the band path
+      for (int d = 3; d <= 37; ++d) energy_flips(d, w[d], w[d - 1]);
+    }
+    if constexpr (C == 2) {
+      // second channel: its energy / sign changes, then the band path's mono signal -- np.mean over the channels of the
+      // float16 samples accumulates in float32 and rounds to float16 (:576): RN((a + b) / 2).  a / 2 and b / 2 are exact in
+      // float16 (the samples are integers), so ONE packed fma per two samples, a * 0.5 + (b * 0.5), rounds the same exact
+      // value once -- instead of two conversions to float32, an add, a multiply and a conversion back per sample.
+      const uint32_t* xp = s_xw + (Cfg::kTot / 2) + 35 * k + 1;
+      const half2_t half = {(_Float16)0.5f, (_Float16)0.5f};
+      uint32_t before = 0u;
 #pragma unroll
-      for (int t = 0; t < 80; ++t) {
-        const int hw = t + 1;
-        const half2_t hv = *reinterpret_cast<const half2_t*>(&w[hw >> 1]);
-        const float x = (float)hv[hw & 1];
-        if (c == 0) m[t] = x;
-        else m[t] = (float)(_Float16)((m[t] + x) * 0.5f);     // np.mean on float16, float32 accumulate (:576)
+      for (int d = 0; d < 41; ++d) {
+        const uint32_t u = xp[d];
+        if (d >= 3 && d <= 37) energy_flips(d, u, before);
+        before = u;
+        const half2_t a = *reinterpret_cast<const half2_t*>(&w[d]);
+        const half2_t b = *reinterpret_cast<const half2_t*>(&u);
+        const half2_t mean = __builtin_elementwise_fma(a, half, b * half);
+        w[d] = *reinterpret_cast<const uint32_t*>(&mean);
       }
+    }
+    // float32 window for the band path
+#pragma unroll
+    for (int t = 0; t < 80; ++t) {
+      const int hw = t + 1;
+      const half2_t hv = *reinterpret_cast<const half2_t*>(&w[hw >> 1]);
+      m[t] = (float)hv[hw & 1];
     }
     // samples at or beyond n_band do not exist for the band rows (arr is truncated first, :577)
     const int64_t nwin0 = 35 * Q0 - 5;
