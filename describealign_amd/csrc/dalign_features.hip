@@ -99,10 +99,10 @@ __global__ __launch_bounds__(FeatCfg<C>::kThreads, DA_FEAT_MIN_WAVES) void k_fea
       uint32_t o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const _Float16 lo = (_Float16)(short)(w[c][e] & 0xffffu);
-        const _Float16 hi = (_Float16)(short)(w[c][e] >> 16);
-        half2_t p = {lo, hi};
-        o[e] = *reinterpret_cast<uint32_t*>(&p);
+        // both halves converted in place (sub-dword addressing): two instructions per pair of samples, no separate pack
+        asm("v_cvt_f16_i16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+            "v_cvt_f16_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1"
+            : "=&v"(o[e]) : "v"(w[c][e]));
       }
       *reinterpret_cast<uint4*>(smem + 2 * (c * Cfg::kTot + 8 * t)) = make_uint4(o[0], o[1], o[2], o[3]);
     }
