@@ -483,6 +483,24 @@ def test_pipeline_equals_sequential(ctx):
     assert np.array_equal(g[3], w[3])
 
 
+def test_pipeline_of_mixed_lengths_equals_sequential(ctx_bf16):
+  """A batch whose pairs differ 12-fold in length, shortest and longest alternating: every chain DP finds different
+  sizes in the slot it reuses (rank map, dense ranks of the matched frames, column plan) and takes a hand-over buffer from
+  the context's pool that an earlier, larger or smaller DP returned -- results must be those of align() pair by pair."""
+  from describealign_amd import align as A, synth
+  lengths = [75.0, 900.0, 120.0, 610.0, 95.0, 333.0, 840.0, 60.0]
+  pairs = [synth.make_pair(100 + k, sec, n_jumps=1 + k % 3, first_gap=20.0, channels=1 + k % 2) for k, sec in enumerate(lengths)]
+  feats = [(ctx_bf16.features(p.video, 0), ctx_bf16.features(p.audio, 1)) for p in pairs]
+  want = [A.align(vf, af, vf[0], af[0], ctx=ctx_bf16) for vf, af in feats]
+  with A.AlignPipeline(ctx_bf16, lp_workers=3) as pipe:
+    got = list(pipe.run(feats + feats[::-1]))
+  assert len(got) == 2 * len(feats)
+  for k, g in enumerate(got):
+    w = want[k] if k < len(feats) else want[2 * len(feats) - 1 - k]
+    assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]) and g[2] == w[2] and g[4] == w[4], k
+    assert np.array_equal(g[3], w[3]), k
+
+
 _TILED_WORKER = r"""
 import os, sys, json
 import numpy as np
