@@ -52,7 +52,7 @@ struct Side {
   DevBuf feat; int64_t feat_stride = 0; int64_t len[2] = {0, 0};
   // match-prep buffers
   DevBuf mfeat;                  // 5 rows uploaded by da_match
-  DevBuf ms[5], nrm[5], dig[5], flg[5];
+  DevBuf ms[5], nrm[5], hash;
   int64_t mlen[5] = {0, 0, 0, 0, 0}; int64_t lmax = 0;
   const float* prep_feat = nullptr;   // device rows the last preparation read (resident rows or the uploaded copy)
 };
@@ -297,7 +297,8 @@ void da_destroy(da_ctx* c) {
     if (s.up0) (void)hipEventDestroy(s.up0);
     if (s.up1) (void)hipEventDestroy(s.up1);
     s.pcm.release(); s.feat.release(); s.mfeat.release();
-    for (int j = 0; j < 5; ++j) { s.ms[j].release(); s.nrm[j].release(); s.dig[j].release(); s.flg[j].release(); }
+    for (int j = 0; j < 5; ++j) { s.ms[j].release(); s.nrm[j].release(); }
+    s.hash.release();
   }
   DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->bfv, &c->bfa, &c->counters, &c->keys0,
                    &c->q0, &c->sort_tmp, &c->rankmap, &c->rowscratch, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
@@ -551,9 +552,8 @@ int upload_and_prep(da_ctx* c, Side& s, const float* feat, int64_t stride, const
     p.len[j] = s.mlen[j];
     HIP_TRY(c, s.ms[j].ensure(sizeof(double) * n)); p.ms[j] = s.ms[j].as<double>();
     HIP_TRY(c, s.nrm[j].ensure(sizeof(double) * n)); p.nrm[j] = s.nrm[j].as<double>();
-    HIP_TRY(c, s.dig[j].ensure(sizeof(uint32_t) * n)); p.digits[j] = s.dig[j].as<uint32_t>();
-    HIP_TRY(c, s.flg[j].ensure(sizeof(uint32_t) * n)); p.flags[j] = s.flg[j].as<uint32_t>();
   }
+  HIP_TRY(c, s.hash.ensure(sizeof(uint32_t) * n * (size_t)(is_video ? da::kHashVideoWords : da::kHashAudioWords))); p.hash = s.hash.as<uint32_t>();
   launch_prep(p, c->hann41.as<double>(), c->stream);
   HIP_TRY(c, hipGetLastError());
   return DA_OK;
@@ -694,9 +694,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
       v.ms_v[j] = V.ms[j].as<double>(); v.ms_a[j] = A.ms[j].as<double>();
       v.nrm_v[j] = V.nrm[j].as<double>(); v.nrm_a[j] = A.nrm[j].as<double>();
     }
-    for (int j = 0; j < 5; ++j) {
-      v.dig_v[j] = V.dig[j].as<uint32_t>(); v.flg_v[j] = V.flg[j].as<uint32_t>(); v.dig_a[j] = A.dig[j].as<uint32_t>();
-    }
+    v.hash_v = V.hash.as<uint32_t>(); v.hash_a = A.hash.as<uint32_t>();
     v.mode = mode;
     v.alist = c->alist.as<int32_t>(); v.n_a = c->last_match.n_a;
     v.vlist = c->vlist.as<int32_t>(); v.n_v = n_v; v.n_pairs = d_cnt + 2;

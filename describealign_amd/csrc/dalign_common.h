@@ -54,9 +54,15 @@ struct PrepArgs {
   int is_video;
   double* ms[5];          // mean-subtracted rows, float64, zero padded by kPad
   double* nrm[5];         // window norms, float64 (len-40 valid entries)
-  uint32_t* digits[5];    // packed base-7 digits, one nibble per tap (audio: | 0x8888888)
-  uint32_t* flags[5];     // video only: ~(probe-next flags at bit 0 of each nibble)
+  uint32_t* hash;         // one hash record per frame (HashSlot below): packed base-7 digits, one nibble per tap (audio: | 0x8888888); video also ~(probe-next flags at bit 0 of each nibble)
 };
+// A frame's hash words of all five features sit together -- audio: 8 words (32 B), video: 16 words (64 B) -- in the order the
+// vote reads them: k_verify takes the vote of 8e8 survivors, and with one array per feature every survivor pulled 3-6
+// separate cache lines through L2 for 4 bytes each (PMC: 55 GB from the fabric per launch, 68 B per survivor).
+//   audio  [0..3] = features 3, 4, 0, 1   [4] = feature 2
+//   video  [0..3] = digits of 3, 4, 0, 1  [4..7] = their flags   [8] = digits of 2, [9] = its flags
+constexpr int kHashAudioWords = 8, kHashVideoWords = 16;
+__host__ __device__ inline int hash_slot(int j) { return j >= 3 ? j - 3 : (j < 2 ? j + 2 : 4); }   // word of feature j's digits (audio) / position among the first four (video); feature 2 -> 4 (audio), handled apart (video)
 void launch_prep(const PrepArgs& a, const double* d_hann41n, hipStream_t s);
 
 // ---- similarity GEMM -----------------------------------------------------------------------
@@ -97,7 +103,7 @@ struct VerifyArgs {
   const unsigned long long* surv; const unsigned long long* n_surv; unsigned long long capacity;
   const double* ms_v[3]; const double* ms_a[3];
   const double* nrm_v[3]; const double* nrm_a[3];
-  const uint32_t* dig_v[5]; const uint32_t* flg_v[5]; const uint32_t* dig_a[5];
+  const uint32_t* hash_v; const uint32_t* hash_a;     // hash records (see PrepArgs::hash)
   int mode;
   const int32_t* alist; int64_t n_a;      // survivor records carry the POSITION in the audio row list and reject bits (bf_emit)
 

@@ -62,8 +62,13 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
   if (i >= nv || nv <= 0) {
     if (i < a.lmax + kPad) {
       a.nrm[j][i] = 1.0;
-      a.digits[j][i] = 0xFFFFFFFFu;          // never matches
-      if (a.is_video) a.flags[j][i] = 0xFFFFFFFFu;
+      if (a.is_video) {
+        uint32_t* h = a.hash + i * kHashVideoWords;
+        h[j == 2 ? 8 : hash_slot(j)] = 0xFFFFFFFFu;            // never matches
+        h[j == 2 ? 9 : 4 + hash_slot(j)] = 0xFFFFFFFFu;
+      } else {
+        a.hash[i * kHashAudioWords + hash_slot(j)] = 0xFFFFFFFFu;
+      }
     }
     return;
   }
@@ -90,10 +95,11 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
     }
   }
   if (a.is_video) {
-    a.digits[j][i] = dig;
-    a.flags[j][i] = ~flg;
+    uint32_t* h = a.hash + i * kHashVideoWords;
+    h[j == 2 ? 8 : hash_slot(j)] = dig;
+    h[j == 2 ? 9 : 4 + hash_slot(j)] = ~flg;
   } else {
-    a.digits[j][i] = dig | 0x08888888u;      // guard bit per nibble: no borrows in the packed subtract
+    a.hash[i * kHashAudioWords + hash_slot(j)] = dig | 0x08888888u;      // guard bit per nibble: no borrows in the packed subtract
   }
 }
 
@@ -786,13 +792,19 @@ void launch_corr(const CorrArgs& a, hipStream_t s) {
 // the two-feature alternative first rejects almost every survivor after 3-6 gathers instead of 9-15
 __device__ inline bool vote_pair(const VerifyArgs& a, int32_t i, int32_t v) {
   if (a.mode != 0) return true;
-  const bool h3 = digit_hit(a.dig_a[3][i], a.dig_v[3][v], a.flg_v[3][v]);
-  const bool h34 = h3 ? true : digit_hit(a.dig_a[4][i], a.dig_v[4][v], a.flg_v[4][v]);
-  if (!h34) return false;
-  const int h0 = digit_hit(a.dig_a[0][i], a.dig_v[0][v], a.flg_v[0][v]) ? 1 : 0;
-  const int h1 = digit_hit(a.dig_a[1][i], a.dig_v[1][v], a.flg_v[1][v]) ? 1 : 0;
-  if (h0 + h1 == 0) return false;
-  if (h0 + h1 < 2 && !digit_hit(a.dig_a[2][i], a.dig_v[2][v], a.flg_v[2][v])) return false;
+  // three 16-byte loads from two cache lines decide almost every pair: features 3, 4, 0, 1 of the audio frame, the same
+  // features' digits and flags of the video frame
+  const uint4 A = *reinterpret_cast<const uint4*>(a.hash_a + (int64_t)i * kHashAudioWords);
+  const uint4 D = *reinterpret_cast<const uint4*>(a.hash_v + (int64_t)v * kHashVideoWords);
+  const uint4 G = *reinterpret_cast<const uint4*>(a.hash_v + (int64_t)v * kHashVideoWords + 4);
+  if (!digit_hit(A.x, D.x, G.x) && !digit_hit(A.y, D.y, G.y)) return false;       // neither feature 3 nor 4
+  const int h01 = (digit_hit(A.z, D.z, G.z) ? 1 : 0) + (digit_hit(A.w, D.w, G.w) ? 1 : 0);
+  if (h01 == 0) return false;
+  if (h01 < 2) {
+    const uint32_t a2 = a.hash_a[(int64_t)i * kHashAudioWords + 4];
+    const uint2 v2 = *reinterpret_cast<const uint2*>(a.hash_v + (int64_t)v * kHashVideoWords + 8);
+    if (!digit_hit(a2, v2.x, v2.y)) return false;
+  }
   return true;
 }
 // exact float64 re-evaluation of one pair (:662-672); returns true and the quality when it is a match
