@@ -812,11 +812,23 @@ __device__ inline bool correlate_pair(const VerifyArgs& a, int32_t i, int32_t v,
   double prob = 1.0;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
+    // The windows are read two doubles at a time (16-byte loads from 8-byte aligned addresses): every lane of a wavefront reads
+    // its own pair's windows, so the texture unit handles each lane's address separately, and this kernel's time was 126
+    // eight-byte loads x 64 lanes per 64 candidate pairs (PMC: vector ALUs 8 % busy, 67 % of the wave cycles waiting).  The sum
+    // is still taken tap by tap in k order.
+    typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
     const double* pa = a.ms_a[j] + i;
     const double* pv = a.ms_v[j] + v;
+    double xa[kWin + 1], xv[kWin + 1];
+#pragma unroll
+    for (int k = 0; k + 1 < kWin; k += 2) {
+      const double2u ta = *reinterpret_cast<const double2u*>(pa + k), tv = *reinterpret_cast<const double2u*>(pv + k);
+      xa[k] = ta.x; xa[k + 1] = ta.y; xv[k] = tv.x; xv[k + 1] = tv.y;
+    }
+    xa[kWin - 1] = pa[kWin - 1]; xv[kWin - 1] = pv[kWin - 1];
     double dot = 0.0;
 #pragma unroll
-    for (int k = 0; k < kWin; ++k) dot = fma(pa[k], pv[k], dot);
+    for (int k = 0; k < kWin; ++k) dot = fma(xa[k], xv[k], dot);
     const double corr = dot / (a.nrm_a[j][i] * a.nrm_v[j][v]);
     const double t = 1.0 - corr;
     prob *= (t > 1e-8 ? t : 1e-8);
@@ -848,18 +860,26 @@ __global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyArgs a, unsigne
   __shared__ unsigned long long s_base;
   if (threadIdx.x == 0) { s_n = 0; s_nc = 0; }
   __syncthreads();
-  const unsigned long long stride = (unsigned long long)gridDim.x * kVerifyThreads;
-  const unsigned long long rounds = (n_rec + stride - 1) / stride;
+  // Workgroup b runs on XCD b % 8.  Each XCD takes one contiguous eighth of the record list and its workgroups stride through
+  // THAT: the records come in flush chunks of one GEMM workgroup (one group of video rows, one stripe of audio columns), so
+  // what an XCD's resident workgroups gather at any moment -- the float64 windows of ~70 chunks -- stays inside its 4 MB L2;
+  // dealt round-robin over the whole list, every chunk's windows went through three different L2s.
+  const unsigned long long per_xcd = gridDim.x / 8;                                         // launch_verify: a multiple of 8
+  const unsigned long long seg = ((n_rec + 7) / 8 + kVerifyThreads - 1) / kVerifyThreads * kVerifyThreads;   // records per XCD
+  const unsigned long long seg_lo = (unsigned long long)(blockIdx.x % 8) * seg;
+  const unsigned long long seg_hi = seg_lo + seg < n_rec ? seg_lo + seg : n_rec;
+  const unsigned long long stride = per_xcd * kVerifyThreads;
+  const unsigned long long rounds = (seg + stride - 1) / stride;
   for (unsigned long long rnd = 0; rnd < rounds; ++rnd) {
-    const unsigned long long p = rnd * stride + (unsigned long long)blockIdx.x * kVerifyThreads + threadIdx.x;
-    const unsigned long long rec = (p < n_rec) ? a.surv[p] : 0ull;
+    const unsigned long long p = seg_lo + rnd * stride + (unsigned long long)(blockIdx.x / 8) * kVerifyThreads + threadIdx.x;
+    const unsigned long long rec = (p < seg_hi) ? a.surv[p] : 0ull;
     // record: position in the audio row list | video tile | lane half | REJECT bits in bf_emit's order
     int32_t i = (int32_t)(rec >> 41);
     const int64_t vtile = (int64_t)((rec >> 17) & 0xFFFFFFull);
     const int h = (int)((rec >> 16) & 1ull);
     uint32_t mask = (uint32_t)(rec & 0xFFFFull) ^ 0xFFFFu;
     if (i < a.n_a) i = a.alist[i]; else mask = 0u;
-    if (p >= n_rec) mask = 0u;
+    if (p >= seg_hi) mask = 0u;
     const bool last_round = (rnd + 1 == rounds);
     while (true) {
       // step 1: expand + vote, at most kVerifyPush pairs per thread and pass (records with more row bits take another
@@ -875,7 +895,11 @@ __global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyArgs a, unsigne
           const int64_t vr = vtile * 32 + row;
           if (vr < a.n_v) {
             const int32_t v = a.vlist[vr];
+#ifdef DA_DBG_VERIFY_NOVOTE           // ablation build: no hash loads, one pair in eight passes
+            if (((uint32_t)i * 2654435761u + (uint32_t)v * 40503u) >> 29 == 0u) s_cand[atomicAdd(&s_nc, 1u)] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v;
+#else
             if (vote_pair(a, i, v)) s_cand[atomicAdd(&s_nc, 1u)] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v;
+#endif
           }
         }
       }
@@ -889,7 +913,12 @@ __global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyArgs a, unsigne
         if (threadIdx.x < take) {
           const unsigned long long key = s_cand[base + threadIdx.x];
           double q;
+#ifdef DA_DBG_VERIFY_NOSTEP2          // ablation build: the exact re-evaluation is skipped (what is left is expansion + vote)
+          if (key == 0x123456789ull) {
+            q = 1.0;
+#else
           if (correlate_pair(a, (int32_t)(key >> 32), (int32_t)(key & 0xffffffffu), q)) {
+#endif
             const unsigned int pos = atomicAdd(&s_n, 1u);             // at most 512 + 256 <= kVerifyStage
             s_key[pos] = key; s_q[pos] = q;
           }
@@ -937,7 +966,7 @@ void launch_unpack_keys(const unsigned long long* keys, int64_t n, int32_t* out_
 
 void launch_verify(const VerifyArgs& a, unsigned long long n_surv_host, hipStream_t s) {
   if (n_surv_host == 0) return;
-  unsigned long long blocks = (n_surv_host + kVerifyThreads - 1) / kVerifyThreads;
+  unsigned long long blocks = ((n_surv_host + kVerifyThreads - 1) / kVerifyThreads + 7) / 8 * 8;     // a multiple of 8: one share per XCD
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(k_verify, dim3((unsigned)blocks), dim3(kVerifyThreads), 0, s, a, n_surv_host);
 }
