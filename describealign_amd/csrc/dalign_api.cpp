@@ -1084,16 +1084,16 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
         max_cols = std::max<int64_t>(1, (int64_t)(0.5 * (double)(free_b + held) / per_col));
       }
     }
-    const da::ChainColumnPlan plan = da::chain_columns_plan(n, sl.n_ranks, max_cols);
-    K.n_cols = plan.n_cols; K.width = plan.width;
     const size_t ctb = da::chain_columns_temp_bytes(n, sl.n_ranks);
     HIP_TRY(c, sl.rowid.ensure(sizeof(int32_t) * nn));
     HIP_TRY(c, sl.ckey.ensure(sizeof(uint16_t) * 2 * nn)); HIP_TRY(c, sl.cval.ensure(sizeof(uint32_t) * 2 * nn));
     HIP_TRY(c, sl.c_row.ensure(sizeof(uint32_t) * nn)); HIP_TRY(c, sl.c_lr.ensure(sizeof(uint16_t) * nn));
     HIP_TRY(c, sl.c_q.ensure(sizeof(double) * nn)); HIP_TRY(c, sl.c_gid.ensure(sizeof(uint32_t) * nn));
-    HIP_TRY(c, sl.col_start.ensure(sizeof(int32_t) * 2 * ((size_t)K.n_cols + 1)));      // + the columns' first ranks
     HIP_TRY(c, sl.rank_cum.ensure(sizeof(int32_t) * 2 * ((size_t)sl.n_ranks + 2)));
-    {
+    // the hand-over buffer last, and with fewer columns if the device does not have the memory after all
+    for (;;) {
+      const da::ChainColumnPlan plan = da::chain_columns_plan(n, sl.n_ranks, max_cols);
+      K.n_cols = plan.n_cols; K.width = plan.width;
       // granule tags must never match what an earlier launch left behind: fresh memory and every 4095th
       // launch are zeroed, in between the salt distinguishes the launches
       const size_t need = 24 * (size_t)K.msg_stride * (size_t)K.n_cols;
@@ -1113,13 +1113,25 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
         }
       }
       const size_t cap_before = sl.msg.cap;
-      HIP_TRY(c, sl.msg.ensure(need));
+      hipError_t e = hipSuccess;
+      if (const char* lim = std::getenv("DALIGN_CHAIN_HANDOVER_LIMIT")) {       // tests: pretend the device has no more than this many bytes for it
+        if (need > (size_t)std::strtoull(lim, nullptr, 10)) e = hipErrorOutOfMemory;
+      }
+      if (e == hipSuccess) e = sl.msg.ensure(need);
+      if (e == hipErrorOutOfMemory && K.n_cols > da::chain_columns_plan(n, sl.n_ranks, 1).n_cols) {
+        (void)hipGetLastError();                           // the estimate above was too generous: half the columns
+        max_cols = std::max<int64_t>(1, K.n_cols / 2);
+        continue;
+      }
+      HIP_TRY(c, e);
       if (sl.msg.cap != cap_before || sl.launches >= 4095) {
         HIP_TRY(c, hipMemsetAsync(sl.msg.p, 0, sl.msg.cap, c->stream));
         sl.launches = 0;
       }
       K.salt = ++sl.launches;
+      break;
     }
+    HIP_TRY(c, sl.col_start.ensure(sizeof(int32_t) * 2 * ((size_t)K.n_cols + 1)));      // + the columns' first ranks
     HIP_TRY(c, sl.ctl.ensure(sizeof(uint32_t) * ((size_t)da::kChainCtlHead + (size_t)K.n_cols + 2) + 8 * (size_t)da::kChainStampWords * (size_t)K.n_cols));   // + diagnostic stamps
     HIP_TRY(c, sl.temp.ensure(std::max(tb, ctb) + 256));
     K.rowid1 = sl.rowid.as<int32_t>();

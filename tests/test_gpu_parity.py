@@ -324,6 +324,27 @@ def test_chain_resident_equals_chain_of_fetched_matches(ctx, native):
     ctx.chain_finish(tickets[0])
 
 
+def test_chain_falls_back_to_fewer_columns_when_the_handover_buffer_does_not_fit(native, monkeypatch):
+  """The column DP sizes its hand-over records (24 B x rows x columns) by what is free on the device; when the allocation fails
+  all the same it halves the column count until it fits.  Same path, fewer columns."""
+  c = native.Context(0, native.PREC_F32)
+  try:
+    pair = cases.align_case("e180")
+    vf = c.features(pair.video, 0); af = c.features(pair.audio, 1)
+    mi, mv, mq = c.match(vf, af)
+    want = c.chain_resident()
+    cols = int(c.stats()["chain_columns"])
+    assert cols >= 4
+    rows = len(np.unique(mi))
+    monkeypatch.setenv("DALIGN_CHAIN_HANDOVER_LIMIT", str(24 * (rows + 256) * 2))      # room for two columns
+    c.match_begin(vf, af); c.match_finish()
+    got = c.chain_resident()
+    assert 1 <= int(c.stats()["chain_columns"]) <= 2 < cols
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+  finally:
+    c.close()
+
+
 def test_chain_begin_refuses_the_next_pairs_row_list(ctx):
   """da_chain_begin ranks the resident matches with the video row list of the match that produced them; the
   next da_match_begin overwrites that list.  Calling chain_begin for pair k after match_begin of pair k+1 used to
