@@ -1061,7 +1061,11 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     da::launch_rankmap(c->vlist.as<int32_t>(), c->pend_nv, c->rankmap.as<int32_t>(), c->stream);
     L.rankmap = c->rankmap.as<int32_t>(); L.rankmap_len = c->res_lv;
     // the row list only says which frames a match may name; the DP's ranks are the frames that do have one (da_match_finish)
-    if (sl.dense.p && sl.dense_len == c->res_lv) L.dense = sl.dense.as<int32_t>() + (sl.dense_len + 1);
+    if (n > 0) {
+      if (!sl.dense.p || sl.dense_len != c->res_lv)     // sl.n_ranks counts exactly these frames: without the table the ranks would not fit the trees
+        return fail(c, DA_ERR_STATE, "da_chain: the resident match list has no rank table (internal error)");
+      L.dense = sl.dense.as<int32_t>() + (sl.dense_len + 1);
+    }
   }
   HIP_TRY(c, hipMemsetAsync(sl.small.p, 0, 128, c->stream));
   dbg.at("rank map");
