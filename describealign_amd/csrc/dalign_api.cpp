@@ -1160,7 +1160,9 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
   HIP_TRY(c, hipEventRecord(sl.e0, st));
   dbg.at("events");
   if (sl.mode == 0) {
-    if (da::launch_chain_columns(L, K, st) != 0) return fail(c, DA_ERR_DEVICE, "da_chain: launch failed");
+    if (const int lrc = da::launch_chain_columns(L, K, st))
+      return fail(c, DA_ERR_DEVICE, "da_chain: launch failed (step %d: %lld matches, %lld ranks, %d columns of at most %d ranks; %s)", -lrc, (long long)n,
+                  (long long)sl.n_ranks, K.n_cols, K.width, hipGetErrorString(hipGetLastError()));
   } else if (da::launch_chain_dp(L, st) != 0) return fail(c, DA_ERR_DEVICE, "da_chain: launch failed");
   HIP_TRY(c, hipGetLastError());
   dbg.at("DP launches");

@@ -950,7 +950,10 @@ ChainColumnPlan chain_columns_plan(int64_t n, int64_t n_ranks, int64_t max_cols)
   else nc = std::min<int64_t>(nc, n >= 300000000LL ? 2048 : 1024);   // 8 h pair, 1.12e9 matches, 2.5e6 ranks: 1 024 columns 907 ms (86 KB of LDS each: one per CU, four rounds), 2 048: 363 ms
   if (max_cols > 0) nc = std::min<int64_t>(nc, max_cols);             // the caller's memory budget for the hand-over records
   nc = std::min<int64_t>(nc, (n_ranks + 63) / 64);
-  nc = std::max<int64_t>(nc, (2 * n_ranks + kColMaxWidth - 3) / (kColMaxWidth - 2));
+  {
+    const int64_t avg_max = (kColMaxWidth - 2) / 2;                   // widest column = 2 x average + 2 must fit the LDS tree
+    nc = std::max<int64_t>(nc, (n_ranks + avg_max - 1) / avg_max);
+  }
   nc = std::max<int64_t>(1, std::min<int64_t>(nc, kColMaxCols));
   const int64_t avg = (n_ranks + nc - 1) / nc;
   const int64_t width = nc == 1 ? n_ranks : std::min<int64_t>(n_ranks, 2 * avg + 2);   // + 1 for the rounding of k_rank_cols' quotient
@@ -972,25 +975,25 @@ size_t chain_columns_temp_bytes(int64_t n, int64_t n_ranks) {
 int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream_t s) {
   if (c.n <= 0) return 0;
   if (c.n > 0x7fffffffLL || cc.n_cols < 1 || cc.n_cols > kColMaxCols || cc.width < 1 || cc.width > kColMaxWidth ||
-      (int64_t)cc.n_cols * cc.width < c.n_ranks || c.n_ranks + 2 > 0x7fffffffLL) return -1;
+      (int64_t)cc.n_cols * cc.width < c.n_ranks || c.n_ranks + 2 > 0x7fffffffLL) return -2;
   const int n = (int)c.n;
   const unsigned blocks = (unsigned)((c.n + 256) / 256);               // covers j = n as well
   // dense row ordinals: inclusive scan of the row-head flags
   {
     size_t bytes = cc.temp_bytes;
     hipcub::TransformInputIterator<int32_t, U8ToI32, const uint8_t*> it(c.flags, U8ToI32{});
-    if (hipcub::DeviceScan::InclusiveSum(cc.temp, bytes, it, cc.rowid1, n, s) != hipSuccess) return -1;
+    if (hipcub::DeviceScan::InclusiveSum(cc.temp, bytes, it, cc.rowid1, n, s) != hipSuccess) return -3;
   }
   // the columns' rank ranges: equal weight (matches + an average share per rank)
   {
     const int64_t m = c.n_ranks + 2;
     int32_t* hist = cc.rank_cum; int32_t* rcol = cc.rank_cum + m;
-    if (hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)m, s) != hipSuccess) return -1;
+    if (hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)m, s) != hipSuccess) return -4;
     const int64_t stride = std::max<int64_t>(1, c.n >> 22);          // ~4e6 samples
     const int64_t n_samples = (c.n + stride - 1) / stride;
     hipLaunchKernelGGL(k_rank_hist, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, s, c.rank, c.n, stride, hist);
     size_t bytes = cc.temp_bytes;
-    if (hipcub::DeviceScan::ExclusiveSum(cc.temp, bytes, hist, rcol, (int)m, s) != hipSuccess) return -1;
+    if (hipcub::DeviceScan::ExclusiveSum(cc.temp, bytes, hist, rcol, (int)m, s) != hipSuccess) return -5;
     const unsigned rb = (unsigned)((m + 255) / 256);
     hipLaunchKernelGGL(k_rank_cols, dim3(rb), dim3(256), 0, s, rcol, c.n_ranks, n_samples, cc.n_cols);
     hipLaunchKernelGGL(k_col_bounds, dim3(rb), dim3(256), 0, s, rcol, c.n_ranks, cc.col_rank0);
@@ -1001,11 +1004,11 @@ int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream
   {
     size_t bytes = cc.temp_bytes;
     if (hipcub::DeviceRadixSort::SortPairs(cc.temp, bytes, (const uint16_t*)cc.key_in, cc.key_out, (const uint32_t*)cc.val_in, cc.val_out, n, 0,
-                                           col_bits(cc.n_cols), s) != hipSuccess) return -1;
+                                           col_bits(cc.n_cols), s) != hipSuccess) return -6;
   }
   hipLaunchKernelGGL(k_col_gather, dim3(blocks), dim3(256), 0, s, cc.key_out, cc.val_out, c.n, cc.col_rank0, cc.n_cols, c.rank, c.q, cc.rowid1,
                      cc.c_row, cc.c_lr, cc.c_q, cc.c_gid, cc.col_start);
-  if (hipMemsetAsync(cc.ctl, 0, sizeof(uint32_t) * (size_t)(kChainCtlHead + cc.n_cols), s) != hipSuccess) return -1;
+  if (hipMemsetAsync(cc.ctl, 0, sizeof(uint32_t) * (size_t)(kChainCtlHead + cc.n_cols), s) != hipSuccess) return -7;
   ColArgs a{};
   a.c_row = cc.c_row; a.c_lr = cc.c_lr; a.c_q = cc.c_q; a.c_gid = cc.c_gid; a.col_start = cc.col_start;
   a.d_nrows = cc.rowid1 + (c.n - 1);
@@ -1030,7 +1033,7 @@ int launch_chain_columns(const ChainLaunch& c, const ChainColumns& cc, hipStream
   else if (lv <= 11) go(k_chain_columns<11>);
   else if (lv <= 12) go(k_chain_columns<12>);
   else go(k_chain_columns<13>);
-  if (launch_backtrack(c.pred, c.n, c.path_ids, c.meta, (const uint32_t*)cc.ctl, c.bt_ec, c.bt_seg, s) != 0) return -1;
+  if (launch_backtrack(c.pred, c.n, c.path_ids, c.meta, (const uint32_t*)cc.ctl, c.bt_ec, c.bt_seg, s) != 0) return -8;
   hipLaunchKernelGGL(k_chain_gather, dim3(256), dim3(256), 0, s, c.keys, c.path_ids, c.meta, c.out_i, c.out_v);
   return 0;
 }

@@ -278,6 +278,23 @@ def test_chain_tiny_and_degenerate_instances(ctx, native):
     check(i, v, q)
 
 
+def test_chain_with_few_matches_per_video_frame_sizes_its_columns_for_the_lds_tree(ctx, native):
+  """Many video frames, few matches each: the column count comes from the LDS limit on a column's width (a column may hold
+  twice the average number of frames, + 2), not from the match count.  81 884 frames -- found by tests/gpu_stress_chain.py --
+  sat exactly where the first formula for that minimum was one column short and the launch was refused."""
+  rng = np.random.default_rng(7)
+  for frames in (81884, 8189 * 2, 8190 * 3 + 1, 4094 * 21, 4094 * 21 + 1):
+    n = 113005
+    v = np.concatenate([np.arange(frames), rng.integers(0, frames, n - frames)]).astype(np.int64)
+    i = rng.integers(0, 2337, n).astype(np.int64)
+    key = np.unique((i << 32) | v)
+    i = (key >> 32).astype(np.int32); v = (key & 0xffffffff).astype(np.int32)
+    q = rng.choice([50.0, 12.5, 3.25, 0.75], len(i))
+    wi, wv = native.chain_host(i, v, q)
+    gi, gv = ctx.chain(i, v, q)
+    assert np.array_equal(gi, wi) and np.array_equal(gv, wv), frames
+
+
 def test_chain_handover_under_concurrent_gemm_load(ctx, native):
   """The columns of the chain DP hand their per-row records to each other through global memory while
   OTHER kernels keep every CU busy (in the batch pipeline: the similarity GEMM of the next pair).  Uneven
