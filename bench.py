@@ -260,6 +260,7 @@ class Bench:
       peak = PEAK_TFLOPS[prec_name]
       res = {
         "metric": "aligned audio-hours/sec", "value": value, "unit": "audio-hours/s", "n_gpus": world,
+        "ranks_in_group": grp.group_size(),
         "steps": steps, "warmup": declared_warmup, "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if prec_name == "f32" else "bf16", "data": "synthetic",
@@ -392,6 +393,46 @@ class Bench:
     return res
 
 
+def launch_ranks(n):
+  """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py <same
+  arguments>` as a child process -- one rank per GPU over RCCL -- BEFORE this process has imported the extension or touched a
+  GPU (a process that has initialised the GPU must never be replaced by another program on this pool, so nothing is exec'ed),
+  relay rank 0's JSON line and return the child's exit code.  With the RCCL backend fewer than N visible devices is an error,
+  never a silent run on fewer GPUs."""
+  import socket
+  import subprocess
+  backend = os.environ.get("DALIGN_DIST_BACKEND", "nccl")
+  if backend == "nccl":
+    import torch
+    have = torch.cuda.device_count()          # counts devices without initialising the runtime
+    if have < n:
+      print(f"bench.py: --gpus {n} needs {n} visible GPUs for one RCCL rank each, this host shows {have} "
+            "(DALIGN_DIST_BACKEND=gloo DALIGN_BENCH_DEVICE=0 runs several ranks on one GPU: launch-path tests only)", file=sys.stderr)
+      return 2
+  port = os.environ.get("MASTER_PORT")
+  if not port:
+    with socket.socket() as sk:
+      sk.bind(("127.0.0.1", 0))
+      port = str(sk.getsockname()[1])
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+         "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+  child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+  lines = []
+  for line in child.stdout:                   # the ranks' stderr goes straight through; stdout is relayed line by line
+    if line.startswith("{"):
+      lines.append(line)
+    else:
+      sys.stderr.write(line)
+  code = child.wait()
+  for line in lines[-1:]:
+    sys.stdout.write(line)
+  sys.stdout.flush()
+  if code == 0 and not lines:
+    print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
+    return 1
+  return code
+
+
 SECONDARY_KEYS = ("value", "unit", "steps", "warmup", "lead_in_pairs_actual", "whole_stream_value", "ms_per_step", "dtype", "config",
                   "realtime_factor", "roofline", "feature_stage", "stage_ms_per_step", "host_s_per_step", "counts", "bound",
                   "gpu_stage_pairs_per_s", "lp_solves_per_s_host", "measured_pairs_per_s", "single_pair_latency_s",
@@ -420,6 +461,14 @@ def main():
   ap.add_argument("--pipeline", type=int, default=-1,
                   help="host worker processes (pass 1, LP); -1 = sized for this rank's share of the host; 0 = strictly sequential align()")
   args = ap.parse_args()
+
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # plain `python bench.py --gpus N`: this process becomes the launcher (it never touches a GPU) and the N ranks run
+    # under torch.distributed.run as its CHILD; their one JSON line is relayed
+    sys.exit(launch_ranks(args.gpus))
+  if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+    print(f"bench.py: --gpus {args.gpus} but the launcher started {os.environ['WORLD_SIZE']} rank(s); the line reports the ranks that ran",
+          file=sys.stderr)
 
   import torch          # noqa: F401  -- FIRST: its bundled HIP runtime must be the one libdalign.so binds to
   from describealign_amd import distrib

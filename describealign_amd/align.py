@@ -437,7 +437,11 @@ def align_tiled(video_features, audio_desc_features, video_energy, audio_desc_en
   t0 = time.perf_counter()
   # blocks of about equal numbers of non-quiet audio rows (:657-658), the rows that cost anything
   n_rows = max(0, n_ae - (2 * NODE_FRAMES - 1))
-  rb, re = row_blocks_by_load(np.asarray(audio_desc_energy[:n_rows]) > 0.5, group.world)[group.rank]
+  blocks = row_blocks_by_load(np.asarray(audio_desc_energy[:n_rows]) > 0.5, group.world)
+  # every rank derives the cuts from ITS copy of the energy row: rank 0's are used everywhere and a rank that had
+  # derived others (one energy value either side of 0.5) fails loudly instead of dropping or doubling rows
+  cuts = group.agree_on([b for b, _ in blocks] + [blocks[-1][1]])
+  rb, re = cuts[group.rank], cuts[group.rank + 1]
   import contextlib
   n_local, match_err = 0, None
   try:

@@ -32,6 +32,10 @@ class Group:
       self.dist = dist
       self.backend = backend
 
+  def group_size(self) -> int:
+    """The process group's own world size (1 without a group): what actually runs, whatever the environment said."""
+    return int(self.dist.get_world_size()) if self.dist is not None else 1
+
   def barrier(self):
     if self.dist is not None:
       self.dist.barrier()
@@ -120,40 +124,66 @@ class Group:
     rank into the slice that rank's block occupies -- rank order is (i, v) order -- while its own block is
     copied into the first slice on the device; the others export their list into tensors of exactly its
     length and send them.  Nothing is padded to the longest list, nothing is concatenated, nothing is copied a
-    second time: an 8 h pair's 1.1e9 matches are 18 GB once, not three times."""
+    second time: an 8 h pair's 1.1e9 matches are 18 GB once, not three times.
+
+    Every rank agrees on rank 0's reserve (an 18 GB allocation that can fail) and on its own export buffers
+    BEFORE any transfer is posted: a failure on one rank is raised on all of them instead of leaving the others
+    blocked in a send that nobody receives."""
     import torch
     dist, dev = self.dist, self.device
-    offs = [0]
-    for c in counts:
-      offs.append(offs[-1] + c)
+    offs = gather_offsets(counts)
     total = offs[-1]
-    if self.rank == 0:
-      pk, pq = ctx.match_import_reserve(total)
-      all_k = _device_view(pk, max(1, total), "<i8", torch.int64, dev)
-      all_q = _device_view(pq, max(1, total), "<f8", torch.float64, dev)
-      ops = []
-      for r in range(1, self.world):
-        if counts[r]:
-          ops.append(dist.P2POp(dist.irecv, all_k[offs[r]:offs[r + 1]], r))
-          ops.append(dist.P2POp(dist.irecv, all_q[offs[r]:offs[r + 1]], r))
+    root = self.rank == 0
+    err, all_k, all_q, keys, qual, pk, pq = None, None, None, None, None, 0, 0
+    try:
+      if root:
+        pk, pq = ctx.match_import_reserve(total)
+        all_k = _device_view(pk, max(1, total), "<i8", torch.int64, dev)
+        all_q = _device_view(pq, max(1, total), "<f8", torch.float64, dev)
+      elif n_local:
+        keys = torch.empty(n_local, dtype=torch.int64, device=dev)
+        qual = torch.empty(n_local, dtype=torch.float64, device=dev)
+    except Exception as e:                                  # noqa: BLE001 -- reported on every rank below
+      err = e
+    if not self.all_ok(err is None):
+      if err is not None:
+        raise err
+      raise RuntimeError("gather of the match lists: another rank could not provide its buffers")
+    if root:
+      ops = [dist.P2POp(dist.irecv, t[offs[r]:offs[r + 1]], r)
+             for r in range(1, self.world) if counts[r] for t in (all_k, all_q)]
       reqs = dist.batch_isend_irecv(ops) if ops else []
       if n_local:                                           # own block: device to device on the context's stream
         ctx.match_export_device(pk, pq, n_local)
       for q in reqs:
         q.wait()
-      torch.cuda.synchronize(dev)
+      _sync_device(dev)
       ctx.match_import_commit(total)
       return total
     if n_local:
-      keys = torch.empty(n_local, dtype=torch.int64, device=dev)
-      qual = torch.empty(n_local, dtype=torch.float64, device=dev)
       # the context copies on ITS stream (non-blocking, no implicit order with torch's): the allocation must be complete
-      torch.cuda.current_stream(dev).synchronize()
+      _sync_device(dev)
       ctx.match_export_device(keys.data_ptr(), qual.data_ptr(), n_local)
       for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, keys, 0), dist.P2POp(dist.isend, qual, 0)]):
         q.wait()
-      torch.cuda.synchronize(dev)
+      _sync_device(dev)
     return None
+
+  def agree_on(self, values):
+    """Rank 0's list of integers on every rank (one broadcast); raises on every rank when a rank had derived
+    different ones -- decisions that every rank computes from its own copy of the data (the row blocks of a tiled
+    pair) must not differ by one float comparison."""
+    if self.dist is None:
+      return [int(v) for v in values]
+    import torch
+    mine = torch.tensor([int(v) for v in values], dtype=torch.int64, device=self.device)
+    agreed = mine.clone()
+    self.dist.broadcast(agreed, src=0)
+    same = bool((mine == agreed).all().item())
+    if not self.all_ok(same):
+      raise RuntimeError("ranks derived different values for a decision they must share: "
+                         f"rank {self.rank} has {mine.tolist()}, rank 0 has {agreed.tolist()}")
+    return [int(v) for v in agreed.tolist()]
 
   def broadcast_result(self, result, error=None):
     """Rank 0's align() result -- (audio_times, video_times, similarity, path, median_slope) -- to every
@@ -200,6 +230,20 @@ class _DeviceArray:
 
   def __init__(self, ptr, n, typestr):
     self.__cuda_array_interface__ = dict(shape=(int(n),), typestr=typestr, data=(int(ptr), False), version=2)
+
+
+def gather_offsets(counts):
+  """Start of every rank's slice in the gathered list (rank order = (i, v) order), total last."""
+  offs = [0]
+  for c in counts:
+    offs.append(offs[-1] + int(c))
+  return offs
+
+
+def _sync_device(device):
+  import torch
+  if getattr(device, "type", "cpu") == "cuda":
+    torch.cuda.synchronize(device)
 
 
 def _device_view(ptr, n, typestr, dtype, device):

@@ -1079,3 +1079,26 @@ def test_bench_launch_contract_two_ranks(tmp_path):
   # the line says what bounds it and what the untimed lead-in really was
   assert d["bound"] in ("host_lp", "gpu") and d["lead_in_pairs_actual"] >= d["warmup"] and d["whole_stream_value"] > 0
   assert d["lp_solves_per_s_host"] == pytest.approx(2 * d["lp_solves_per_s_rank"], rel=1e-3) and d["gpu_stage_pairs_per_s"] > 0
+
+
+def test_plain_bench_command_starts_its_own_ranks():
+  """`python bench.py --gpus 2` WITHOUT a launcher (how a scaling run may be started): the process must start two ranks itself
+  (torch.distributed.run as a child, before it touches the GPU) and relay rank 0's line; n_gpus is the process group's own size.
+  Both ranks share the one GPU here (gloo; RCCL refuses two ranks on one device).  With RCCL, asking for more ranks than there
+  are GPUs fails loudly instead of measuring one GPU."""
+  import subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+  cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--pipeline", "2",
+         "--no-cpu-baseline", "--workload", "cfg-small"]
+  res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, DALIGN_DIST_BACKEND="gloo", DALIGN_BENCH_DEVICE="0"), cwd=root)
+  assert res.returncode == 0, res.stderr[-2000:]
+  lines = [l for l in res.stdout.splitlines() if l.strip()]
+  assert len(lines) == 1 and lines[0].startswith("{"), res.stdout[-2000:]
+  d = json.loads(lines[0])
+  assert d["n_gpus"] == 2 == d["ranks_in_group"] and d["steps"] == 4 and d["value"] > 0
+  import torch
+  if torch.cuda.device_count() < 8:
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "cfg-small"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert res.returncode != 0 and "needs 8 visible GPUs" in res.stderr and not res.stdout.strip()

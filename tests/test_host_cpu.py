@@ -395,10 +395,132 @@ try:
   raise SystemExit("no error raised")
 except RuntimeError as e:
   assert "mismatched" in str(e)
+# decisions every rank derives for itself (the row blocks of a tiled pair): rank 0's everywhere, a deviating rank fails all
+assert g.agree_on([0, 5, 9]) == [0, 5, 9]
+try:
+  g.agree_on([0, 5 + g.rank, 9])
+  raise SystemExit("no error raised")
+except RuntimeError as e:
+  assert "different values" in str(e)
+# the RCCL branch itself (exact-size point-to-point transfers into library-owned memory), moved over gloo between
+# two real ranks: the "device" arrays are host memory here, everything else is the code RCCL runs
+import ctypes, torch
+class P2PCtx:
+  def __init__(self):
+    self.k = self.q = None; self.committed = None
+  def match_import_reserve(self, total):
+    self.k = np.full(max(1, total), -1, dtype=np.int64); self.q = np.full(max(1, total), -1.0)
+    return self.k.ctypes.data, self.q.ctypes.data
+  def match_export_device(self, pk, pq, k):
+    ctypes.memmove(pk, ((mi[:k].astype(np.int64) << 32) | mv[:k]).ctypes.data, 8 * k)
+    ctypes.memmove(pq, np.ascontiguousarray(mq[:k]).ctypes.data, 8 * k)
+  def match_import_commit(self, total):
+    self.committed = total
+pctx = P2PCtx()
+def host_view(ptr, n, typestr, dtype, device):
+  a = pctx.k if ptr == pctx.k.ctypes.data else pctx.q
+  assert a.ctypes.data == ptr and len(a) == n
+  return torch.from_numpy(a)
+distrib._device_view = host_view
+for n_here, counts in ((n, [3, 7]), (0 if g.rank == 1 else n, [3, 0])):
+  total = g._gather_device(pctx, n_here, counts)
+  if g.rank == 0:
+    assert total == sum(counts) == pctx.committed
+    assert np.array_equal(pctx.k[:3] >> 32, np.arange(3)) and np.array_equal(pctx.q[:3], mq[:3])
+    if counts[1]:
+      assert np.array_equal(pctx.k[3:] >> 32, np.arange(7) + 100) and np.array_equal(pctx.k[3:] & 0xffffffff, np.arange(7) * 4)
+      assert np.array_equal(pctx.q[3:], np.linspace(0.5, 50.0, 7) + 1)
+  else:
+    assert total is None
+# rank 0 cannot reserve: raised on BOTH ranks before a single transfer is posted (nobody blocks in a send)
+class NoRoom(P2PCtx):
+  def match_import_reserve(self, total):
+    raise MemoryError("da_match_import_reserve: out of device memory")
+try:
+  g._gather_device(NoRoom(), n, [3, 7])
+  raise SystemExit("no error raised")
+except MemoryError:
+  assert g.rank == 0
+except RuntimeError as e:
+  assert g.rank == 1 and "another rank" in str(e)
 g.barrier()
 g.close()
 print("rank", g.rank, "ok", mine)
 """
+
+
+class _RecordingDist:
+  """Stand-in for torch.distributed that records the point-to-point operations Group._gather_device posts."""
+  irecv, isend = "irecv", "isend"
+
+  class ReduceOp:
+    MIN = "min"
+
+  class P2POp:
+    def __init__(self, op, tensor, peer):
+      self.op, self.tensor, self.peer = op, tensor, peer
+
+  class _Req:
+    def wait(self):
+      pass
+
+  def __init__(self):
+    self.posted = []
+
+  def all_reduce(self, t, op=None):
+    pass
+
+  def batch_isend_irecv(self, ops):
+    self.posted.extend(ops)
+    return [self._Req() for _ in ops]
+
+
+@pytest.mark.parametrize("counts", [[5, 9], [4, 0, 7, 1, 0, 3, 2, 6], [0, 0, 5], [0, 0]])
+def test_p2p_gather_posts_exact_slices_in_rank_order(counts, monkeypatch):
+  """The RCCL gather of a tiled pair (distrib.Group._gather_device): on rank 0 one receive per non-empty rank into exactly
+  that rank's slice of the reserved arrays, in rank order; every other rank sends exactly its list; an empty rank posts nothing."""
+  import torch
+  from describealign_amd import distrib
+  world, offs = len(counts), distrib.gather_offsets(counts)
+  assert offs[0] == 0 and offs[-1] == sum(counts) and all(offs[r + 1] - offs[r] == counts[r] for r in range(world))
+
+  class Ctx:
+    def __init__(self):
+      self.calls = []
+      self.k = np.zeros(max(1, offs[-1]), dtype=np.int64); self.q = np.zeros(max(1, offs[-1]))
+    def match_import_reserve(self, total):
+      self.calls.append(("reserve", total)); return self.k.ctypes.data, self.q.ctypes.data
+    def match_export_device(self, pk, pq, n):
+      self.calls.append(("export", pk, pq, n))
+    def match_import_commit(self, total):
+      self.calls.append(("commit", total))
+
+  for rank in range(world):
+    g = object.__new__(distrib.Group)
+    g.rank, g.local_rank, g.world, g.backend, g.device = rank, rank, world, "nccl", torch.device("cpu")
+    g.dist = _RecordingDist()
+    ctx = Ctx()
+    monkeypatch.setattr(distrib, "_device_view", lambda ptr, n, ts, dt, dev: torch.from_numpy(ctx.k if ptr == ctx.k.ctypes.data else ctx.q))
+    got = g._gather_device(ctx, counts[rank], counts)
+    ops = g.dist.posted
+    if rank == 0:
+      assert got == offs[-1] and ctx.calls[0] == ("reserve", offs[-1]) and ctx.calls[-1] == ("commit", offs[-1])
+      senders = [r for r in range(1, world) if counts[r]]
+      assert [o.peer for o in ops] == [r for r in senders for _ in (0, 1)] and all(o.op == "irecv" for o in ops)
+      for o in ops:
+        base = ctx.k if o.tensor.dtype == torch.int64 else ctx.q
+        assert o.tensor.numel() == counts[o.peer] and o.tensor.data_ptr() == base.ctypes.data + 8 * offs[o.peer]
+      assert [o.tensor.dtype for o in ops] == [torch.int64, torch.float64] * len(senders)
+      exports = [c for c in ctx.calls if c[0] == "export"]
+      assert exports == ([("export", ctx.k.ctypes.data, ctx.q.ctypes.data, counts[0])] if counts[0] else [])
+    else:
+      assert got is None and not any(c[0] in ("reserve", "commit") for c in ctx.calls)
+      if counts[rank]:
+        assert [(o.op, o.peer, o.tensor.numel(), o.tensor.dtype) for o in ops] == \
+               [("isend", 0, counts[rank], torch.int64), ("isend", 0, counts[rank], torch.float64)]
+        assert ctx.calls == [("export", ops[0].tensor.data_ptr(), ops[1].tensor.data_ptr(), counts[rank])]
+      else:
+        assert ops == [] and ctx.calls == []
 
 
 def test_two_rank_gloo_sharding(tmp_path):
@@ -582,3 +704,12 @@ def test_cpu_order_is_a_permutation_with_physical_cores_first():
   n_cores = len({min(siblings(c)) for c in cpus})
   first = order[:n_cores]
   assert len({min(siblings(c)) for c in first}) == n_cores, "the first n_cores entries must be distinct physical cores"
+
+
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+  """`python bench.py --gpus N` starts its N ranks itself; with the RCCL backend and fewer than N visible GPUs it must exit
+  non-zero with a message and print no result line (never a silent one-GPU measurement labelled N)."""
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DALIGN_DIST_BACKEND")}
+  res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--workload", "cfg-small"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+  assert res.returncode != 0 and "needs 64 visible GPUs" in res.stderr and not res.stdout.strip()
