@@ -336,20 +336,26 @@ class Context:
     return [out[0, :le]] + [out[k, :lo] for k in range(1, 5)]      # row views of one buffer
 
   def _recycled(self, shape, dtype):
-    """A result buffer of this shape that nobody holds any more, else a new one.  The rows handed out are VIEWS of their
-    buffer, so CPython's reference count says exactly when the caller (and whoever it passed them to) is done with it.
-    Why: a 2 h side's rows are 30 MB; allocated afresh per pair they arrive as new mmap'd pages, zeroed and faulted in
-    under the process-wide address-space lock that every other thread of a batch pipeline needs for its own buffers."""
+    """A page-locked result buffer of this shape that nobody holds any more, else a new one.  The pool keeps the flat base
+    arrays; what is handed out (and every row view cut from it) has that base as its numpy `base`, so CPython's reference
+    count of the base says exactly when the caller -- and whoever it passed rows to -- is done with it.
+    Why pooled: a 2 h side's rows are 30 MB; allocated afresh per pair they arrive as new mmap'd pages, zeroed and faulted in
+    under the process-wide address-space lock that every other thread of a batch pipeline needs for its own buffers.
+    Why page-locked: the download is then one DMA on the context's stream; a copy to pageable memory is staged by the
+    runtime through the null stream, which waits for every blocking stream of the device -- the CU-masked streams of the
+    chain DPs (hipExtStreamCreateWithCUMask takes no flags) -- i.e. for the previous pair's DP."""
     import sys
+    count = int(np.prod(shape))
     pool = self._pool
-    for k, buf in enumerate(pool):
-      if buf.shape == tuple(shape) and buf.dtype == dtype and sys.getrefcount(buf) == 3:     # the pool, `buf`, getrefcount's argument
-        return buf
-    buf = np.empty(shape, dtype=dtype)
-    pool.append(buf)
+    for base in pool:
+      if base.size == count and base.dtype == dtype and sys.getrefcount(base) == 3:    # the pool, `base`, getrefcount's argument
+        return base.reshape(shape)
+    base = pinned_empty((count,), dtype)
+    base = base.base if isinstance(base.base, np.ndarray) else base     # the flat array every view's `base` collapses to
+    pool.append(base)
     if len(pool) > 24:                           # shapes that no longer occur
-      pool[:] = [b for b in pool if sys.getrefcount(b) > 3][-16:] + [buf]
-    return buf
+      pool[:] = [b for b in pool if sys.getrefcount(b) > 3][-16:] + [base]
+    return base.reshape(shape)
 
   def features(self, pcm: np.ndarray, side: int = SIDE_VIDEO):
     """Upload + feature kernel: the five feature rows as a list of float32 arrays."""

@@ -104,8 +104,8 @@ def get_key_frame_data(video_file, time=None, entry="pts_time", ffprobe=None):
   if ffprobe is None:
     raise RuntimeError("no ffprobe binary on PATH")
   interval = f"%+{max(60, time + 40)}" if time is not None else "%"
-  argv = [ffprobe, "-show_format", "-show_streams", "-of", "json", "-select_streams", "V", "-show_frames",
-          "-skip_frame", "nokey", "-read_intervals", interval, "-show_entries", "frame=" + entry, video_file]
+  argv = ([ffprobe, "-show_format", "-show_streams", "-of", "json"] +
+          _options(select_streams='V', show_frames=None, skip_frame='nokey', read_intervals=interval, show_entries='frame=' + entry) + [video_file])
   res = subprocess.run(argv, capture_output=True)
   if res.returncode != 0:
     raise RuntimeError("ffprobe error: " + res.stderr.decode("utf-8", "replace"))
@@ -129,21 +129,33 @@ def get_closest_key_frame_time(video_file, time, ffprobe=None):
   return closest_key_frame_time(get_key_frame_data(video_file, time, ffprobe=ffprobe), time)
 
 
+def _options(**kwargs):
+  """Options as the reference's ffmpeg-python graph compiles them (ffmpeg-python 0.2.0, `convert_kwargs_to_cmd_line_args`): in
+  sorted key order, `-key value`, a None value a bare `-key`.  Keeping that order keeps the "FFmpeg command:" line of the
+  alignment report identical to the reference's (tests/golden/commands.json holds what the reference compiles)."""
+  args = []
+  for k in sorted(kwargs):
+    args.append(f"-{k}")
+    if kwargs[k] is not None:
+      args.append(f"{kwargs[k]}")
+  return args
+
+
 def _mux_command(ffmpeg, video_file, audio_desc_file, output_filename, setts_cmd, video_offset,
                  after_start_key_frame, median_slope):
-  """ffmpeg argv for the default (video re-timing) output, same options as :489-510."""
+  """ffmpeg argv for the default (video re-timing) output: what the graph of :489-510 compiles to."""
   start_offset = video_offset - after_start_key_frame
   audio_codec = 'copy' if os.path.splitext(audio_desc_file)[1] != '.wav' else 'aac'
   standards = 'normal' if os.path.splitext(audio_desc_file)[1] != '.flac' else 'experimental'
   sub_stretch = f":duration='DURATION*{1. / median_slope:.6f}'"
-  return [ffmpeg, "-itsoffset", f"{max(0, start_offset):.6f}", "-i", audio_desc_file,
-          "-an", "-ss", f"{after_start_key_frame:.6f}", "-itsoffset", f"{max(0, -start_offset):.6f}", "-dn",
-          "-i", video_file, "-map", "0", "-map", "1",
-          "-acodec", audio_codec, "-vcodec", "copy", "-scodec", "copy", "-max_interleave_delta", "0",
-          "-loglevel", "error", "-strict", standards, "-movflags", "frag_keyframe",
-          "-bsf:v", f"setts=pts='{setts_cmd}':dts='{setts_cmd}'", "-bsf:s", f"setts=ts='{setts_cmd}'" + sub_stretch,
-          "-disposition:a:0", "default+visual_impaired+descriptions", "-metadata:s:a:0", "title=AD",
-          output_filename, "-y"]
+  return ([ffmpeg] + _options(itsoffset=f"{max(0, start_offset):.6f}") + ["-i", audio_desc_file] +
+          _options(an=None, ss=f"{after_start_key_frame:.6f}", itsoffset=f"{max(0, -start_offset):.6f}", dn=None) + ["-i", video_file] +
+          ["-map", "0", "-map", "1"] +
+          _options(acodec=audio_codec, vcodec='copy', scodec='copy', max_interleave_delta='0', loglevel='error',
+                   strict=standards, movflags='frag_keyframe',
+                   **{'bsf:v': f"setts=pts='{setts_cmd}':dts='{setts_cmd}'", 'bsf:s': f"setts=ts='{setts_cmd}'" + sub_stretch,
+                      "disposition:a:0": "default+visual_impaired+descriptions", "metadata:s:a:0": "title=AD"}) +
+          [output_filename, "-y"])
 
 
 def parse_first_audio_track_is_ad(ffprobe_json) -> bool:
@@ -169,19 +181,20 @@ def is_first_video_track_ad(video_file, ffprobe=None) -> bool:
 
 
 def _replaced_media_command(ffmpeg, output_filename, video_file, first_track_is_ad=False):
-  """ffmpeg argv for the --stretch_audio output (same options as :468-487): the new stereo track is
+  """ffmpeg argv for the --stretch_audio output (what the graphs of :468-487 compile to): the new stereo track is
   piped in as s16le and either stored on its own (audio-only input) or muxed in front of the
   original streams.  The video's own first audio track becomes "original" unless it already is an
   audio description (the output of a previous run, :478-480)."""
-  head = [ffmpeg, "-f", "s16le", "-acodec", "pcm_s16le", "-ac", "2", "-ar", str(media.AUDIO_SAMPLE_RATE), "-i", "pipe:"]
+  head = [ffmpeg, "-f", "s16le"] + _options(acodec='pcm_s16le', ac=2, ar=media.AUDIO_SAMPLE_RATE) + ["-i", "pipe:"]
   if video_file is None:
-    return head + ["-loglevel", "error", output_filename, "-y"]
-  second = (["-disposition:a:1", "visual_impaired+descriptions"] if first_track_is_ad else
-            ["-disposition:a:1", "original", "-metadata:s:a:1", "title=original"])
-  return head + ["-dn", "-i", video_file, "-map", "0", "-map", "1",
-                 "-acodec", "copy", "-vcodec", "copy", "-scodec", "copy", "-max_interleave_delta", "0",
-                 "-loglevel", "error", "-c:a:0", "aac", "-disposition:a:0", "default+visual_impaired+descriptions",
-                 "-metadata:s:a:0", "title=AD"] + second + [output_filename, "-y"]
+    return head + _options(loglevel='error') + [output_filename, "-y"]
+  kwargs = {"c:a:0": "aac", "disposition:a:0": "default+visual_impaired+descriptions",
+            "metadata:s:a:0": "title=AD", "disposition:a:1": "visual_impaired+descriptions"}
+  if not first_track_is_ad:
+    kwargs.update({"disposition:a:1": "original", "metadata:s:a:1": "title=original"})
+  return (head + _options(dn=None) + ["-i", video_file, "-map", "0", "-map", "1"] +
+          _options(acodec='copy', vcodec='copy', scodec='copy', max_interleave_delta='0', loglevel='error', **kwargs) +
+          [output_filename, "-y"])
 
 
 def _write_replaced_media(ffmpeg, output_filename, frames, video_file):

@@ -94,6 +94,7 @@ constexpr int kMaxChainSlots = 16;
 // GPU-feeding thread stalled inside it).  `launches` travels with the buffer (the tag salt of its next DP).
 struct HandoverBuf { DevBuf buf; unsigned launches = 0; };
 constexpr size_t kHandoverKeep = 3;
+constexpr size_t kHandoverKeepBytes = (size_t)64 << 30;
 
 // ---- pass 2 on the host: points of the banded extension, state of the second DP
 struct BandPoint { double j; int32_t i; int32_t cl; double q; };
@@ -148,6 +149,12 @@ struct da_ctx {
   int pend_mode = 0; int64_t pend_nv = 0; size_t pend_cap = 0;
   hipEvent_t gemm_e0 = nullptr, gemm_e1 = nullptr, prep_e0 = nullptr, prep_e1 = nullptr;
   hipStream_t copy_stream = nullptr;
+  // Page-locked words for the counts the host reads back (row counts, survivors, matches, rows / frames with a match).
+  // Page-locked for two reasons: the copies are queued with hipMemcpyAsync and some error paths return before the stream is
+  // synchronised -- a copy into a stack local could land in a dead frame; and a copy to PAGEABLE memory is staged by the
+  // runtime through the null stream, which waits for every blocking stream of the device, i.e. for the CU-masked streams of
+  // the chain DPs in flight (hipExtStreamCreateWithCUMask takes no flags): the GEMM of pair k + 1 would start after the DP of pair k.
+  unsigned long long* h_pin = nullptr;   // [0..1] row counts (4 x int32), [2] survivors, [3] matches, [4] rows with a match, [5] frames with a match
   MatchArgs last_match{};
   da_stats_t st{};
   // audio replacement (--stretch_audio)
@@ -176,7 +183,10 @@ void give_back_handover(da_ctx* c, ChainSlot& sl) {
   if (!sl.msg.p) return;
   c->handover_free.push_back(HandoverBuf{sl.msg, sl.launches});
   sl.msg = DevBuf{}; sl.launches = 0;
-  if (c->handover_free.size() > kHandoverKeep) {
+  // at most kHandoverKeep idle buffers and at most kHandoverKeepBytes of them (always one): the buffers of 2 h pairs are 7 GB,
+  // those of an 8 h pair 54 GB -- three of them idle in every context would leave no room for a second context on the device
+  auto idle_bytes = [&] { size_t b = 0; for (const HandoverBuf& h : c->handover_free) b += h.buf.cap; return b; };
+  while (c->handover_free.size() > kHandoverKeep || (c->handover_free.size() > 1 && idle_bytes() > kHandoverKeepBytes)) {
     size_t small = 0;
     for (size_t k = 1; k < c->handover_free.size(); ++k) if (c->handover_free[k].buf.cap < c->handover_free[small].buf.cap) small = k;
     c->handover_free[small].buf.release();
@@ -199,13 +209,47 @@ int enqueue_dense_ranks(da_ctx* c, ChainSlot& sl, int64_t n, int64_t lv, int32_t
   return DA_OK;
 }
 
+// Streams with a compute-unit mask (hipExtStreamCreateWithCUMask).  Mask bit b is CU b / 8 of XCD b % 8 (the driver deals the
+// bits round-robin over the eight XCDs).  A chain DP is ~1 000 single-wavefront column workgroups: spread over the chip, each
+// one keeps a whole CU from taking a GEMM workgroup (four waves of 428 registers need all four SIMDs empty) while it occupies
+// one SIMD of it; confined to a few CUs per XCD the columns pack there and the GEMM keeps the rest.
+//   DALIGN_CHAIN_CUS = k      the chain DP's streams get the first k CUs of every XCD (0 / unset: no mask)
+//   DALIGN_CHAIN_CUS = xN     ... N whole XCDs (neighbouring columns then hand over through ONE L2)
+//   DALIGN_MAIN_CUS  = rest   the context's main stream (GEMM, verify, sort) gets the complement
+bool chain_cu_mask(uint32_t (&mask)[8]) {
+  const char* e = std::getenv("DALIGN_CHAIN_CUS");
+  for (uint32_t& w : mask) w = 0u;
+  if (!e || !*e) return false;
+  if (*e == 'x' || *e == 'X') {
+    const int n = std::max(1, std::min(7, std::atoi(e + 1)));
+    for (int b = 0; b < 256; ++b) if (b % 8 < n) mask[b / 32] |= 1u << (b % 32);
+    return true;
+  }
+  const int k = std::atoi(e);
+  if (k <= 0 || k >= 32) return false;
+  for (int b = 0; b < 8 * k; ++b) mask[b / 32] |= 1u << (b % 32);
+  return true;
+}
+hipError_t create_stream(hipStream_t* s, bool chain) {
+  uint32_t mask[8];
+  if (chain_cu_mask(mask)) {
+    const char* m = std::getenv("DALIGN_MAIN_CUS");
+    if (chain) return hipExtStreamCreateWithCUMask(s, 8, mask);
+    if (m && std::strcmp(m, "rest") == 0) {
+      for (uint32_t& w : mask) w = ~w;
+      return hipExtStreamCreateWithCUMask(s, 8, mask);
+    }
+  }
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 // a free chain slot (creating one if needed); -1 when all kMaxChainSlots are in flight
 int acquire_slot(da_ctx* c) {
   for (size_t k = 0; k < c->slots.size(); ++k)
     if (c->slots[k]->state == 0) return (int)k;
   if ((int)c->slots.size() >= kMaxChainSlots) return -1;
   ChainSlot* sl = new ChainSlot();
-  if (hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking) != hipSuccess ||
+  if (create_stream(&sl->stream, true) != hipSuccess ||
       hipEventCreate(&sl->e0) != hipSuccess || hipEventCreate(&sl->e1) != hipSuccess ||
       hipEventCreateWithFlags(&sl->ready, hipEventDisableTiming) != hipSuccess ||
       hipHostMalloc((void**)&sl->h_small, 64, hipHostMallocDefault) != hipSuccess) {
@@ -271,11 +315,12 @@ int da_create(int device_id, int precision, da_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete c; return DA_ERR_DEVICE; }
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return DA_ERR_DEVICE; }
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DA_ERR_DEVICE; }
+  if (create_stream(&c->stream, false) != hipSuccess) { delete c; return DA_ERR_DEVICE; }
   (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
   (void)hipEventCreate(&c->gemm_e0); (void)hipEventCreate(&c->gemm_e1);
   (void)hipEventCreate(&c->prep_e0); (void)hipEventCreate(&c->prep_e1);
   if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DA_ERR_DEVICE; }
+  if (hipHostMalloc((void**)&c->h_pin, 64, hipHostMallocDefault) != hipSuccess) { c->h_pin = nullptr; da_destroy(c); return DA_ERR_DEVICE; }
   FeatTables T; build_tables(T);
   if (c->tables.ensure(sizeof T) != hipSuccess ||
       hipMemcpy(c->tables.p, &T, sizeof T, hipMemcpyHostToDevice) != hipSuccess) { da_destroy(c); return DA_ERR_DEVICE; }
@@ -314,6 +359,7 @@ void da_destroy(da_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (hipEvent_t e : {c->gemm_e0, c->gemm_e1, c->prep_e0, c->prep_e1}) if (e) (void)hipEventDestroy(e);
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -621,8 +667,8 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
       if (da::select_rows(V.prep_feat, 0, nv, true, c->rowscratch.as<int32_t>(), c->vlist.as<int32_t>(), d_cnt32, c->sort_tmp.p, tb, c->stream) != 0 ||
           da::select_rows(A.prep_feat, b, e, false, nullptr, c->alist.as<int32_t>(), d_cnt32 + 2, c->sort_tmp.p, tb, c->stream) != 0)
         return fail(c, DA_ERR_DEVICE, "da_match: row list compaction failed");
-      int32_t h_cnt[4] = {0, 0, 0, 0};
-      HIP_TRY(c, hipMemcpyAsync(h_cnt, d_cnt32, sizeof h_cnt, hipMemcpyDeviceToHost, c->stream));
+      int32_t* h_cnt = reinterpret_cast<int32_t*>(c->h_pin);
+      HIP_TRY(c, hipMemcpyAsync(h_cnt, d_cnt32, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       n_v = h_cnt[0]; n_a = h_cnt[2];
     }
@@ -671,8 +717,9 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
   unsigned long long n_surv = 0;
   size_t cap = c->pend_cap;
   for (int attempt = 0; attempt < 3; ++attempt) {
-    HIP_TRY(c, hipMemcpyAsync(&n_surv, d_cnt, sizeof n_surv, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_pin + 2, d_cnt, sizeof n_surv, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    n_surv = c->h_pin[2];
     float ms = 0.f; (void)hipEventElapsedTime(&ms, c->gemm_e0, c->gemm_e1); c->st.gemm_ms = ms;
     if (n_surv <= cap) break;
     if (attempt == 2) return fail(c, DA_ERR_DEVICE, "da_match: survivor list kept overflowing");
@@ -707,8 +754,9 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
       HIP_TRY(c, hipMemsetAsync(d_cnt + 1, 0, 2 * sizeof(unsigned long long), c->stream));
       launch_verify(v, n_surv, c->stream);
       HIP_TRY(c, hipGetLastError());
-      HIP_TRY(c, hipMemcpyAsync(&n_match, d_cnt + 1, sizeof n_match, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(c->h_pin + 3, d_cnt + 1, sizeof n_match, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
+      n_match = c->h_pin[3];
       if (n_match <= mcap) break;
       if (attempt == 1) return fail(c, DA_ERR_DEVICE, "da_match: match list kept overflowing");
       mcap = (size_t)n_match + 1024;
@@ -740,13 +788,14 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
     unsigned long long* d_rows = c->counters.as<unsigned long long>() + 7;    // bytes 56..63 of `counters`
     HIP_TRY(c, hipMemsetAsync(d_rows, 0, sizeof n_rows, c->stream));
     if (n_match > 0) da::launch_count_rows(sl.keys.as<unsigned long long>(), (int64_t)n_match, d_rows, c->stream);
-    HIP_TRY(c, hipMemcpyAsync(&n_rows, d_rows, sizeof n_rows, hipMemcpyDeviceToHost, c->stream));
-    int32_t n_used = 0;                                    // ... and the video frames that have one: the DP's ranks
-    if (int rc = enqueue_dense_ranks(c, sl, (int64_t)n_match, c->res_lv, &n_used)) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_pin + 4, d_rows, sizeof n_rows, hipMemcpyDeviceToHost, c->stream));
+    int32_t* n_used = reinterpret_cast<int32_t*>(c->h_pin + 5);   // ... and the video frames that have one: the DP's ranks
+    if (int rc = enqueue_dense_ranks(c, sl, (int64_t)n_match, c->res_lv, n_used)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    n_rows = c->h_pin[4];
     sl.rows_hint = (int64_t)n_rows;
-    sl.n_ranks = n_used;
+    sl.n_ranks = *n_used;
     float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.verify_ms = ms;
   }
   c->st.matches = (double)n_match;
@@ -850,11 +899,12 @@ extern "C" int da_match_import_commit(da_ctx* c, int64_t n) {
   unsigned long long* d_rows = c->counters.as<unsigned long long>() + 7;      // bytes 56..63 of `counters`
   HIP_TRY(c, hipMemsetAsync(d_rows, 0, sizeof n_rows, c->stream));
   if (n > 0) da::launch_count_rows(sl.keys.as<unsigned long long>(), n, d_rows, c->stream);
-  HIP_TRY(c, hipMemcpyAsync(&n_rows, d_rows, sizeof n_rows, hipMemcpyDeviceToHost, c->stream));
-  int32_t n_used = 0;
-  if (int rc = enqueue_dense_ranks(c, sl, n, c->res_lv, &n_used)) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->h_pin + 4, d_rows, sizeof n_rows, hipMemcpyDeviceToHost, c->stream));
+  int32_t* n_used = reinterpret_cast<int32_t*>(c->h_pin + 5);
+  if (int rc = enqueue_dense_ranks(c, sl, n, c->res_lv, n_used)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  sl.n = n; sl.n_ranks = n_used; sl.state = 1;
+  n_rows = c->h_pin[4];
+  sl.n = n; sl.n_ranks = *n_used; sl.state = 1;
   sl.rows_hint = (int64_t)n_rows;
   c->res_slot = c->import_slot; c->import_slot = -1;
   c->n_match_resident = (unsigned long long)n;

@@ -90,8 +90,9 @@ def _read_wav_any_channels(media_file):
 def _ffmpeg_decode_command(exe, media_file, num_channels):
   """The reference's decode (describealign.py:149-153): first audio stream, s16le at 44.1 kHz,
   aresample=async=1:first_pts=0, downmix to num_channels."""
-  return [exe, "-i", media_file, "-f", "s16le", "-acodec", "pcm_s16le", "-af", "aresample=async=1:first_pts=0",
-          "-map", "0:a:0", "-ac", str(num_channels), "-ar", str(AUDIO_SAMPLE_RATE), "-loglevel", "error", "-"]
+  # options in the order the reference's ffmpeg-python graph compiles them (sorted by name; tests/golden/commands.json)
+  return [exe, "-i", media_file, "-f", "s16le", "-ac", str(num_channels), "-acodec", "pcm_s16le", "-af", "aresample=async=1:first_pts=0",
+          "-ar", str(AUDIO_SAMPLE_RATE), "-loglevel", "error", "-map", "0:a:0", "-"]
 
 
 def _wav_pcm_span(media_file, num_channels):

@@ -352,6 +352,60 @@ def gen_combine_stretch(name):
   return meta
 
 
+def gen_commands():
+  """The command lines the reference hands to ffmpeg / ffprobe (describealign.py:149-153 decode, :443-449 and :460-462 probes,
+  :464-515 default mux and --stretch_audio mux), recorded by running the reference's own functions against
+  tests/golden/ffmpeg_python_double.py (ffmpeg-python is not installable here; the double restates its compile rules).
+  -> tests/golden/commands.json: [{name, args, argv | probe_argv | logged}]"""
+  import ffmpeg_python_double as dbl
+  saved = {k: getattr(ref, k) for k in ("ffmpeg", "get_ffmpeg", "get_ffprobe")}
+  ref.ffmpeg = dbl; ref.get_ffmpeg = lambda: "ffmpeg"; ref.get_ffprobe = lambda: "ffprobe"
+  out = []
+  try:
+    def take():
+      rec = list(dbl.RECORDED); dbl.RECORDED.clear(); return rec
+    # decode (:149-157): the double returns no bytes, the reshape of an empty stream is fine
+    for ch in (1, 2):
+      take()
+      ref.parse_audio_from_file("/media/show.mkv", ch)
+      out.append(dict(name=f"decode_{ch}ch", args=dict(media_file="/media/show.mkv", num_channels=ch), argv=take()[0][1]))
+    # probes (:443-449, :460-462)
+    dbl.PROBE_RESULT = {"frames": [{"pts_time": "0.000000"}, {"pts_time": "10.010000"}, {"pkt_pts_time": "3"}]}
+    for t in (None, 12.5, 300.0):
+      take()
+      times = ref.get_key_frame_data("/media/show.mkv", t)
+      out.append(dict(name=f"key_frames_{t}", args=dict(video_file="/media/show.mkv", time=t), argv=take()[0][1], returned=[float(x) for x in times]))
+    dbl.PROBE_RESULT = {"streams": [{"disposition": {"descriptions": 0, "visual_impaired": 1}}]}
+    take()
+    ad = ref.is_first_video_track_ad("/media/show.mkv")
+    out.append(dict(name="first_track_is_ad", args=dict(video_file="/media/show.mkv"), argv=take()[0][1], returned=bool(ad)))
+    # default mux (:489-515): extensions decide codec / strictness; offsets of either sign; a rate change
+    setts = "if(lt(PTS,10),PTS*1.000000+0.500000,PTS*0.990000+1.250000)"
+    for name, ad_file, off, key, slope in (("mux_mp3_late", "/media/ad.mp3", 3.25, 1.5, 1.0), ("mux_wav_early", "/media/ad.wav", 0.75, 2.0, 1.0),
+                                           ("mux_flac_rate", "/media/ad.flac", 12.0, 11.123456, 1.0004), ("mux_m4a_zero", "/media/ad.m4a", 0.0, 0.0, 0.98)):
+      take()
+      logged = ref.write_replaced_media_to_disk("/out/ad_show.mkv", None, "/media/show.mkv", ad_file, setts, off, key, slope)
+      out.append(dict(name=name, args=dict(output_filename="/out/ad_show.mkv", video_file="/media/show.mkv", audio_desc_file=ad_file, setts_cmd=setts,
+                                           video_offset=off, after_start_key_frame=key, median_slope=slope), argv=take()[0][1], logged=logged))
+    # --stretch_audio mux (:468-488): with a video (first track AD or not) and audio only
+    media_arr = np.zeros((2, 441), dtype=np.float16)
+    for name, video, first_ad in (("stretch_video_first_original", "/media/show.mkv", 0), ("stretch_video_first_ad", "/media/described_show.mkv", 1),
+                                  ("stretch_audio_only", None, 0)):
+      dbl.PROBE_RESULT = {"streams": [{"disposition": {"descriptions": first_ad, "visual_impaired": 0}}]}
+      take()
+      logged = ref.write_replaced_media_to_disk("/out/ad_show.mkv", media_arr, video)
+      rec = take()
+      out.append(dict(name=name, args=dict(output_filename="/out/ad_show.mkv", video_file=video, first_track_is_ad=bool(first_ad)),
+                      argv=[a for k, a in rec if k == "run_async"][0], probe_argv=[a for k, a in rec if k == "probe"],
+                      stdin_bytes=[a for k, a in rec if k == "stdin_bytes"][0], logged=logged))
+  finally:
+    for k, v in saved.items():
+      setattr(ref, k, v)
+  json.dump(out, open(os.path.join(HERE, "commands.json"), "w"), indent=1)
+  print(f"[commands] {len(out)} command lines recorded")
+  return dict(count=len(out), how="reference functions run against tests/golden/ffmpeg_python_double.py (ffmpeg-python 0.2.0's compile rules restated)")
+
+
 def main(argv):
   idx_path = os.path.join(HERE, "index.json")
   index = json.load(open(idx_path)) if os.path.exists(idx_path) else {}
@@ -366,6 +420,8 @@ def main(argv):
     if name == "features":
       index["features"] = gen_features()
       print("[features] done")
+    elif name == "commands":
+      index["commands"] = gen_commands()
     elif name.startswith("combine_stretch:"):
       index.setdefault("combine_stretch", {})[name[16:]] = gen_combine_stretch(name[16:])
     elif name.startswith("stretch:"):

@@ -1050,7 +1050,7 @@ def test_combine_default_path_through_decoder_probe_and_mux_doubles(ctx, tmp_pat
   res2 = combine.process_pair(str(tmp_path / "described_show.mkv"), str(tmp_path / "ad.mka"), False, ctx, stretch_audio=True,
                               output_dir=out_dir, alignment_dir=plot_dir)
   rec = json.loads(open(os.path.join(out_dir, "ad_described_show.mkv")).read().split("\n")[0])
-  assert rec["argv"][:10] == ["-f", "s16le", "-acodec", "pcm_s16le", "-ac", "2", "-ar", "44100", "-i", "pipe:"]
+  assert rec["argv"][:10] == ["-f", "s16le", "-ac", "2", "-acodec", "pcm_s16le", "-ar", "44100", "-i", "pipe:"]
   assert "visual_impaired+descriptions" in rec["argv"][rec["argv"].index("-disposition:a:1") + 1]
   assert rec["stdin_bytes"] == 4 * len(pair.video if pair.video.ndim == 1 else pair.video[0])    # stereo s16le frames of the video's length
   assert res2 is not None

@@ -635,7 +635,7 @@ def test_stretch_audio_command_lines_follow_the_reference_options():
   as the described track, without one it is stored on its own."""
   from describealign_amd import combine
   with_video = combine._replaced_media_command("ffmpeg", "out/ad_show.mkv", "show.mkv")
-  assert with_video[:11] == ["ffmpeg", "-f", "s16le", "-acodec", "pcm_s16le", "-ac", "2", "-ar", "44100", "-i", "pipe:"]
+  assert with_video[:11] == ["ffmpeg", "-f", "s16le", "-ac", "2", "-acodec", "pcm_s16le", "-ar", "44100", "-i", "pipe:"]
   joined = " ".join(with_video)
   for needle in ("-i show.mkv", "-acodec copy", "-vcodec copy", "-scodec copy", "-max_interleave_delta 0",
                  "-c:a:0 aac", "-disposition:a:0 default+visual_impaired+descriptions", "-metadata:s:a:0 title=AD",
@@ -713,3 +713,81 @@ def test_bench_refuses_more_rccl_ranks_than_gpus():
   res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--workload", "cfg-small"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
   assert res.returncode != 0 and "needs 64 visible GPUs" in res.stderr and not res.stdout.strip()
+
+
+def test_result_buffers_are_handed_out_again_once_dropped(monkeypatch):
+  """Context._recycled: the rows of a pair are views of one pooled buffer; when the caller has dropped them all the same
+  memory must be handed out for the next pair (and never while a single row view is still alive)."""
+  import ctypes as C
+  from describealign_amd import _native
+
+  def fake_pinned(shape, dtype=np.int16):          # what pinned_empty builds, without the device allocation
+    count = int(np.prod(shape))
+    buf = (C.c_uint8 * max(1, count * np.dtype(dtype).itemsize))()
+    return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+  monkeypatch.setattr(_native, "pinned_empty", fake_pinned)
+
+  class Holder:
+    _pool = []
+  h = Holder()
+  a = _native.Context._recycled(h, (5, 100), np.float32)
+  addr = a.ctypes.data
+  rows = [a[0, :90]] + [a[k, :89] for k in range(1, 5)]
+  del a
+  b = _native.Context._recycled(h, (5, 100), np.float32)          # the rows of the first buffer are still held
+  assert b.ctypes.data != addr and len(h._pool) == 2
+  keep = rows.pop()
+  del rows
+  c = _native.Context._recycled(h, (5, 100), np.float32)          # one row view left: still not free
+  assert c.ctypes.data not in (addr, b.ctypes.data) and len(h._pool) == 3
+  del keep
+  d = _native.Context._recycled(h, (5, 100), np.float32)
+  assert d.ctypes.data == addr and d.shape == (5, 100) and len(h._pool) == 3
+  e = _native.Context._recycled(h, (5, 64), np.float32)           # another shape: its own buffer
+  assert e.shape == (5, 64) and len(h._pool) == 4
+
+
+def test_command_lines_equal_what_the_reference_compiles():
+  """tests/golden/commands.json holds the argv the REFERENCE's own functions compile (describealign.py:149-153 decode, :443-449
+  and :460-462 probes, :464-515 both mux graphs) -- recorded by make_golden.py through a recording restatement of ffmpeg-python
+  0.2.0's compile rules (tests/golden/ffmpeg_python_double.py; neither the package nor the binaries exist in this image).
+  The product builds its command lines directly; they must be the same lists, and the "FFmpeg command:" text of the report
+  (subprocess.list2cmdline of that list, back-slashes turned, :513-514) the same string."""
+  import json
+  from describealign_amd import combine, media
+  recs = {r["name"]: r for r in json.load(open(os.path.join(GOLD, "commands.json")))}
+  assert len(recs) == 13
+  for ch in (1, 2):
+    r = recs[f"decode_{ch}ch"]
+    assert media._ffmpeg_decode_command("ffmpeg", r["args"]["media_file"], ch) == r["argv"]
+  seen = []
+  real_run = subprocess.run
+
+  class Done:
+    returncode, stderr = 0, b""
+    def __init__(self, out): self.stdout = out
+  def fake_run(argv, **kw):
+    seen.append(list(argv))
+    return Done(b'{"frames": [{"pts_time": "0.000000"}, {"pts_time": "10.010000"}, {"pkt_pts_time": "3"}], "streams": [{"disposition": {"descriptions": 0, "visual_impaired": 1}}]}')
+  subprocess.run = fake_run
+  try:
+    for name in ("key_frames_None", "key_frames_12.5", "key_frames_300.0"):
+      r = recs[name]
+      times = combine.get_key_frame_data(r["args"]["video_file"], r["args"]["time"], ffprobe="ffprobe")
+      assert seen.pop() == r["argv"] and [float(t) for t in times] == r["returned"]
+    r = recs["first_track_is_ad"]
+    assert combine.is_first_video_track_ad(r["args"]["video_file"], ffprobe="ffprobe") is r["returned"] and seen.pop() == r["argv"]
+  finally:
+    subprocess.run = real_run
+  for name in ("mux_mp3_late", "mux_wav_early", "mux_flac_rate", "mux_m4a_zero"):
+    r = recs[name]; a = r["args"]
+    argv = combine._mux_command("ffmpeg", a["video_file"], a["audio_desc_file"], a["output_filename"], a["setts_cmd"], a["video_offset"],
+                                a["after_start_key_frame"], a["median_slope"])
+    assert argv == r["argv"], name
+    assert subprocess.list2cmdline(argv).replace("\\", "/") == r["logged"]
+  for name in ("stretch_video_first_original", "stretch_video_first_ad", "stretch_audio_only"):
+    r = recs[name]; a = r["args"]
+    argv = combine._replaced_media_command("ffmpeg", a["output_filename"], a["video_file"], a["first_track_is_ad"])
+    assert argv == r["argv"], name
+    assert subprocess.list2cmdline(argv).replace("\\", "/") == r["logged"]
