@@ -228,13 +228,14 @@ class Bench:
 
     for tm in sel:
       d = tm["device"]
-      for k in ("gemm_ms", "gemm_flops", "gemm_pairs", "verify_ms", "prep_ms", "chain_ms", "refine_kernel_ms",
+      for k in ("gemm_ms", "gemm_flops", "gemm_pairs", "verify_ms", "verify_kernel_ms", "prep_ms", "chain_ms", "refine_kernel_ms",
                 "refine_dp_ms", "survivors", "matches"):
         add(k, d[k])
       add("lp_s", tm["lp_s"]); add("match_s", tm["match_s"]); add("chain_s", tm["chain_s"])
       add("n_path1", tm["n_path1"]); add("n_fit_points", tm["n_fit_points"])
       add("align_s", tm["match_s"] + tm["chain_s"] + tm["pass1_host_s"] + tm["lp_s"] + tm["cluster_s"] + tm["refine_s"] + tm["nodes_s"])
-      for name in ("pass1_host_s", "cluster_s", "refine_s", "nodes_s", "worker_s", "features_s", "pace_s", "chain_begin_s"):
+      for name in ("pass1_host_s", "cluster_s", "refine_s", "nodes_s", "worker_s", "features_s", "pace_s", "chain_begin_s",
+                   "match_begin_s", "collect_under_gemm_s", "match_finish_s"):
         add(name, tm.get(name, 0.0))
       if "t_handoff" in tm and "done_t" in tm:      # where a pair spends its time between the stages (pipelined runs)
         add("iv_copy", tm["t_copied"] - tm["t_handoff"]); add("iv_wait_for_worker_slot", tm["t_submitted"] - tm["t_copied"])
@@ -258,6 +259,12 @@ class Bench:
       value = hours * world * steps / elapsed
       gemm_tf = acc["gemm_flops"] / (acc["gemm_ms"] * 1e-3) / 1e12 if acc.get("gemm_ms") else 0.0
       peak = PEAK_TFLOPS[prec_name]
+      # the same figure over EVERY launch of the stream (lead-in and tail included): what a rocprofv3 --stats average of this
+      # command shows -- in the lead-in the pairs are admitted at the GPU's own rate and every GEMM has the previous pair's
+      # chain DP, verify and sort beside it
+      all_ms = [tm["device"]["gemm_ms"] for tm in tms if tm.get("device", {}).get("gemm_ms")]
+      all_flops = [tm["device"]["gemm_flops"] for tm in tms if tm.get("device", {}).get("gemm_ms")]
+      gemm_tf_all = sum(all_flops) / (sum(all_ms) * 1e-3) / 1e12 if all_ms else 0.0
       res = {
         "metric": "aligned audio-hours/sec", "value": value, "unit": "audio-hours/s", "n_gpus": world,
         "ranks_in_group": grp.group_size(),
@@ -280,18 +287,22 @@ class Bench:
         "single_pair_realtime_factor": round(wl["seconds"] / (acc["align_s"] / k), 1),
         "roofline": {"bound": "mfma", "kernel": "k_match_" + prec_name, "achieved": gemm_tf, "peak": peak, "unit": "TFLOP/s",
                      "frac": gemm_tf / peak, "traffic": None,
+                     "frac_all_launches": gemm_tf_all / peak, "avg_launch_ms_all_launches": sum(all_ms) / max(1, len(all_ms)),
+                     "launches_all": len(all_ms),
                      "avg_launch_ms": acc["gemm_ms"] / k, "flops_per_launch": acc["gemm_flops"] / k,
                      "algorithmic": "246 flop x (non-quiet audio frames) x (every 4th non-quiet video frame)",
-                     "note": "avg_launch_ms = HIP events around the GEMM launches of the TIMED pairs; a rocprofv3 --stats average of the same command "
-                             "covers every launch of the run, lead-in included (those pairs are admitted at the GPU's own rate, with the previous pair's "
-                             "chain DP, verify and sort beside every GEMM) -- profiles/r03_bench_cfg2_bf16_gemm_by_region.json split such a trace. "
+                     "note": "frac / avg_launch_ms = HIP events around the GEMM launches of the TIMED pairs; frac_all_launches / avg_launch_ms_all_launches = "
+                             "the same over every launch of the stream, lead-in and tail included: the figure a rocprofv3 --stats average of this command "
+                             "supports (profiles/r05_bench_cfg2_bf16_kernel_stats.csv). "
                              "bf16: the kernel is bound by board power, not by its schedule -- a loop of nothing but its MFMAs on random operands holds "
                              "1.86 GHz on 256 CUs (2.38 on one) = 0.60-0.66 of the 2.4 GHz dense peak (profiles/r04_issue_microbench.txt, DESIGN.md 4.3)"},
         "feature_stage": {"bound": "hbm", "achieved": acc["feat_bytes"] / (acc["feat_ms"] * 1e-3) / 1e9 if acc.get("feat_ms") else 0.0,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_step": acc["feat_bytes"] / k,
                           "ms_per_step": acc["feat_ms"] / k},
-        "stage_ms_per_step": {n: round(acc[n] / k, 3) for n in ("feat_ms", "prep_ms", "gemm_ms", "verify_ms", "chain_ms",
+        "stage_ms_per_step": {n: round(acc[n] / k, 3) for n in ("feat_ms", "prep_ms", "gemm_ms", "verify_ms", "verify_kernel_ms", "chain_ms",
                                                                 "refine_kernel_ms", "refine_dp_ms")},
+        "stage_ms_note": "verify_ms = everything between the GEMM and the resident sorted match list (k_verify, radix sort, unpack, row / frame counts, "
+                         "with whatever shares the device at that moment); verify_kernel_ms = k_verify alone",
         "host_s_per_step": {"lp": round(acc["lp_s"] / k, 4), "align_latency_per_pair": round(acc["align_s"] / k, 4),
                             "gpu_match_stage_wall": round(acc["match_s"] / k, 4),
                             "chain_enqueue_to_collected": round(acc["chain_s"] / k, 4),
@@ -299,7 +310,10 @@ class Bench:
                             "cluster": round(acc.get("cluster_s", 0.0) / k, 4), "refine": round(acc.get("refine_s", 0.0) / k, 4),
                             "nodes": round(acc.get("nodes_s", 0.0) / k, 4),
                             "gpu_thread": {"pace_wait": round(acc.get("pace_s", 0.0) / k, 4), "features_incl_download": round(acc.get("features_s", 0.0) / k, 4),
-                                           "match_begin_to_finish": round(acc["match_s"] / k, 4), "chain_begin": round(acc.get("chain_begin_s", 0.0) / k, 4)},
+                                           "match_begin_to_finish": round(acc["match_s"] / k, 4), "chain_begin": round(acc.get("chain_begin_s", 0.0) / k, 4),
+                                           "match_begin_call": round(acc.get("match_begin_s", 0.0) / k, 4),
+                                           "collect_chains_under_gemm": round(acc.get("collect_under_gemm_s", 0.0) / k, 4),
+                                           "match_finish_call": round(acc.get("match_finish_s", 0.0) / k, 4)},
                             "intervals": {n[3:]: round(acc[n] / k, 4) for n in sorted(acc) if n.startswith("iv_")}},
         "pipeline": {"lp_worker_processes": workers, "gpu_streams": len(gpu_ctxs), "host_cores": os.cpu_count(),
                      "worker_count_rationale": "1.5 worker processes per L3 domain of the host (align.default_worker_count): one HiGHS solve of a long pair "
@@ -335,7 +349,7 @@ class Bench:
                            f"this rank's share of the host ({os.cpu_count()} logical CPUs, {world} rank(s): the host's LP capacity does not grow with the GPU count)")
       # HBM traffic of the dominant kernel from the committed PMC profile of this workload (PMC
       # collection needs its own rocprofv3 passes; bench.py itself only times with HIP events)
-      for prof_name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+      for prof_name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
           prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
           key = workload + "_" + prec_name
@@ -348,6 +362,14 @@ class Bench:
             alg = 12.0 * acc["matches"] / k
             res["roofline"]["algorithmic_bytes_per_launch"] = alg
             res["roofline"]["traffic_over_algorithmic"] = round(res["roofline"]["traffic"] / alg, 2) if alg > 0 else None
+            # the two parts separately: what the prefilter writes (8 B per survivor record, measured in THIS run) and the rest
+            # (the operand streams where they miss L2: the resident side re-read once per stripe, the streamed side once per XCD)
+            surv_bytes = 8.0 * acc["survivors"] / k
+            res["roofline"]["traffic_parts"] = {
+                "survivor_records_bytes": surv_bytes, "survivor_records_over_algorithmic": round(surv_bytes / alg, 2) if alg > 0 else None,
+                "survivor_records_per_verified_match": round(acc["survivors"] / acc["matches"], 2) if acc.get("matches") else None,
+                "operand_streams_bytes": max(0.0, res["roofline"]["traffic"] - surv_bytes),
+                "operand_streams_over_algorithmic": round(max(0.0, res["roofline"]["traffic"] - surv_bytes) / alg, 2) if alg > 0 else None}
             res["roofline"]["traffic_note"] = (
                 "requests of the L2s to the fabric (mostly served by the 256 MB MALL), per launch: the survivor records of the prefilter "
                 "(8 B each, 11 per verified match) and the two explicit operand streams where they miss an XCD's 4 MB L2 (the streamed "
@@ -356,6 +378,25 @@ class Bench:
             break
         except Exception:
           pass
+      if workers > 0 and out is not None and not quick:
+        # the host LP of this pair ONCE MORE with the host otherwise idle (the pipeline has drained): what a solve costs alone
+        # against what it cost beside the other workers' solves in the timed region
+        try:
+          with quiet:
+            vf1 = ctx.features_resident(_native.SIDE_VIDEO); af1 = ctx.features_resident(_native.SIDE_AUDIO)
+            tm1 = {}
+            A.align(vf1, af1, vf1[0], af1[0], ctx=ctx, timings=tm1)
+          if tm1.get("device", {}).get("gemm_ms"):
+            res["roofline"]["alone_launch_ms_same_device"] = round(tm1["device"]["gemm_ms"], 3)
+            res["roofline"]["alone_frac_same_device"] = tm1["device"]["gemm_flops"] / (tm1["device"]["gemm_ms"] * 1e-3) / 1e12 / peak
+          res["host_lp"] = {"solve_s_alone": round(tm1["lp_s"], 3), "solve_s_under_load": round(acc["lp_s"] / k, 3), "workers": workers,
+                            "solves_per_s_one_worker_alone": round(1.0 / tm1["lp_s"], 3), "solves_per_s_under_load_all_workers": round(lp_rate, 3),
+                            "fit_points": int(tm1["n_fit_points"]), "sequential_pair_s_idle_host": round(tm1["total_s"], 3),
+                            "note": "one sequential align() of this rank's pair after the pipeline has drained (host and GPU otherwise idle): its "
+                                    "scipy.optimize.linprog solve beside the mean solve time of the timed pairs inside the worker pool (the solves "
+                                    "share L3 slices and memory bandwidth)"}
+        except Exception as e:
+          res["host_lp"] = {"error": str(e)}
       if with_stretch:
         # outside the timed region: the --stretch_audio stage once on this
         # rank's resident pair with the nodes just found
@@ -436,7 +477,7 @@ def launch_ranks(n):
 SECONDARY_KEYS = ("value", "unit", "steps", "warmup", "lead_in_pairs_actual", "whole_stream_value", "ms_per_step", "dtype", "config",
                   "realtime_factor", "roofline", "feature_stage", "stage_ms_per_step", "host_s_per_step", "counts", "bound",
                   "gpu_stage_pairs_per_s", "lp_solves_per_s_host", "measured_pairs_per_s", "single_pair_latency_s",
-                  "max_offset_err_vs_injected_ms")
+                  "max_offset_err_vs_injected_ms", "timed_region", "host_lp", "lp_worker_utilisation")
 
 
 def main():
@@ -490,13 +531,14 @@ def main():
                              "note": "PCM in page-locked host memory (da_host_alloc), uploaded asynchronously on the copy stream "
                                      "(da_pcm_upload_async) in every step; value = whole-step rate including that transfer"}
   if single and args.workload == "cfg2" and not args.no_secondary and args.precision is None:
-    sec = b.run("cfg1", max(args.steps, 64), max(args.warmup, 8), with_cpu_baseline=False, with_stretch=False)
+    # timed regions of >= 10 s (cfg1: ~47 ms per pair, cfg3: ~70 ms): a 3-5 s region reads +-10 % from one host to the next
+    sec = b.run("cfg1", max(args.steps, 256), max(args.warmup, 8), with_cpu_baseline=False, with_stretch=False)
     if res is not None and sec is not None:
-      res["secondary"] = {k: sec[k] for k in SECONDARY_KEYS}
+      res["secondary"] = {k: sec[k] for k in SECONDARY_KEYS if k in sec}
     if not args.no_cfg3:
-      sec = b.run("cfg3", max(args.steps, 64), max(args.warmup, 8), with_cpu_baseline=False, with_stretch=False)
+      sec = b.run("cfg3", max(args.steps, 192), max(args.warmup, 8), with_cpu_baseline=False, with_stretch=False)
       if res is not None and sec is not None:
-        res["secondary_cfg3"] = {k: sec[k] for k in SECONDARY_KEYS}
+        res["secondary_cfg3"] = {k: sec[k] for k in SECONDARY_KEYS if k in sec}
   if grp.rank == 0:
     print(json.dumps(res))
   grp.close()

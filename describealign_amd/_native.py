@@ -15,7 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DALIGN_LIB") or os.path.join(_HERE, "libdalign.so")   # DALIGN_LIB: diagnostic builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 BF16_GUARD = 2.0 ** -7 + 2.0 ** -14   # csrc/dalign_common.h kBf16Guard: subtracted from the norm slot of the bf16 GEMM
 
 PREC_F32, PREC_BF16 = 0, 1
@@ -30,7 +30,7 @@ EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm
            "da_pcm_stream_open", "da_pcm_stream_piece", "da_pcm_stream_sync", "da_pcm_stream_frames", "da_pcm_stream_error", "da_pcm_adopt",
            "da_pcm_stream_close",
            "da_features_resident", "da_features", "da_match", "da_match_begin", "da_match_finish", "da_match_fetch",
-           "da_match_corr", "da_trim", "da_match_dump_tile", "da_match_export_device", "da_match_import_device", "da_match_import_reserve", "da_match_import_commit", "da_chain", "da_chain_begin", "da_chain_finish", "da_chain_resident", "da_chain_poll",
+           "da_match_corr", "da_trim", "da_match_dump_tile", "da_match_export_device", "da_match_import_device", "da_match_import_reserve", "da_match_import_commit", "da_chain", "da_chain_begin", "da_chain_begin_exclusive", "da_chain_finish", "da_chain_resident", "da_chain_poll",
            "da_refine", "da_stats", "da_replace_segments", "da_stretch_resident", "da_stretch_schedule"]
 
 
@@ -39,7 +39,7 @@ class Stats(C.Structure):
       "features_ms", "features_bytes", "prep_ms", "gemm_ms", "gemm_pairs", "gemm_flops", "verify_ms",
       "survivors", "matches", "chain_ms", "refine_kernel_ms", "refine_dp_ms", "refine_points", "h2d_ms",
       "resample_ms", "resample_points", "resample_bytes", "correlate_ms", "correlate_windows", "viterbi_ms",
-      "splice_ms", "splice_points", "stretch_prepare_ms", "stretch_finish_ms", "chain_columns", "chain_column_width")]
+      "splice_ms", "splice_points", "stretch_prepare_ms", "stretch_finish_ms", "chain_columns", "chain_column_width", "verify_kernel_ms")]
 
   def as_dict(self):
     return {n: getattr(self, n) for n, _ in self._fields_}
@@ -108,6 +108,7 @@ def load():
     lib.da_match_dump_tile.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.da_chain.argtypes = [vp, vp, vp, vp, i64, C.c_double, vp, vp, P(i64)]
     lib.da_chain_begin.argtypes = [vp, P(C.c_uint64)]
+    lib.da_chain_begin_exclusive.argtypes = [vp, P(C.c_uint64)]
     lib.da_chain_finish.argtypes = [vp, C.c_uint64, C.c_double, vp, vp, P(i64)]
     lib.da_chain_resident.argtypes = [vp, C.c_double, vp, vp, P(i64)]
     lib.da_chain_poll.argtypes = [vp, C.c_uint64]
@@ -473,12 +474,13 @@ class Context:
     self._check(self._lib.da_chain(self._h, _ptr(i), _ptr(v), _ptr(q), n, float(min_len), _ptr(pi), _ptr(pv), C.byref(m)))
     return pi[:m.value].copy(), pv[:m.value].copy()
 
-  def chain_begin(self) -> int:
+  def chain_begin(self, exclusive: bool = False) -> int:
     """Hand the resident matches of the last match()/match_finish() to the device chain DP and
     enqueue it on its own stream; returns a ticket for chain_finish.  The context is free for the
-    next match_begin at once."""
+    next match_begin at once.  exclusive: the caller waits for this DP before it launches anything else
+    (da_chain_begin_exclusive: the DP is not confined to the few CUs per XCD that DPs beside a GEMM get)."""
     t = C.c_uint64(0)
-    self._check(self._lib.da_chain_begin(self._h, C.byref(t)))
+    self._check((self._lib.da_chain_begin_exclusive if exclusive else self._lib.da_chain_begin)(self._h, C.byref(t)))
     return t.value
 
   def chain_finish(self, ticket: int, min_len: float = 0.0):
@@ -505,7 +507,7 @@ class Context:
 
   def chain_resident(self, min_len: float = 0.0):
     """Stage-2 chain DP on the matches still resident from the last match (describealign.py:654-698)."""
-    return self.chain_finish(self.chain_begin(), min_len)
+    return self.chain_finish(self.chain_begin(exclusive=True), min_len)
 
   def refine(self, a_scaled, v_scaled, cl_x0, cl_x1, cl_offset, cl_slope, min_len: float = 0.0):
     """Banded line extension + second DP -- describealign.py:895-993.  Returns (path[M,5], n_points)."""

@@ -530,6 +530,53 @@ def _cpu_topology(cpus=None):
   return primary, secondary, domain
 
 
+def _smt_siblings(cpus):
+  """cpu -> the set of hardware threads of its physical core (itself included), from sysfs; without sysfs the usual
+  Linux numbering (second half of the list = siblings of the first half)."""
+  out = {}
+  try:
+    for c in cpus:
+      txt = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+      sibs = set()
+      for part in txt.split(","):
+        if "-" in part:
+          a, b = part.split("-"); sibs.update(range(int(a), int(b) + 1))
+        elif part:
+          sibs.add(int(part))
+      out[c] = sibs
+  except Exception:
+    cpus = sorted(cpus)
+    half = max(1, len(cpus) // 2)
+    out = {c: {c, cpus[(k + half) % len(cpus)]} for k, c in enumerate(cpus)}
+  return out
+
+
+def aux_core_order(cpus, worker_cores, topology=None, siblings=None):
+  """(rest, dealt): the CPUs left for a pipeline's own threads once the LP workers' cores and their SMT siblings are set
+  aside, and the physical cores among them in the order the threads take them -- L3 domains with the fewest LP workers
+  first, one core per domain before a second one of any."""
+  primary, _, domain = topology if topology is not None else _cpu_topology(cpus)
+  sib = siblings if siblings is not None else _smt_siblings(cpus)
+  taken = set()
+  for c in worker_cores:
+    taken.update(sib.get(c, {c}))
+  rest = set(cpus) - taken
+  load = {}
+  for c in worker_cores:
+    load[domain[c]] = load.get(domain[c], 0) + 1
+  by_dom = {}
+  for c in sorted(c for c in primary if c in rest):
+    by_dom.setdefault(domain[c], []).append(c)
+  doms = sorted(by_dom, key=lambda d: (load.get(d, 0), d))
+  dealt, k, n = [], 0, sum(len(v) for v in by_dom.values())
+  while len(dealt) < n:
+    for d in doms:
+      if k < len(by_dom[d]):
+        dealt.append(by_dom[d][k])
+    k += 1
+  return rest, dealt
+
+
 def cpu_order(cpus=None):
   """The CPUs this process may use, ordered so that the first K are the best K places for K
   single-threaded solver processes: one hardware thread per physical core first (a HiGHS solve runs
@@ -690,25 +737,29 @@ class AlignPipeline:
         os.environ.pop(k, None)
       else:
         os.environ[k] = v
-    # keep this process's own threads (GPU feeder, refine pool, the caller) off the cores the LP
-    # workers are pinned to and off their SMT siblings; threads created below inherit the mask
+    # keep this process's own threads (GPU feeder, refine pool, hand-off, the caller) off the cores the LP workers of
+    # EVERY rank of this host are pinned to and off their SMT siblings; threads created below inherit the mask.  The
+    # pools' threads are then pinned one per core (`_aux_cores`: physical cores in the L3 domains with the fewest LP
+    # workers first), so that the second DP -- a pointer chase through ~270 MB per 2 h pair -- and the hand-off copies do
+    # not migrate between domains from pair to pair (round 4: the same binary ran the second DP 65 % slower on one host).
     self._old_affinity = None
-    if pin and int(os.environ.get("DALIGN_PIN_MAIN", "1")) and local_world == 1:
+    self._aux_cores, self._aux_next, self._pin_lock = [], 0, threading.Lock()
+    if pin and int(os.environ.get("DALIGN_PIN_MAIN", "1")):
       try:
         cpus = sorted(os.sched_getaffinity(0))
-        half = len(cpus) // 2
-        taken = set()
-        for c in order[:self.depth]:
-          taken.update({c, cpus[(cpus.index(c) + half) % len(cpus)]})
-        rest = set(cpus) - taken
-        if len(rest) >= 8:
+        rest, dealt = aux_core_order(cpus, order[:self.depth * local_world])
+        if len(rest) >= 8 * local_world:
+          mine_aux = dealt[local_rank::local_world] if local_world > 1 else dealt
           self._old_affinity = set(cpus)
-          os.sched_setaffinity(0, rest)
+          if local_world == 1:
+            os.sched_setaffinity(0, rest)
+          if int(os.environ.get("DALIGN_PIN_THREADS", "1")):
+            self._aux_cores = mine_aux
       except Exception:
         self._old_affinity = None
-    self.gpu_threads = [cf.ThreadPoolExecutor(max_workers=1) for _ in self.gpu_ctxs]
-    self.refine_pool = cf.ThreadPoolExecutor(max_workers=max(1, int(refine_threads)))
-    self.handoff_pool = cf.ThreadPoolExecutor(max_workers=2)      # copies path + feature rows into the workers' /dev/shm blocks
+    self.gpu_threads = [cf.ThreadPoolExecutor(max_workers=1, initializer=self._pin_thread) for _ in self.gpu_ctxs]
+    self.refine_pool = cf.ThreadPoolExecutor(max_workers=max(1, int(refine_threads)), initializer=self._pin_thread)
+    self.handoff_pool = cf.ThreadPoolExecutor(max_workers=2, initializer=self._pin_thread)      # copies path + feature rows into the workers' /dev/shm blocks
     self._local = threading.local()
     self._ctxs = []
     self._lock = threading.Lock()
@@ -730,6 +781,19 @@ class AlignPipeline:
     import sys
     self._old_switch = sys.getswitchinterval()
     sys.setswitchinterval(2e-4)
+
+  def _pin_thread(self):
+    """Initializer of the pipeline's own threads: each takes the next core of `_aux_cores` for itself."""
+    import threading
+    with self._pin_lock:
+      if not self._aux_cores or self._aux_next >= len(self._aux_cores):
+        return
+      core = self._aux_cores[self._aux_next]
+      self._aux_next += 1
+    try:
+      os.sched_setaffinity(threading.get_native_id(), {core})
+    except Exception:
+      pass
 
   def _thread_ctx(self):
     c = getattr(self._local, "ctx", None)
@@ -785,10 +849,14 @@ class AlignPipeline:
       tm["features_s"] = time.perf_counter() - t0
       t1 = time.perf_counter()
       ctx.match_begin(vf, af, self.mode)
+      ta = time.perf_counter()
       self._collect_chains(ctx, block_above=self.max_chains - 1)
+      tb = time.perf_counter()
       n = ctx.match_finish()
+      tc = time.perf_counter()
       tm["device"] = ctx.stats()
       tm["match_s"] = time.perf_counter() - t1
+      tm["match_begin_s"], tm["collect_under_gemm_s"], tm["match_finish_s"] = ta - t1, tb - ta, tc - tb
       tm["n_matches"] = n
       t2 = time.perf_counter()
       ticket = ctx.chain_begin()

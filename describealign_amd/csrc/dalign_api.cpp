@@ -70,7 +70,9 @@ struct ChainSlot {
   unsigned launches = 0;          // column DPs that have written `msg` since it was last zeroed (tag salt)
   int64_t rows_hint = 0;          // audio rows of the match that filled this slot (upper bound on the rows with matches), 0 = unknown
   int mode = 0;                   // how the DP in flight was launched: 0 = columns, 1 / 4 = one workgroup of 1 / 4 wavefronts
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // the DP's own stream, confined to a few CUs per XCD (create_stream): DPs that run BESIDE the next pairs' GEMMs
+  hipStream_t wide = nullptr;     // ... and an unconfined one for the blocking entry points (da_chain, da_chain_resident: nothing of this context overlaps)
+  hipStream_t run = nullptr;      // the one the DP in flight was enqueued on
   hipEvent_t e0 = nullptr, e1 = nullptr, ready = nullptr;
   int64_t n = 0, n_ranks = 0;
   int state = 0;                  // 0 free, 1 holds the last finished match, 2 chain DP enqueued, 3 reserved for an import
@@ -80,9 +82,10 @@ struct ChainSlot {
     for (DevBuf* b : {&keys, &q, &rank, &flags, &rows, &pred, &tree, &ids, &out_iv, &small, &temp,
                       &rowid, &ckey, &cval, &c_row, &c_lr, &c_q, &c_gid, &col_start, &rank_cum, &msg, &ctl, &seg, &dense}) b->release();
     if (stream) (void)hipStreamDestroy(stream);
+    if (wide) (void)hipStreamDestroy(wide);
     for (hipEvent_t e : {e0, e1, ready}) if (e) (void)hipEventDestroy(e);
     if (h_small) (void)hipHostFree(h_small);
-    stream = nullptr; e0 = e1 = ready = nullptr; h_small = nullptr;
+    stream = wide = run = nullptr; e0 = e1 = ready = nullptr; h_small = nullptr;
   }
 };
 constexpr int kMaxChainSlots = 16;
@@ -213,13 +216,13 @@ int enqueue_dense_ranks(da_ctx* c, ChainSlot& sl, int64_t n, int64_t lv, int32_t
 // bits round-robin over the eight XCDs).  A chain DP is ~1 000 single-wavefront column workgroups: spread over the chip, each
 // one keeps a whole CU from taking a GEMM workgroup (four waves of 428 registers need all four SIMDs empty) while it occupies
 // one SIMD of it; confined to a few CUs per XCD the columns pack there and the GEMM keeps the rest.
-//   DALIGN_CHAIN_CUS = k      the chain DP's streams get the first k CUs of every XCD (0 / unset: no mask)
+//   DALIGN_CHAIN_CUS = k      the chain DP's streams get the first k CUs of every XCD (default 8; 0: no mask)
 //   DALIGN_CHAIN_CUS = xN     ... N whole XCDs (neighbouring columns then hand over through ONE L2)
 //   DALIGN_MAIN_CUS  = rest   the context's main stream (GEMM, verify, sort) gets the complement
 bool chain_cu_mask(uint32_t (&mask)[8]) {
   const char* e = std::getenv("DALIGN_CHAIN_CUS");
   for (uint32_t& w : mask) w = 0u;
-  if (!e || !*e) return false;
+  if (!e || !*e) e = "8";                      // the default (sweep: profiles/r05_cu_mask_sweep.jsonl); "0" = no mask
   if (*e == 'x' || *e == 'X') {
     const int n = std::max(1, std::min(7, std::atoi(e + 1)));
     for (int b = 0; b < 256; ++b) if (b % 8 < n) mask[b / 32] |= 1u << (b % 32);
@@ -249,7 +252,7 @@ int acquire_slot(da_ctx* c) {
     if (c->slots[k]->state == 0) return (int)k;
   if ((int)c->slots.size() >= kMaxChainSlots) return -1;
   ChainSlot* sl = new ChainSlot();
-  if (create_stream(&sl->stream, true) != hipSuccess ||
+  if (create_stream(&sl->stream, true) != hipSuccess || hipStreamCreateWithFlags(&sl->wide, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&sl->e0) != hipSuccess || hipEventCreate(&sl->e1) != hipSuccess ||
       hipEventCreateWithFlags(&sl->ready, hipEventDisableTiming) != hipSuccess ||
       hipHostMalloc((void**)&sl->h_small, 64, hipHostMallocDefault) != hipSuccess) {
@@ -298,7 +301,7 @@ void build_tables(FeatTables& T) {
 
 extern "C" {
 
-int da_abi_version(void) { return 4; }
+int da_abi_version(void) { return 5; }
 
 const char* da_last_error(const da_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -350,7 +353,11 @@ void da_destroy(da_ctx* c) {
                    &c->band_y, &c->band_q, &c->band_part, &c->band_tab, &c->band_cl, &c->band_keys, &c->band_ids, &c->band_head,
                    &c->band_out, &c->band_tmp};
   for (DevBuf* b : all) b->release();
-  for (ChainSlot* sl : c->slots) { if (sl->stream) (void)hipStreamSynchronize(sl->stream); sl->release(); delete sl; }
+  for (ChainSlot* sl : c->slots) {
+    if (sl->stream) (void)hipStreamSynchronize(sl->stream);
+    if (sl->wide) (void)hipStreamSynchronize(sl->wide);
+    sl->release(); delete sl;
+  }
   for (HandoverBuf& h : c->handover_free) h.buf.release();
   c->slots.clear();
   c->st_video.release(); c->st_audio.release(); c->st_out.release();
@@ -675,7 +682,7 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
   }
   c->st.gemm_pairs = (double)n_v * (double)n_a;
   c->st.gemm_flops = 246.0 * c->st.gemm_pairs;
-  c->st.survivors = 0; c->st.matches = 0; c->st.gemm_ms = 0; c->st.verify_ms = 0;
+  c->st.survivors = 0; c->st.matches = 0; c->st.gemm_ms = 0; c->st.verify_ms = 0; c->st.verify_kernel_ms = 0;
 
   MatchArgs m{};
   for (int j = 0; j < 3; ++j) {
@@ -752,8 +759,10 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
       HIP_TRY(c, c->q0.ensure(sizeof(double) * mcap));
       v.keys = c->keys0.as<unsigned long long>(); v.quals = c->q0.as<double>(); v.out_capacity = mcap;
       HIP_TRY(c, hipMemsetAsync(d_cnt + 1, 0, 2 * sizeof(unsigned long long), c->stream));
+      HIP_TRY(c, hipEventRecord(c->prep_e0, c->stream));          // (the prep events have been read above: free for the kernel's own bracket)
       launch_verify(v, n_surv, c->stream);
       HIP_TRY(c, hipGetLastError());
+      HIP_TRY(c, hipEventRecord(c->prep_e1, c->stream));
       HIP_TRY(c, hipMemcpyAsync(c->h_pin + 3, d_cnt + 1, sizeof n_match, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       n_match = c->h_pin[3];
@@ -797,6 +806,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
     sl.rows_hint = (int64_t)n_rows;
     sl.n_ranks = *n_used;
     float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.verify_ms = ms;
+    ms = 0.f; (void)hipEventElapsedTime(&ms, c->prep_e0, c->prep_e1); c->st.verify_kernel_ms = ms;
   }
   c->st.matches = (double)n_match;
   c->n_match_resident = n_match;
@@ -1066,7 +1076,7 @@ struct DbgTimes {
   ~DbgTimes() { if (on) std::fprintf(stderr, "[%s] total %8.3f ms\n", who, now_ms() - t0); }
 };
 
-int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
+int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist, bool wide = false) {
   DbgTimes dbg("chain_enqueue");
   const int64_t n = sl.n;
   const size_t nn = (size_t)std::max<int64_t>(1, n);
@@ -1092,7 +1102,8 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
     HIP_TRY(c, sl.temp.ensure(tb + 256));
   }
   dbg.at("ensure (common)");
-  hipStream_t st = sl.stream;
+  hipStream_t st = wide ? sl.wide : sl.stream;
+  sl.run = st;
   // `small`: int32 [0] rows, [1] err; int64 [1] best id, [2] path length
   ChainLaunch L{};
   L.keys = sl.keys.as<unsigned long long>(); L.q = sl.q.as<double>(); L.n = n;
@@ -1228,7 +1239,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist) {
 
 // wait for a slot's DP and hand the path out; frees the slot unless the caller's buffers were too small
 int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
-  HIP_TRY(c, hipStreamSynchronize(sl.stream));
+  HIP_TRY(c, hipStreamSynchronize(sl.run));
   float ms = 0.f; (void)hipEventElapsedTime(&ms, sl.e0, sl.e1); c->st.chain_ms = ms;
   give_back_handover(c, sl);
   if (std::getenv("DALIGN_DEBUG_STAMPS") && sl.mode == 0 && sl.n > 0) {   // diagnostic builds (-DDA_CHAIN_STAMPS) only
@@ -1283,9 +1294,9 @@ int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int
   if (L > 0) {
     if (!path_i || !path_v) return fail(c, DA_ERR_ARG, "da_chain: null output");
     const size_t nn = (size_t)std::max<int64_t>(1, sl.n);
-    HIP_TRY(c, hipMemcpyAsync(path_i, sl.out_iv.as<int32_t>(), sizeof(int32_t) * L, hipMemcpyDeviceToHost, sl.stream));
-    HIP_TRY(c, hipMemcpyAsync(path_v, sl.out_iv.as<int32_t>() + nn, sizeof(int32_t) * L, hipMemcpyDeviceToHost, sl.stream));
-    HIP_TRY(c, hipStreamSynchronize(sl.stream));
+    HIP_TRY(c, hipMemcpyAsync(path_i, sl.out_iv.as<int32_t>(), sizeof(int32_t) * L, hipMemcpyDeviceToHost, sl.run));
+    HIP_TRY(c, hipMemcpyAsync(path_v, sl.out_iv.as<int32_t>() + nn, sizeof(int32_t) * L, hipMemcpyDeviceToHost, sl.run));
+    HIP_TRY(c, hipStreamSynchronize(sl.run));
   }
   sl.state = 0;
   return DA_OK;
@@ -1321,7 +1332,7 @@ extern "C" int da_chain(da_ctx* c, const int32_t* pi, const int32_t* pv, const d
   }
   sl.n = n; sl.n_ranks = nr;
   { int64_t rows = 0; for (int64_t k = 0; k < n; ++k) rows += (k == 0 || pi[k] != pi[k - 1]); sl.rows_hint = rows; }
-  int rc = chain_enqueue(c, sl, false);
+  int rc = chain_enqueue(c, sl, false, true);
   if (rc) { (void)hipStreamSynchronize(c->stream); sl.state = 0; return rc; }
   HIP_TRY(c, hipStreamSynchronize(c->stream));          // the host staging vectors go out of scope
   rc = chain_collect(c, sl, min_len, path_i, path_v, n_path);
@@ -1329,7 +1340,8 @@ extern "C" int da_chain(da_ctx* c, const int32_t* pi, const int32_t* pv, const d
   return rc;
 }
 
-extern "C" int da_chain_begin(da_ctx* c, uint64_t* ticket) {
+namespace {
+int chain_begin_on(da_ctx* c, uint64_t* ticket, bool wide) {
   if (!c) return DA_ERR_ARG;
   if (!ticket) return fail(c, DA_ERR_ARG, "da_chain_begin: null ticket");
   if (!c->fetch_ready) return fail(c, DA_ERR_STATE, "da_chain_begin: no finished match is resident");
@@ -1345,12 +1357,16 @@ extern "C" int da_chain_begin(da_ctx* c, uint64_t* ticket) {
   }
   ChainSlot& sl = *c->slots[si];
   if (sl.state == 2) return fail(c, DA_ERR_STATE, "da_chain_begin: the chain DP of this match is already in flight");
-  const int rc = chain_enqueue(c, sl, true);
+  const int rc = chain_enqueue(c, sl, true, wide);
   if (rc) return rc;
   c->res_slot = si;                                     // still the resident match (da_match_fetch keeps working)
   *ticket = sl.ticket;
   return DA_OK;
 }
+}  // namespace
+
+extern "C" int da_chain_begin(da_ctx* c, uint64_t* ticket) { return chain_begin_on(c, ticket, false); }
+extern "C" int da_chain_begin_exclusive(da_ctx* c, uint64_t* ticket) { return chain_begin_on(c, ticket, true); }
 
 extern "C" int da_chain_finish(da_ctx* c, uint64_t ticket, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
   if (!c) return DA_ERR_ARG;
@@ -1371,7 +1387,7 @@ extern "C" int da_chain_poll(da_ctx* c, uint64_t ticket) {
   if (!c) return DA_ERR_ARG;
   for (ChainSlot* sl : c->slots)
     if (sl->state == 2 && sl->ticket == ticket) {
-      const hipError_t e = hipStreamQuery(sl->stream);
+      const hipError_t e = hipStreamQuery(sl->run);
       if (e == hipSuccess) return 1;
       if (e == hipErrorNotReady) return 0;
       return fail(c, DA_ERR_DEVICE, "da_chain_poll: %s", hipGetErrorString(e));
@@ -1381,7 +1397,7 @@ extern "C" int da_chain_poll(da_ctx* c, uint64_t ticket) {
 
 extern "C" int da_chain_resident(da_ctx* c, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
   uint64_t t = 0;
-  int rc = da_chain_begin(c, &t);
+  int rc = chain_begin_on(c, &t, true);                 // blocking call: the DP has the chip to itself
   if (rc) return rc;
   return da_chain_finish(c, t, min_len, path_i, path_v, n_path);
 }

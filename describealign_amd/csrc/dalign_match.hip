@@ -214,10 +214,41 @@ __device__ __forceinline__ int bf_bit_row(int b) { return (b & 1) ? 8 + (b >> 1)
 // Survivors of one finished phase: every lane whose code word is not all-reject stages one record
 //   lo = reject bits | h << 16 | vtile << 17,   hi = vtile >> 15 | (position in the audio row list) << 9
 // at the next free slot of its wave's LDS buffer.  The caller flushes the buffer before it can overflow.
+#ifdef DA_DBG_BF_FAKEVOTE
+// Ablation (round 5, profiles/r05_vote_in_gemm.txt): what would the reference's hash vote cost INSIDE the GEMM's rare path?  The
+// build does the work of a vote for the first surviving row of every lane that has one -- four 16-byte LDS reads of a
+// "video hash record" (the wave's 192 rows x 64 B would live in LDS), five closed-form digit tests against eight words standing
+// in for the column's audio record -- and then keeps one record in eight (what the real vote keeps), so that the emission path,
+// the survivor list and k_verify see the volume a voted list would have.  Results are meaningless; only times are read.
+__device__ uint32_t g_fakevote_zero;                 // stays 0: makes the vote's outcome formally live without changing the 1-in-8 rule
+__device__ __forceinline__ bool bf_fake_vote(const uint4* s_vhash, uint32_t codes, uint32_t acol, int64_t vtile) {
+  const uint32_t surv = (~bf_reject_bits(codes)) & 0xFFFFu;
+  const int b = __ffs(surv) - 1;
+  const int g = bf_bit_row(b < 0 ? 0 : b);
+  const uint4* rec = s_vhash + ((int)(vtile & 3) * 32 + ((g & 3) + 8 * (g >> 2))) * 4;
+  const uint4 D0 = rec[0], G0 = rec[1], D1 = rec[2], G1 = rec[3];
+  const uint32_t a0 = acol * 0x9E3779B1u | 0x08888888u, a1 = (acol ^ 0x5bd1e995u) * 0x85EBCA6Bu | 0x08888888u;
+  int hits = 0;
+  hits += digit_hit(a0, D0.x, G0.x) ? 1 : 0; hits += digit_hit(a1, D0.y, G0.y) ? 1 : 0;
+  hits += digit_hit(a0 ^ 0x01010101u, D0.z, G0.z) ? 1 : 0; hits += digit_hit(a1 ^ 0x02020202u, D0.w, G0.w) ? 1 : 0;
+  hits += digit_hit(a0 ^ 0x03030303u, D1.x, G1.x) ? 1 : 0;
+  const bool keep = (((acol * 2654435761u) ^ ((uint32_t)vtile * 40503u) ^ (codes * 0x27D4EB2Fu)) >> 29) == 0u;       // 1 in 8
+  return keep || ((uint32_t)hits & g_fakevote_zero) != 0u;
+}
+#endif
+
 __device__ __forceinline__ void bf_emit(SurvSink& sk, int h, int64_t vtile, uint32_t codes, uint32_t acol) {
+#ifdef DA_DBG_BF_FAKEVOTE
+  bool any = codes != kBdAllReject;
+  if (__ballot(any) == 0ull) return;
+  if (any) any = bf_fake_vote(reinterpret_cast<const uint4*>(sk.s_buf + sk.cap + 64), codes, acol, vtile);
+  const unsigned long long m = __ballot(any);
+  if (m == 0ull) return;
+#else
   const bool any = codes != kBdAllReject;
   const unsigned long long m = __ballot(any);
   if (m == 0ull) return;               // ~4 in 10 phases have no survivor at all
+#endif
   const int pos = sk.count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
   const uint32_t lo = bf_reject_bits(codes) | ((uint32_t)h << 16) | ((uint32_t)vtile << 17);
   const uint32_t hi = (acol << 9) | (uint32_t)(vtile >> 15);
@@ -370,7 +401,11 @@ __global__ __launch_bounds__(64) void k_bf16_audio_frags(MatchArgs a) {
 // tiles of the audio operand: nine 1 KiB loads per tile, issued one whole tile (54 MFMAs) ahead into a second
 // register set, every fragment feeding six MFMAs.
 __global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
+#ifdef DA_DBG_BF_FAKEVOTE
+  __shared__ unsigned long long s_surv[kBdWaves][kBdSurv + 64 + 1024];           // + 8 KiB of stand-in hash records per wave
+#else
   __shared__ unsigned long long s_surv[kBdWaves][kBdSurv + 64];
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -895,7 +930,9 @@ __global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyArgs a, unsigne
           const int64_t vr = vtile * 32 + row;
           if (vr < a.n_v) {
             const int32_t v = a.vlist[vr];
-#ifdef DA_DBG_VERIFY_NOVOTE           // ablation build: no hash loads, one pair in eight passes
+#if defined(DA_DBG_VERIFY_ALLPASS)     // ablation build: the records arrive voted (DA_DBG_BF_FAKEVOTE): every pair goes to the exact step
+            s_cand[atomicAdd(&s_nc, 1u)] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v;
+#elif defined(DA_DBG_VERIFY_NOVOTE)   // ablation build: no hash loads, one pair in eight passes
             if (((uint32_t)i * 2654435761u + (uint32_t)v * 40503u) >> 29 == 0u) s_cand[atomicAdd(&s_nc, 1u)] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v;
 #else
             if (vote_pair(a, i, v)) s_cand[atomicAdd(&s_nc, 1u)] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)v;

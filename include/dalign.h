@@ -192,6 +192,12 @@ int da_chain(da_ctx* ctx, const int32_t* i, const int32_t* v, const double* q, i
  * da_chain_begin) BEFORE the next da_match_begin on the context; afterwards it fails with DA_ERR_STATE.
  * Limits: fewer than 2^31 matches and 2^24 distinct video rows. */
 int da_chain_begin(da_ctx* ctx, uint64_t* ticket);
+/* da_chain_begin for a caller that will wait for this DP before it launches anything else on the device (the sequential
+ * align() of describealign.py:654-698, rank 0 of a tiled long pair): the DP gets the whole chip.  da_chain_begin's DPs are
+ * meant to run BESIDE the similarity GEMMs of the next pairs and are confined to a few compute units per XCD (a column
+ * wavefront on a CU keeps a whole GEMM workgroup off it), which makes a DP that runs alone ~1.4x slower than it need be.
+ * Same ticket, same da_chain_finish / da_chain_poll. */
+int da_chain_begin_exclusive(da_ctx* ctx, uint64_t* ticket);
 int da_chain_finish(da_ctx* ctx, uint64_t ticket, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path);
 int da_chain_resident(da_ctx* ctx, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path);
 /* 1 when the DP behind `ticket` has completed (da_chain_finish will not block), 0 while it runs,
@@ -244,7 +250,7 @@ typedef struct da_stats_t {
   double gemm_ms;            /* similarity GEMM kernel */
   double gemm_pairs;         /* (audio rows) x (video rows) evaluated */
   double gemm_flops;         /* 246 flop per pair (2*41*3, describealign.py:664-667) */
-  double verify_ms;          /* exact re-verification + compaction + sort */
+  double verify_ms;          /* exact re-verification + compaction + sort + the counts behind it (everything between the GEMM and the resident, sorted match list) */
   double survivors;          /* pairs the GEMM passed to verification */
   double matches;            /* verified matches returned */
   double chain_ms;           /* stage-2 chain DP: device time of the last collected DP (host time with a NULL-ctx call) */
@@ -266,6 +272,7 @@ typedef struct da_stats_t {
   /* chain DP geometry of the last enqueued DP (ABI v4): rank columns and their width; 0 = one-workgroup kernel */
   double chain_columns;
   double chain_column_width;
+  double verify_kernel_ms;   /* of verify_ms: the exact re-verification kernel alone (k_verify, last attempt) */
 } da_stats_t;
 
 int da_stats(const da_ctx* ctx, da_stats_t* out);

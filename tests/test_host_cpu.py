@@ -791,3 +791,25 @@ def test_command_lines_equal_what_the_reference_compiles():
     argv = combine._replaced_media_command("ffmpeg", a["output_filename"], a["video_file"], a["first_track_is_ad"])
     assert argv == r["argv"], name
     assert subprocess.list2cmdline(argv).replace("\\", "/") == r["logged"]
+
+
+def test_pipeline_threads_take_quiet_cores_away_from_the_lp_workers():
+  """align.aux_core_order: a host of 2 x 16 cores with SMT (siblings c, c + 32), 8 cores per L3 domain, 6 LP workers: the
+  workers' cores AND their siblings are set aside; the pipeline's own threads take physical cores, the domains without a
+  worker first, one per domain before a second of any."""
+  from describealign_amd import align as A
+  cpus = list(range(64))
+  primary, secondary = cpus[:32], cpus[32:]
+  domain = {c: 8 * ((c % 32) // 8) for c in cpus}
+  sib = {c: {c % 32, c % 32 + 32} for c in cpus}
+  workers = [0, 8, 16, 1, 9, 2]                       # domains 0 / 8 / 16 carry 3 / 2 / 1 workers, domain 24 none
+  rest, dealt = A.aux_core_order(cpus, workers, topology=(primary, secondary, domain), siblings=sib)
+  assert rest == set(cpus) - set(workers) - {w + 32 for w in workers}
+  assert all(c in primary and c in rest for c in dealt) and len(set(dealt)) == len(dealt) == 32 - 6
+  assert [domain[c] for c in dealt[:4]] == [24, 16, 8, 0] and dealt[0] == 24 and dealt[3] == 3
+  assert [domain[c] for c in dealt[4:8]] == [24, 16, 8, 0]
+  # the live host: whatever its topology, the result is consistent with it
+  live = sorted(os.sched_getaffinity(0))
+  order = A.cpu_order(live)
+  rest, dealt = A.aux_core_order(live, order[:2])
+  assert not (set(order[:2]) & rest) and set(dealt) <= rest
