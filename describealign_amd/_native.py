@@ -47,7 +47,7 @@ class Stats(C.Structure):
 
 def build(verbose: bool = False) -> str:
   """Compile libdalign.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-  cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+  cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4", "all", "dbg"]      # dbg: the diagnostic / test-hook library the GPU tests load by name
   res = subprocess.run(cmd, capture_output=True, text=True)
   if verbose or res.returncode != 0:
     print(res.stdout[-4000:])

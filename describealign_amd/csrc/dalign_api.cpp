@@ -1179,9 +1179,11 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist, bool wide = fa
       }
       const size_t cap_before = sl.msg.cap;
       hipError_t e = hipSuccess;
-      if (const char* lim = std::getenv("DALIGN_CHAIN_HANDOVER_LIMIT")) {       // tests: pretend the device has no more than this many bytes for it
+#ifdef DA_TEST_HOOKS   // libdalign_dbg.so only (make dbg): pretend the device has no more than this many bytes for the buffer
+      if (const char* lim = std::getenv("DALIGN_CHAIN_HANDOVER_LIMIT")) {
         if (need > (size_t)std::strtoull(lim, nullptr, 10)) e = hipErrorOutOfMemory;
       }
+#endif
       if (e == hipSuccess) e = sl.msg.ensure(need);
       if (e == hipErrorOutOfMemory && K.n_cols > da::chain_columns_plan(n, sl.n_ranks, 1).n_cols) {
         (void)hipGetLastError();                           // the estimate above was too generous: half the columns

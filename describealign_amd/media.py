@@ -105,7 +105,12 @@ def _wav_pcm_span(media_file, num_channels):
       nbytes = w.getnframes() * 2 * num_channels
       w.setpos(0)
       # the wave module has parsed the chunks and stands at the first frame: the underlying file's position is the data offset
-      return w.getfp().file.tell() if hasattr(w.getfp(), "file") else None, nbytes
+      offset = w.getfp().file.tell() if hasattr(w.getfp(), "file") else None
+      if offset is not None:
+        # a streamed WAV (`ffmpeg -f wav -`) declares a data size of 0xFFFFFFFF: never more than the file holds, whole frames
+        have = max(0, os.path.getsize(media_file) - offset)
+        nbytes = min(nbytes, have - have % (2 * num_channels))
+      return offset, nbytes
   except (wave.Error, EOFError, OSError, ValueError, AttributeError):
     return None
 

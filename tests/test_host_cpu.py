@@ -813,3 +813,23 @@ def test_pipeline_threads_take_quiet_cores_away_from_the_lp_workers():
   order = A.cpu_order(live)
   rest, dealt = A.aux_core_order(live, order[:2])
   assert not (set(order[:2]) & rest) and set(dealt) <= rest
+
+
+def test_streamed_wav_with_an_unknown_data_size_is_read_as_far_as_the_file_goes(tmp_path):
+  """A WAV written to a pipe (`ffmpeg -f wav -`) declares 0xFFFFFFFF data bytes: the native reader must size its buffer by the
+  file, not by the header (a 4 GiB -- in batch mode page-locked -- allocation for a 2 s clip otherwise)."""
+  import struct
+  from describealign_amd import media
+  rng = np.random.default_rng(4)
+  pcm = rng.integers(-2000, 2000, size=(2, 88200), dtype=np.int16)
+  path = str(tmp_path / "piped.wav")
+  media.write_wav(path, pcm)
+  raw = bytearray(open(path, "rb").read())
+  at = raw.index(b"data") + 4
+  raw[at:at + 4] = struct.pack("<I", 0xFFFFFFFF)
+  raw[4:8] = struct.pack("<I", 0xFFFFFFFF)
+  open(path, "wb").write(bytes(raw) + b"\x01")          # and a ragged tail byte
+  span = media._wav_pcm_span(path, 2)
+  assert span is not None and span[1] == pcm.size * 2
+  got = media.parse_audio_from_file(path, 2)
+  assert got.shape == pcm.shape and np.array_equal(np.asarray(got, dtype=np.int16), pcm)
