@@ -144,11 +144,17 @@ class Bench:
     feat = {}
     lock = threading.Lock()
 
+    fused = workers > 0 and not args.separate_calls
+
     def make_job(idx):
       def job(c):
         if include_h2d:
           c.pcm_upload_async(_native.SIDE_VIDEO, self.pinned[workload][0])
           c.pcm_upload_async(_native.SIDE_AUDIO, self.pinned[workload][1])
+        if fused and not include_h2d:
+          # the pair's PCM is resident: the pipeline runs features + matching + chain enqueue as ONE native call (da_pair_stage);
+          # the feature times come back with that call's statistics (tm["device"])
+          return A.RESIDENT_PCM
         vf = c.features_resident(_native.SIDE_VIDEO)
         s_v = c.stats()
         af = c.features_resident(_native.SIDE_AUDIO)
@@ -218,6 +224,7 @@ class Bench:
       done_times = sorted(tm["done_t"] for tm in tms)
       t0 = done_times[warmup - 1] if warmup > 0 else t_start
       t1 = done_times[warmup + steps - 1]
+    tms_by_idx = {k: tm for k, tm in enumerate(tms)}          # results are delivered in submission order
     elapsed = grp.max_over_ranks(t1 - t0)
     out = outs[warmup + steps - 1]
     sel = tms[warmup:warmup + steps]
@@ -242,7 +249,10 @@ class Bench:
         add("iv_in_worker_pool", tm["t_worker_back"] - tm["t_submitted"]); add("iv_wait_for_refine_thread", tm["t_refine_start"] - tm["t_worker_back"])
         add("iv_refine_and_nodes", tm["done_t"] - tm["t_refine_start"])
     for idx in range(warmup, warmup + steps):
-      add("feat_ms", feat[idx][0]); add("feat_bytes", feat[idx][1])
+      if idx in feat:
+        add("feat_ms", feat[idx][0]); add("feat_bytes", feat[idx][1])
+      else:                                    # fused stage: both sides' feature kernels are in the pair's own statistics
+        add("feat_ms", tms_by_idx[idx]["device"]["features_ms"]); add("feat_bytes", tms_by_idx[idx]["device"]["features_bytes"])
 
     # accuracy of the recovered piecewise offsets against the injected truth (this rank's pair)
     x, y = out[0], out[1]
@@ -499,6 +509,9 @@ def main():
                   help="diagnostic: re-upload the PCM over PCIe inside every step (the PCIe-inclusive rate; never the headline value)")
   ap.add_argument("--gpu-streams", type=int, default=1,
                   help="contexts (HIP streams + host threads) feeding the GPU matching stage; pipelined mode only")
+  ap.add_argument("--separate-calls", action="store_true",
+                  help="diagnostic: the GPU thread issues features / match_begin / match_finish / chain_begin as separate calls (round-4 behaviour) "
+                       "instead of the one native call per pair (da_pair_stage)")
   ap.add_argument("--pipeline", type=int, default=-1,
                   help="host worker processes (pass 1, LP); -1 = sized for this rank's share of the host; 0 = strictly sequential align()")
   args = ap.parse_args()

@@ -30,7 +30,7 @@ EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm
            "da_pcm_stream_open", "da_pcm_stream_piece", "da_pcm_stream_sync", "da_pcm_stream_frames", "da_pcm_stream_error", "da_pcm_adopt",
            "da_pcm_stream_close",
            "da_features_resident", "da_features", "da_match", "da_match_begin", "da_match_finish", "da_match_fetch",
-           "da_match_corr", "da_trim", "da_match_dump_tile", "da_match_export_device", "da_match_import_device", "da_match_import_reserve", "da_match_import_commit", "da_chain", "da_chain_begin", "da_chain_begin_exclusive", "da_chain_finish", "da_chain_resident", "da_chain_poll",
+           "da_match_corr", "da_trim", "da_match_dump_tile", "da_match_export_device", "da_match_import_device", "da_match_import_reserve", "da_match_import_commit", "da_chain", "da_chain_begin", "da_chain_begin_exclusive", "da_pair_stage", "da_chain_finish", "da_chain_resident", "da_chain_poll",
            "da_refine", "da_stats", "da_replace_segments", "da_stretch_resident", "da_stretch_schedule"]
 
 
@@ -109,6 +109,7 @@ def load():
     lib.da_chain.argtypes = [vp, vp, vp, vp, i64, C.c_double, vp, vp, P(i64)]
     lib.da_chain_begin.argtypes = [vp, P(C.c_uint64)]
     lib.da_chain_begin_exclusive.argtypes = [vp, P(C.c_uint64)]
+    lib.da_pair_stage.argtypes = [vp, vp, i64, vp, i64, i32, P(i64), P(i64), P(i64), P(C.c_uint64)]
     lib.da_chain_finish.argtypes = [vp, C.c_uint64, C.c_double, vp, vp, P(i64)]
     lib.da_chain_resident.argtypes = [vp, C.c_double, vp, vp, P(i64)]
     lib.da_chain_poll.argtypes = [vp, C.c_uint64]
@@ -336,6 +337,28 @@ class Context:
     self._rows[side] = (out, le, lo)           # match_begin recognises these rows and skips their upload
     return [out[0, :le]] + [out[k, :lo] for k in range(1, 5)]      # row views of one buffer
 
+  def pair_stage(self, mode: int = MATCH_HASHED):
+    """The device stage of one pair of a batch in ONE native call (da_pair_stage): features of both resident PCM sides,
+    matching, and the chain DP enqueued.  Returns (video rows, audio rows, number of matches, chain ticket); the rows are the
+    lists features_resident() would return.  The interpreter lock is free for the other threads of a pipeline from the
+    first kernel to the last."""
+    outs, lens = [], []
+    for side in (SIDE_VIDEO, SIDE_AUDIO):
+      le = ((self._n[side] // 105) + 1) // 2
+      self._rows.pop(side, None)
+      outs.append(self._recycled((5, max(le, 1)), np.float32))
+      lens.append((C.c_int64 * 2)())
+    n = C.c_int64(0); t = C.c_uint64(0)
+    self._check(self._lib.da_pair_stage(self._h, _ptr(outs[0]), outs[0].shape[1], _ptr(outs[1]), outs[1].shape[1], mode,
+                                        lens[0], lens[1], C.byref(n), C.byref(t)))
+    rows = []
+    for side, out, ln in zip((SIDE_VIDEO, SIDE_AUDIO), outs, lens):
+      self._inflight.pop(side, None)
+      self._rows[side] = (out, ln[0], ln[1])
+      rows.append([out[0, :ln[0]]] + [out[k, :ln[1]] for k in range(1, 5)])
+    self._pending_rows = None
+    return rows[0], rows[1], n.value, t.value
+
   def _recycled(self, shape, dtype):
     """A page-locked result buffer of this shape that nobody holds any more, else a new one.  The pool keeps the flat base
     arrays; what is handed out (and every row view cut from it) has that base as its numpy `base`, so CPython's reference
@@ -382,8 +405,9 @@ class Context:
       return None
     out, le, lo = held
     for k, f in enumerate(feats):
-      if not isinstance(f, np.ndarray) or f.base is not out or f.dtype != np.float32 or len(f) != (le if k == 0 else lo) \
-         or f.ctypes.data != out[k].ctypes.data:
+      # (a row view's `base` is the pooled flat buffer `out` itself is a view of: numpy collapses view chains)
+      if not isinstance(f, np.ndarray) or (f.base is not out and f.base is not out.base) or f.dtype != np.float32 \
+         or len(f) != (le if k == 0 else lo) or f.ctypes.data != out[k].ctypes.data:
         return None
     return out, (C.c_int64 * 2)(le, lo)
 

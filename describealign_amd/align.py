@@ -489,6 +489,9 @@ def align_tiled(video_features, audio_desc_features, video_energy, audio_desc_en
   return out
 
 
+RESIDENT_PCM = object()    # what a pipeline job returns when the pair's PCM is resident on the context it was given (see AlignPipeline._gpu_stage)
+
+
 def _lp_worker(args):
   fx, fy = args
   t0 = time.perf_counter()
@@ -845,22 +848,36 @@ class AlignPipeline:
       self._pace(ctx)
       t0 = time.perf_counter()
       tm["pace_s"] = t0 - tp
-      vf, af = job(ctx) if callable(job) else job
-      tm["features_s"] = time.perf_counter() - t0
-      t1 = time.perf_counter()
-      ctx.match_begin(vf, af, self.mode)
-      ta = time.perf_counter()
-      self._collect_chains(ctx, block_above=self.max_chains - 1)
-      tb = time.perf_counter()
-      n = ctx.match_finish()
-      tc = time.perf_counter()
-      tm["device"] = ctx.stats()
-      tm["match_s"] = time.perf_counter() - t1
-      tm["match_begin_s"], tm["collect_under_gemm_s"], tm["match_finish_s"] = ta - t1, tb - ta, tc - tb
-      tm["n_matches"] = n
-      t2 = time.perf_counter()
-      ticket = ctx.chain_begin()
-      tm["chain_begin_s"] = time.perf_counter() - t2
+      got = job(ctx) if callable(job) else job
+      if got is RESIDENT_PCM:
+        # the pair's PCM is resident on this context: everything up to the enqueued chain DP in one native call.  Finished DPs
+        # of earlier pairs are handed on first (they used to be collected under the GEMM; one GEMM later costs nothing: the
+        # LP stage behind them takes 20-200 x a GEMM)
+        self._collect_chains(ctx, block_above=self.max_chains - 1)
+        tm["features_s"] = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        vf, af, n, ticket = ctx.pair_stage(self.mode)
+        tm["device"] = ctx.stats()
+        tm["match_s"] = time.perf_counter() - t1
+        tm["match_begin_s"], tm["collect_under_gemm_s"], tm["match_finish_s"], tm["chain_begin_s"] = 0.0, 0.0, tm["match_s"], 0.0
+        tm["n_matches"] = n
+      else:
+        vf, af = got
+        tm["features_s"] = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        ctx.match_begin(vf, af, self.mode)
+        ta = time.perf_counter()
+        self._collect_chains(ctx, block_above=self.max_chains - 1)
+        tb = time.perf_counter()
+        n = ctx.match_finish()
+        tc = time.perf_counter()
+        tm["device"] = ctx.stats()
+        tm["match_s"] = time.perf_counter() - t1
+        tm["match_begin_s"], tm["collect_under_gemm_s"], tm["match_finish_s"] = ta - t1, tb - ta, tc - tb
+        tm["n_matches"] = n
+        t2 = time.perf_counter()
+        ticket = ctx.chain_begin()
+        tm["chain_begin_s"] = time.perf_counter() - t2
       tm["t_gpu_stage_end"] = time.perf_counter()
       self._chains.setdefault(id(ctx), []).append((ticket, vf, af, tm, fname, done, time.perf_counter()))
     except BaseException as e:

@@ -150,7 +150,7 @@ struct da_ctx {
   bool fetch_ready = false;       // results of the last finished match are resident (keys0 / the result slot)
   bool rows_of_resident = false;  // vlist / res_lv / pend_nv still describe the RESIDENT match (no da_match_begin since its finish)
   int pend_mode = 0; int64_t pend_nv = 0; size_t pend_cap = 0;
-  hipEvent_t gemm_e0 = nullptr, gemm_e1 = nullptr, prep_e0 = nullptr, prep_e1 = nullptr;
+  hipEvent_t gemm_e0 = nullptr, gemm_e1 = nullptr, prep_e0 = nullptr, prep_e1 = nullptr, feat_e0 = nullptr, feat_e1 = nullptr;
   hipStream_t copy_stream = nullptr;
   // Page-locked words for the counts the host reads back (row counts, survivors, matches, rows / frames with a match).
   // Page-locked for two reasons: the copies are queued with hipMemcpyAsync and some error paths return before the stream is
@@ -322,6 +322,7 @@ int da_create(int device_id, int precision, da_ctx** out) {
   (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
   (void)hipEventCreate(&c->gemm_e0); (void)hipEventCreate(&c->gemm_e1);
   (void)hipEventCreate(&c->prep_e0); (void)hipEventCreate(&c->prep_e1);
+  (void)hipEventCreate(&c->feat_e0); (void)hipEventCreate(&c->feat_e1);
   if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DA_ERR_DEVICE; }
   if (hipHostMalloc((void**)&c->h_pin, 64, hipHostMallocDefault) != hipSuccess) { c->h_pin = nullptr; da_destroy(c); return DA_ERR_DEVICE; }
   FeatTables T; build_tables(T);
@@ -364,7 +365,7 @@ void da_destroy(da_ctx* c) {
   da::stretch_destroy(c->stretch); c->stretch = nullptr;
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
-  for (hipEvent_t e : {c->gemm_e0, c->gemm_e1, c->prep_e0, c->prep_e1}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {c->gemm_e0, c->gemm_e1, c->prep_e0, c->prep_e1, c->feat_e0, c->feat_e1}) if (e) (void)hipEventDestroy(e);
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -524,12 +525,13 @@ int da_pcm_adopt(da_ctx* c, int side, da_pcm_stream* st) {
 }
 
 // ------------------------------------------------------------------------------------- features
-int da_features_resident(da_ctx* c, int side, float* feats, int64_t row_stride, int64_t lengths[2]) {
-  if (!c) return DA_ERR_ARG;
+namespace {
+// the fused feature kernel + the download of its rows, enqueued on the context's stream; nothing is waited for.  e0 / e1: the
+// events that bracket the kernel (null: not recorded -- the caller brackets several launches itself)
+int features_enqueue(da_ctx* c, int side, float* feats, int64_t row_stride, int64_t lengths[2], hipEvent_t e0, hipEvent_t e1) {
   if (side < 0 || side > 1 || !lengths) return fail(c, DA_ERR_ARG, "da_features_resident: bad argument");
   Side& s = c->side[side];
   if (s.channels == 0) return fail(c, DA_ERR_STATE, "da_features_resident: no PCM uploaded for side %d", side);
-  HIP_TRY(c, hipSetDevice(c->device));
   const int64_t nb = s.n / 105;
   const int64_t le = (nb + 1) / 2, lo = s.n / 210;
   lengths[0] = le; lengths[1] = lo;
@@ -544,21 +546,34 @@ int da_features_resident(da_ctx* c, int side, float* feats, int64_t row_stride, 
   a.out = s.feat.as<float>(); a.row_stride = dstride;
   if (s.upload_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, s.up1, 0));       // the PCM copy of da_pcm_upload_async
   HIP_TRY(c, hipMemsetAsync(s.feat.p, 0, sizeof(float) * 5 * (size_t)dstride, c->stream));
-  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  if (e0) HIP_TRY(c, hipEventRecord(e0, c->stream));
   launch_features(a, s.channels, c->tables.as<FeatTables>(), c->stream);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  if (e1) HIP_TRY(c, hipEventRecord(e1, c->stream));
   if (feats && le > 0)
     HIP_TRY(c, hipMemcpy2DAsync(feats, sizeof(float) * row_stride, s.feat.p, sizeof(float) * dstride,
                                 sizeof(float) * le, 5, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-  c->st.features_ms = ms;
-  if (s.upload_pending) {                                  // the stream has been synchronised: the copy is done
+  return DA_OK;
+}
+// behind a synchronisation of the stream: the asynchronous PCM copy (if any) is done
+void features_landed(da_ctx* c, int side) {
+  Side& s = c->side[side];
+  if (s.upload_pending) {
     float up = 0.f; (void)hipEventElapsedTime(&up, s.up0, s.up1); c->st.h2d_ms = up;
     s.upload_pending = false;
   }
-  c->st.features_bytes = 2.0 * s.channels * (double)s.n + 5.0 * 4.0 * (double)lo;
+}
+}  // namespace
+
+int da_features_resident(da_ctx* c, int side, float* feats, int64_t row_stride, int64_t lengths[2]) {
+  if (!c) return DA_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = features_enqueue(c, side, feats, row_stride, lengths, c->ev0, c->ev1)) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  c->st.features_ms = ms;
+  features_landed(c, side);
+  c->st.features_bytes = 2.0 * c->side[side].channels * (double)c->side[side].n + 5.0 * 4.0 * (double)lengths[1];
   return DA_OK;
 }
 
@@ -1369,6 +1384,32 @@ int chain_begin_on(da_ctx* c, uint64_t* ticket, bool wide) {
 
 extern "C" int da_chain_begin(da_ctx* c, uint64_t* ticket) { return chain_begin_on(c, ticket, false); }
 extern "C" int da_chain_begin_exclusive(da_ctx* c, uint64_t* ticket) { return chain_begin_on(c, ticket, true); }
+
+// The whole device stage of one pair of a batch in ONE call: features of both resident PCM sides, preparation, similarity
+// GEMM, verification + sort, and the chain DP enqueued on its own stream.  What it saves over the five calls it replaces is
+// not device work but the caller between them: a Python thread that feeds the GPU from inside a busy pipeline re-acquires
+// the interpreter lock after every call, and the device waited 8 of every 51 ms for it (profiles/r05_trace_cfg1_gaps.json).
+extern "C" int da_pair_stage(da_ctx* c, float* v_rows, int64_t v_stride, float* a_rows, int64_t a_stride, int mode,
+                             int64_t v_lengths[2], int64_t a_lengths[2], int64_t* n_matches, uint64_t* ticket) {
+  if (!c) return DA_ERR_ARG;
+  if (!v_lengths || !a_lengths || !n_matches || !ticket) return fail(c, DA_ERR_ARG, "da_pair_stage: bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  // one event bracket around both feature kernels (the downloads of the video rows lie inside it: a few hundred microseconds
+  // of copy engine time beside the audio side's kernel)
+  if (int rc = features_enqueue(c, DA_SIDE_VIDEO, v_rows, v_stride, v_lengths, c->feat_e0, nullptr)) return rc;
+  if (int rc = features_enqueue(c, DA_SIDE_AUDIO, a_rows, a_stride, a_lengths, nullptr, c->feat_e1)) return rc;
+  // the rows stay on the device: da_match_begin's host pointers are only read when the rows are NOT resident
+  if (int rc = da_match_begin(c, v_rows ? v_rows : reinterpret_cast<float*>(c->h_pin), v_stride > 0 ? v_stride : v_lengths[0], v_lengths,
+                              a_rows ? a_rows : reinterpret_cast<float*>(c->h_pin), a_stride > 0 ? a_stride : a_lengths[0], a_lengths,
+                              mode | DA_MATCH_RESIDENT_ROWS, 0, -1)) return rc;
+  // da_match_begin has synchronised the stream (row counts): features and downloads are complete
+  { float ms = 0.f; (void)hipEventElapsedTime(&ms, c->feat_e0, c->feat_e1); c->st.features_ms = ms; }
+  features_landed(c, DA_SIDE_VIDEO); features_landed(c, DA_SIDE_AUDIO);
+  c->st.features_bytes = 2.0 * c->side[0].channels * (double)c->side[0].n + 5.0 * 4.0 * (double)v_lengths[1] +
+                         2.0 * c->side[1].channels * (double)c->side[1].n + 5.0 * 4.0 * (double)a_lengths[1];
+  if (int rc = da_match_finish(c, n_matches)) return rc;
+  return da_chain_begin(c, ticket);
+}
 
 extern "C" int da_chain_finish(da_ctx* c, uint64_t ticket, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
   if (!c) return DA_ERR_ARG;

@@ -199,6 +199,13 @@ int da_chain_begin(da_ctx* ctx, uint64_t* ticket);
  * Same ticket, same da_chain_finish / da_chain_poll. */
 int da_chain_begin_exclusive(da_ctx* ctx, uint64_t* ticket);
 int da_chain_finish(da_ctx* ctx, uint64_t ticket, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path);
+/* One pair of a directory batch (describealign.py:1077-1122, the loop body up to the path DP) in ONE call, for the thread that
+ * feeds a GPU: da_features_resident of both sides (PCM resident from da_pcm_upload / da_pcm_upload_async / da_pcm_adopt; the
+ * rows are downloaded into v_rows / a_rows, [5][stride] each, ideally page-locked -- or NULL: not downloaded), da_match_begin on
+ * those resident rows, da_match_finish, da_chain_begin.  Same results, same da_stats (features_ms / features_bytes: both sides
+ * together) as the five calls; *ticket goes to da_chain_poll / da_chain_finish.  mode as da_match. */
+int da_pair_stage(da_ctx* ctx, float* v_rows, int64_t v_stride, float* a_rows, int64_t a_stride, int mode,
+                  int64_t v_lengths[2], int64_t a_lengths[2], int64_t* n_matches, uint64_t* ticket);
 int da_chain_resident(da_ctx* ctx, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path);
 /* 1 when the DP behind `ticket` has completed (da_chain_finish will not block), 0 while it runs,
  * negative on error.  Lets the thread that feeds the context collect finished DPs between its own

@@ -1152,3 +1152,31 @@ def test_plain_bench_command_starts_its_own_ranks():
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "cfg-small"],
                          capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert res.returncode != 0 and "needs 8 visible GPUs" in res.stderr and not res.stdout.strip()
+
+
+def test_one_call_pair_stage_equals_the_five_calls(ctx_bf16, native):
+  """da_pair_stage (features of both resident sides + match_begin + match_finish + chain_begin in one native call, what the
+  GPU-feeding thread of a batch uses) against the separate calls: identical rows, matches, path; and a batch fed through it
+  equals sequential align()."""
+  from describealign_amd import align as A, synth
+  c = ctx_bf16
+  pair = cases.align_case("e600")
+  c.pcm_upload(0, pair.video); c.pcm_upload(1, pair.audio)
+  vf = [r.copy() for r in c.features_resident(0)]; af = [r.copy() for r in c.features_resident(1)]
+  mi, mv, mq = c.match(vf, af)
+  pi, pv = c.chain_resident()
+  vf2, af2, n, ticket = c.pair_stage()
+  assert n == len(mi)
+  for a_, b_ in zip(vf + af, list(vf2) + list(af2)):
+    assert a_.shape == b_.shape and np.array_equal(a_, b_)
+  gi, gv, gq = c.match_fetch(n)
+  assert np.array_equal(gi, mi) and np.array_equal(gv, mv) and np.array_equal(gq, mq)
+  qi, qv = c.chain_finish(ticket)
+  assert np.array_equal(qi, pi) and np.array_equal(qv, pv)
+  st = c.stats()
+  assert st["features_ms"] > 0 and st["features_bytes"] == pytest.approx(2.0 * (pair.video.size + pair.audio.size) + 20.0 * (len(vf[1]) + len(af[1])))
+  want = A.align(vf, af, vf[0], af[0], ctx=c)
+  with A.AlignPipeline(c, lp_workers=2) as pipe:
+    got = list(pipe.run([lambda ctx_: A.RESIDENT_PCM] * 3, expected=3))
+  for g in got:
+    assert np.array_equal(g[0], want[0]) and np.array_equal(g[1], want[1]) and g[2] == want[2] and np.array_equal(g[3], want[3])
