@@ -377,8 +377,17 @@ class Context:
     base = pinned_empty((count,), dtype)
     base = base.base if isinstance(base.base, np.ndarray) else base     # the flat array every view's `base` collapses to
     pool.append(base)
-    if len(pool) > 24:                           # shapes that no longer occur
-      pool[:] = [b for b in pool if sys.getrefcount(b) > 3][-16:] + [base]
+    # The pool has to hold every buffer a batch pipeline keeps in flight (window x 2 sides: ~100), or each pair allocates two
+    # page-locked buffers and frees two -- and hipHostFree waits for the whole device to go idle, with the runtime's lock held:
+    # the GPU-feeding thread's next launch then sits behind the chain DP in flight (measured: 40 % of a configs[1] batch's GEMMs
+    # started 13 ms late, profiles/r05_pipeline_stalls.txt).  So: nothing is dropped below a byte budget, and then only FREE
+    # buffers of shapes other than the one just asked for.
+    budget = int(os.environ.get("DALIGN_ROW_POOL_BYTES", str(8 << 30)))
+    if sum(b.nbytes for b in pool) > budget:
+      keep = [b for b in pool if sys.getrefcount(b) > 3 or b.size == count]
+      if sum(b.nbytes for b in keep) > budget:                           # still over: free buffers of this shape go as well
+        keep = [b for b in keep if sys.getrefcount(b) > 3 or b is base]
+      pool[:] = keep
     return base.reshape(shape)
 
   def features(self, pcm: np.ndarray, side: int = SIDE_VIDEO):

@@ -908,10 +908,12 @@ class AlignPipeline:
       waited = True
       self._collect_chains(ctx)                          # finished DPs are still handed on while waiting
       time.sleep(min(wait, 0.004))
-    if waited:
-      # host-bound: the GPU has time to spare, so the chain DPs still in flight (57 ms each) are let finish before the next
-      # similarity GEMM starts -- beside a DP the GEMM loses the CUs its columns sit on (a column wave's 152 registers and a
-      # GEMM wave's 428 do not fit one SIMD); when the GPU stage is the slower one nothing is waited for and they overlap
+    if waited and os.environ.get("DALIGN_CHAIN_CUS", "") == "0":
+      # (only without the chain DP's CU mask, i.e. DALIGN_CHAIN_CUS=0)  host-bound: the GPU has time to spare, so the chain DPs
+      # still in flight are let finish before the next similarity GEMM starts -- spread over the chip, a DP's column waves keep
+      # whole CUs from taking GEMM workgroups (+25 % GEMM time).  Confined to 8 CUs per XCD (the default) a DP costs the GEMM
+      # nothing, and waiting for it here only serialised the two: in a batch near the balance of GPU and LP stage (configs[1])
+      # the pacing waits a millisecond now and then, and each time the next pair's kernels started 6 ms late -- behind the DP.
       self._collect_chains(ctx, block_above=0)
     with self._lock:
       self._n_admitted += 1
@@ -931,8 +933,16 @@ class AlignPipeline:
     """Runs on the GPU thread after every pair: while no further pair is waiting for this context,
     wait for its outstanding chain DPs one at a time (otherwise they are collected under the next
     pair's GEMM) -- so a caller that stops submitting until results arrive cannot starve them."""
+    # (polling, not da_chain_finish's blocking wait: the next pair may be submitted a millisecond from now -- the caller
+    # submits one whenever a result is delivered -- and a thread blocked on a 6-50 ms DP would start that pair's kernels only
+    # behind it: a kernel trace of the configs[1] batch showed every pair's feature kernels 6 ms late, right behind the previous
+    # pair's DP, profiles/r05_trace_cfg1_gaps.json)
     while self._chains.get(id(ctx)) and self._queued.get(id(ctx), 0) <= 0:
-      self._collect_chains(ctx, block_above=len(self._chains[id(ctx)]) - 1)
+      queue = self._chains[id(ctx)]
+      if ctx.chain_done(queue[0][0]):
+        self._hand_off(ctx, *queue.pop(0))
+      else:
+        time.sleep(0.0003)
 
   def _hand_off(self, ctx, ticket, vf, af, tm, fname, done, t_begin):
     """Collect a finished chain DP (on the thread that owns the context) and pass the pair on; the copy into

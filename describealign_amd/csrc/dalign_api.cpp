@@ -123,6 +123,14 @@ double now_ms() {
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+struct DbgTimes {
+  bool on; double t0, last; const char* who;
+  explicit DbgTimes(const char* w) : on(std::getenv("DALIGN_DEBUG_TIMES") != nullptr), t0(now_ms()), last(t0), who(w) {}
+  void at(const char* what) { if (on) { const double t = now_ms(); std::fprintf(stderr, "[%s] %-28s +%8.3f ms\n", who, what, t - last); last = t; } }
+  ~DbgTimes() { if (on) std::fprintf(stderr, "[%s] total %8.3f ms (entered at %.3f ms)\n", who, now_ms() - t0, std::fmod(t0, 1e6)); }
+};
+
+
 }  // namespace
 
 struct da_ctx {
@@ -738,9 +746,11 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
   const int mode = c->pend_mode; const int64_t n_v = c->pend_nv;
   unsigned long long n_surv = 0;
   size_t cap = c->pend_cap;
+  DbgTimes dbgf("match_finish");
   for (int attempt = 0; attempt < 3; ++attempt) {
     HIP_TRY(c, hipMemcpyAsync(c->h_pin + 2, d_cnt, sizeof n_surv, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dbgf.at("GEMM done (survivor count read)");
     n_surv = c->h_pin[2];
     float ms = 0.f; (void)hipEventElapsedTime(&ms, c->gemm_e0, c->gemm_e1); c->st.gemm_ms = ms;
     if (n_surv <= cap) break;
@@ -780,6 +790,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
       HIP_TRY(c, hipEventRecord(c->prep_e1, c->stream));
       HIP_TRY(c, hipMemcpyAsync(c->h_pin + 3, d_cnt + 1, sizeof n_match, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
+      dbgf.at("k_verify done (match count read)");
       n_match = c->h_pin[3];
       if (n_match <= mcap) break;
       if (attempt == 1) return fail(c, DA_ERR_DEVICE, "da_match: match list kept overflowing");
@@ -816,7 +827,9 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
     int32_t* n_used = reinterpret_cast<int32_t*>(c->h_pin + 5);   // ... and the video frames that have one: the DP's ranks
     if (int rc = enqueue_dense_ranks(c, sl, (int64_t)n_match, c->res_lv, n_used)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    dbgf.at("sort + counts enqueued");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dbgf.at("sort + counts done");
     n_rows = c->h_pin[4];
     sl.rows_hint = (int64_t)n_rows;
     sl.n_ranks = *n_used;
@@ -1084,13 +1097,6 @@ int chain_host(da_ctx* c, const int32_t* pi, const int32_t* pv, const double* pq
 // enqueue the device DP of slot `sl` (sorted keys / q resident).  The per-match ranks come either
 // from the video row list of the match (rank_from_vlist) or have been uploaded into sl.rank.
 // DALIGN_DEBUG_TIMES=1: wall-clock stamps of the host side of chain_enqueue on stderr (where does the calling thread wait?)
-struct DbgTimes {
-  bool on; double t0, last; const char* who;
-  explicit DbgTimes(const char* w) : on(std::getenv("DALIGN_DEBUG_TIMES") != nullptr), t0(now_ms()), last(t0), who(w) {}
-  void at(const char* what) { if (on) { const double t = now_ms(); std::fprintf(stderr, "[%s] %-28s +%8.3f ms\n", who, what, t - last); last = t; } }
-  ~DbgTimes() { if (on) std::fprintf(stderr, "[%s] total %8.3f ms\n", who, now_ms() - t0); }
-};
-
 int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist, bool wide = false) {
   DbgTimes dbg("chain_enqueue");
   const int64_t n = sl.n;
@@ -1394,6 +1400,7 @@ extern "C" int da_pair_stage(da_ctx* c, float* v_rows, int64_t v_stride, float* 
   if (!c) return DA_ERR_ARG;
   if (!v_lengths || !a_lengths || !n_matches || !ticket) return fail(c, DA_ERR_ARG, "da_pair_stage: bad argument");
   HIP_TRY(c, hipSetDevice(c->device));
+  DbgTimes dbg("pair_stage");
   // one event bracket around both feature kernels (the downloads of the video rows lie inside it: a few hundred microseconds
   // of copy engine time beside the audio side's kernel)
   if (int rc = features_enqueue(c, DA_SIDE_VIDEO, v_rows, v_stride, v_lengths, c->feat_e0, nullptr)) return rc;
@@ -1402,13 +1409,19 @@ extern "C" int da_pair_stage(da_ctx* c, float* v_rows, int64_t v_stride, float* 
   if (int rc = da_match_begin(c, v_rows ? v_rows : reinterpret_cast<float*>(c->h_pin), v_stride > 0 ? v_stride : v_lengths[0], v_lengths,
                               a_rows ? a_rows : reinterpret_cast<float*>(c->h_pin), a_stride > 0 ? a_stride : a_lengths[0], a_lengths,
                               mode | DA_MATCH_RESIDENT_ROWS, 0, -1)) return rc;
+  dbg.at("features enqueued + match_begin (sync on the row counts, GEMM launched)");
   // da_match_begin has synchronised the stream (row counts): features and downloads are complete
   { float ms = 0.f; (void)hipEventElapsedTime(&ms, c->feat_e0, c->feat_e1); c->st.features_ms = ms; }
   features_landed(c, DA_SIDE_VIDEO); features_landed(c, DA_SIDE_AUDIO);
   c->st.features_bytes = 2.0 * c->side[0].channels * (double)c->side[0].n + 5.0 * 4.0 * (double)v_lengths[1] +
                          2.0 * c->side[1].channels * (double)c->side[1].n + 5.0 * 4.0 * (double)a_lengths[1];
   if (int rc = da_match_finish(c, n_matches)) return rc;
-  return da_chain_begin(c, ticket);
+  dbg.at("match_finish");
+  if (dbg.on) std::fprintf(stderr, "[pair_stage] kernels: features %.3f prep %.3f gemm %.3f verify %.3f (k_verify %.3f) ms; result slot %d\n",
+                           c->st.features_ms, c->st.prep_ms, c->st.gemm_ms, c->st.verify_ms, c->st.verify_kernel_ms, c->res_slot);
+  const int rc = da_chain_begin(c, ticket);
+  dbg.at("chain_begin");
+  return rc;
 }
 
 extern "C" int da_chain_finish(da_ctx* c, uint64_t ticket, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {

@@ -35,6 +35,15 @@ def main():
   out = dict(trace=path, gemm_launches=len(gemms), gemm_ms_mean=round(sum(dur) / max(1, len(dur)) * 1e-6, 3),
              gap_ms_mean=round(sum(gaps) / n * 1e-6, 3), period_ms_mean=round((gemms[-1][0] - gemms[0][0]) / n * 1e-6, 3),
              busy_ms_per_gap_by_kernel={a: round(b / n * 1e-6, 3) for a, b in sorted(inside.items(), key=lambda x: -x[1])[:24]})
+  # the timeline of one typical gap (the median one): every kernel that overlaps it, times relative to the GEMM's end
+  order = sorted(range(len(gaps)), key=lambda t: gaps[t])
+  t = order[len(order) // 2]
+  e0, s1 = gemms[t][1], gemms[t + 1][0]
+  line = []
+  for s_, e_, n_ in rows:
+    if e_ > e0 and s_ < s1 and not n_.startswith("k_match_"):
+      line.append([round((s_ - e0) * 1e-3, 1), round((e_ - e0) * 1e-3, 1), n_[:60]])
+  out["median_gap_timeline_us"] = dict(gap_us=round((s1 - e0) * 1e-3, 1), kernels=line[:160])
   print(json.dumps(out, indent=1))
 
 
