@@ -158,7 +158,7 @@ struct da_ctx {
   bool fetch_ready = false;       // results of the last finished match are resident (keys0 / the result slot)
   bool rows_of_resident = false;  // vlist / res_lv / pend_nv still describe the RESIDENT match (no da_match_begin since its finish)
   int pend_mode = 0; int64_t pend_nv = 0; size_t pend_cap = 0;
-  hipEvent_t gemm_e0 = nullptr, gemm_e1 = nullptr, prep_e0 = nullptr, prep_e1 = nullptr, feat_e0 = nullptr, feat_e1 = nullptr;
+  hipEvent_t gemm_e0 = nullptr, gemm_e1 = nullptr, prep_e0 = nullptr, prep_e1 = nullptr, feat_e0 = nullptr, feat_e1 = nullptr, feat_e2 = nullptr, feat_e3 = nullptr;
   hipStream_t copy_stream = nullptr;
   // Page-locked words for the counts the host reads back (row counts, survivors, matches, rows / frames with a match).
   // Page-locked for two reasons: the copies are queued with hipMemcpyAsync and some error paths return before the stream is
@@ -330,7 +330,7 @@ int da_create(int device_id, int precision, da_ctx** out) {
   (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
   (void)hipEventCreate(&c->gemm_e0); (void)hipEventCreate(&c->gemm_e1);
   (void)hipEventCreate(&c->prep_e0); (void)hipEventCreate(&c->prep_e1);
-  (void)hipEventCreate(&c->feat_e0); (void)hipEventCreate(&c->feat_e1);
+  (void)hipEventCreate(&c->feat_e0); (void)hipEventCreate(&c->feat_e1); (void)hipEventCreate(&c->feat_e2); (void)hipEventCreate(&c->feat_e3);
   if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DA_ERR_DEVICE; }
   if (hipHostMalloc((void**)&c->h_pin, 64, hipHostMallocDefault) != hipSuccess) { c->h_pin = nullptr; da_destroy(c); return DA_ERR_DEVICE; }
   FeatTables T; build_tables(T);
@@ -373,7 +373,7 @@ void da_destroy(da_ctx* c) {
   da::stretch_destroy(c->stretch); c->stretch = nullptr;
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
-  for (hipEvent_t e : {c->gemm_e0, c->gemm_e1, c->prep_e0, c->prep_e1, c->feat_e0, c->feat_e1}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {c->gemm_e0, c->gemm_e1, c->prep_e0, c->prep_e1, c->feat_e0, c->feat_e1, c->feat_e2, c->feat_e3}) if (e) (void)hipEventDestroy(e);
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1401,17 +1401,16 @@ extern "C" int da_pair_stage(da_ctx* c, float* v_rows, int64_t v_stride, float* 
   if (!v_lengths || !a_lengths || !n_matches || !ticket) return fail(c, DA_ERR_ARG, "da_pair_stage: bad argument");
   HIP_TRY(c, hipSetDevice(c->device));
   DbgTimes dbg("pair_stage");
-  // one event bracket around both feature kernels (the downloads of the video rows lie inside it: a few hundred microseconds
-  // of copy engine time beside the audio side's kernel)
-  if (int rc = features_enqueue(c, DA_SIDE_VIDEO, v_rows, v_stride, v_lengths, c->feat_e0, nullptr)) return rc;
-  if (int rc = features_enqueue(c, DA_SIDE_AUDIO, a_rows, a_stride, a_lengths, nullptr, c->feat_e1)) return rc;
+  // each side's feature kernel in its own event bracket (the row downloads lie outside them)
+  if (int rc = features_enqueue(c, DA_SIDE_VIDEO, v_rows, v_stride, v_lengths, c->feat_e0, c->feat_e1)) return rc;
+  if (int rc = features_enqueue(c, DA_SIDE_AUDIO, a_rows, a_stride, a_lengths, c->feat_e2, c->feat_e3)) return rc;
   // the rows stay on the device: da_match_begin's host pointers are only read when the rows are NOT resident
   if (int rc = da_match_begin(c, v_rows ? v_rows : reinterpret_cast<float*>(c->h_pin), v_stride > 0 ? v_stride : v_lengths[0], v_lengths,
                               a_rows ? a_rows : reinterpret_cast<float*>(c->h_pin), a_stride > 0 ? a_stride : a_lengths[0], a_lengths,
                               mode | DA_MATCH_RESIDENT_ROWS, 0, -1)) return rc;
   dbg.at("features enqueued + match_begin (sync on the row counts, GEMM launched)");
   // da_match_begin has synchronised the stream (row counts): features and downloads are complete
-  { float ms = 0.f; (void)hipEventElapsedTime(&ms, c->feat_e0, c->feat_e1); c->st.features_ms = ms; }
+  { float m0 = 0.f, m1 = 0.f; (void)hipEventElapsedTime(&m0, c->feat_e0, c->feat_e1); (void)hipEventElapsedTime(&m1, c->feat_e2, c->feat_e3); c->st.features_ms = m0 + m1; }
   features_landed(c, DA_SIDE_VIDEO); features_landed(c, DA_SIDE_AUDIO);
   c->st.features_bytes = 2.0 * c->side[0].channels * (double)c->side[0].n + 5.0 * 4.0 * (double)v_lengths[1] +
                          2.0 * c->side[1].channels * (double)c->side[1].n + 5.0 * 4.0 * (double)a_lengths[1];
