@@ -62,7 +62,11 @@ struct PrepArgs {
 //   audio  [0..3] = features 3, 4, 0, 1   [4] = feature 2
 //   video  [0..3] = digits of 3, 4, 0, 1  [4..7] = their flags   [8] = digits of 2, [9] = its flags
 constexpr int kHashAudioWords = 8, kHashVideoWords = 16;
-__host__ __device__ inline int hash_slot(int j) { return j >= 3 ? j - 3 : (j < 2 ? j + 2 : 4); }   // word of feature j's digits (audio) / position among the first four (video); feature 2 -> 4 (audio), handled apart (video)
+__host__ __device__ inline int hash_slot(int j) { return j >= 3 ? j - 3 : (j < 2 ? j + 2 : 4); }   // word of feature j's digits in an AUDIO record: features 3, 4, 0, 1, 2
+// VIDEO record, in the order the vote reads it: [D3 D4 G3 G4 | D0 D1 G0 G1 | D2 G2 ...] (D digits, G the inverted probe-next flags):
+// the first 16 bytes decide "feature 3 or 4 hits", which fails for most pairs -- they never load the second 16 bytes
+__host__ __device__ inline int hash_vdigits(int j) { return j == 3 ? 0 : j == 4 ? 1 : j == 0 ? 4 : j == 1 ? 5 : 8; }
+__host__ __device__ inline int hash_vflags(int j) { return j == 3 ? 2 : j == 4 ? 3 : j == 0 ? 6 : j == 1 ? 7 : 9; }
 void launch_prep(const PrepArgs& a, const double* d_hann41n, hipStream_t s);
 
 // ---- similarity GEMM -----------------------------------------------------------------------

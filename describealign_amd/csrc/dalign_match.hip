@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
       a.nrm[j][i] = 1.0;
       if (a.is_video) {
         uint32_t* h = a.hash + i * kHashVideoWords;
-        h[j == 2 ? 8 : hash_slot(j)] = 0xFFFFFFFFu;            // never matches
-        h[j == 2 ? 9 : 4 + hash_slot(j)] = 0xFFFFFFFFu;
+        h[hash_vdigits(j)] = 0xFFFFFFFFu;            // never matches
+        h[hash_vflags(j)] = 0xFFFFFFFFu;
       } else {
         a.hash[i * kHashAudioWords + hash_slot(j)] = 0xFFFFFFFFu;
       }
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void k_prep_norm(PrepArgs a) {
   }
   if (a.is_video) {
     uint32_t* h = a.hash + i * kHashVideoWords;
-    h[j == 2 ? 8 : hash_slot(j)] = dig;
-    h[j == 2 ? 9 : 4 + hash_slot(j)] = ~flg;
+    h[hash_vdigits(j)] = dig;
+    h[hash_vflags(j)] = ~flg;
   } else {
     a.hash[i * kHashAudioWords + hash_slot(j)] = dig | 0x08888888u;      // guard bit per nibble: no borrows in the packed subtract
   }
@@ -827,17 +827,18 @@ void launch_corr(const CorrArgs& a, hipStream_t s) {
 // the two-feature alternative first rejects almost every survivor after 3-6 gathers instead of 9-15
 __device__ inline bool vote_pair(const VerifyArgs& a, int32_t i, int32_t v) {
   if (a.mode != 0) return true;
-  // three 16-byte loads from two cache lines decide almost every pair: features 3, 4, 0, 1 of the audio frame, the same
-  // features' digits and flags of the video frame
+  // the audio frame's features 3, 4, 0, 1 (16 bytes) and the first 16 bytes of the video frame's record decide "3 or 4": most
+  // pairs end here; the second 16 bytes (features 0, 1) and, for a tie, feature 2's two words follow only for the rest
   const uint4 A = *reinterpret_cast<const uint4*>(a.hash_a + (int64_t)i * kHashAudioWords);
-  const uint4 D = *reinterpret_cast<const uint4*>(a.hash_v + (int64_t)v * kHashVideoWords);
-  const uint4 G = *reinterpret_cast<const uint4*>(a.hash_v + (int64_t)v * kHashVideoWords + 4);
-  if (!digit_hit(A.x, D.x, G.x) && !digit_hit(A.y, D.y, G.y)) return false;       // neither feature 3 nor 4
-  const int h01 = (digit_hit(A.z, D.z, G.z) ? 1 : 0) + (digit_hit(A.w, D.w, G.w) ? 1 : 0);
+  const uint32_t* hv = a.hash_v + (int64_t)v * kHashVideoWords;
+  const uint4 P = *reinterpret_cast<const uint4*>(hv);
+  if (!digit_hit(A.x, P.x, P.z) && !digit_hit(A.y, P.y, P.w)) return false;       // neither feature 3 nor 4
+  const uint4 Q = *reinterpret_cast<const uint4*>(hv + 4);
+  const int h01 = (digit_hit(A.z, Q.x, Q.z) ? 1 : 0) + (digit_hit(A.w, Q.y, Q.w) ? 1 : 0);
   if (h01 == 0) return false;
   if (h01 < 2) {
     const uint32_t a2 = a.hash_a[(int64_t)i * kHashAudioWords + 4];
-    const uint2 v2 = *reinterpret_cast<const uint2*>(a.hash_v + (int64_t)v * kHashVideoWords + 8);
+    const uint2 v2 = *reinterpret_cast<const uint2*>(hv + 8);
     if (!digit_hit(a2, v2.x, v2.y)) return false;
   }
   return true;
