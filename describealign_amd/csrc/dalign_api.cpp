@@ -14,6 +14,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -99,6 +100,37 @@ struct HandoverBuf { DevBuf buf; unsigned launches = 0; };
 constexpr size_t kHandoverKeep = 3;
 constexpr size_t kHandoverKeepBytes = (size_t)64 << 30;
 
+// Page-locked staging for the host <-> device copies of a call whose caller hands in ordinary (pageable) memory (da_refine: the
+// scaled feature stacks of a worker process, the points coming back).  A copy straight from / to pageable memory makes the
+// runtime pin and unpin those pages around it -- page-table updates on the device that the dispatches of OTHER contexts wait
+// for: with four refine threads beside it, 40 % of the feeding thread's GEMMs started 5-15 ms late
+// (tests/gpu_probe_refine_beside.py, profiles/r05_pipeline_stalls.txt).  One block per context, grown by replacement; regions
+// are handed out by bumping an offset and all given back by reset() at the next call.
+struct PinArena {
+  char* base = nullptr; size_t cap = 0, used = 0;
+  std::vector<void*> retired;                     // superseded blocks: freed by release() (never in the steady state)
+  void reset() { used = 0; }
+  void* take(size_t bytes) {
+    const size_t at = (used + 255) & ~(size_t)255;
+    if (at + bytes > cap) {
+      const size_t want = std::max<size_t>((at + bytes) * 2, (size_t)1 << 20);
+      void* p = nullptr;
+      if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      if (base) { std::memcpy(p, base, used); retired.push_back(base); }      // regions already handed out stay valid in the OLD block
+      // (callers keep their pointers: the old block lives until release(); only new regions come from the new block)
+      base = static_cast<char*>(p); cap = want;
+    }
+    used = at + bytes;
+    return base + at;
+  }
+  void release() {
+    for (void* p : retired) (void)hipHostFree(p);
+    retired.clear();
+    if (base) (void)hipHostFree(base);
+    base = nullptr; cap = used = 0;
+  }
+};
+
 // ---- pass 2 on the host: points of the banded extension, state of the second DP
 struct BandPoint { double j; int32_t i; int32_t cl; double q; };
 struct DpEntry { double j; int32_t i; int32_t cl; double q; double cum; int32_t id; uint32_t gen; };
@@ -121,6 +153,20 @@ struct RefineScratch {
 double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// Wait for a stream by POLLING its completion (hipStreamQuery reads the signal in memory) with 50 us naps, instead of
+// hipStreamSynchronize's blocked wait, whose wake-up travels interrupt -> kernel worker -> this thread and arrived up to 13 ms
+// late on a host whose cores are busy with the LP workers of a batch (profiles/r05_pipeline_stalls.txt): the GPU-feeding thread
+// then launched everything behind that wait late.  DALIGN_BLOCKING_SYNC=1: the runtime's own wait.
+hipError_t stream_wait(hipStream_t s) {
+  static const bool blocking = std::getenv("DALIGN_BLOCKING_SYNC") != nullptr;
+  if (blocking) return hipStreamSynchronize(s);
+  for (;;) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e != hipErrorNotReady) return e;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
 }
 
 struct DbgTimes {
@@ -151,6 +197,7 @@ struct da_ctx {
   DevBuf pair_i, pair_v, pair_c;
   DevBuf ascaled, vscaled, band_y, band_q, band_part, band_tab, band_cl, band_keys, band_ids, band_head, band_out, band_tmp;
   RefineScratch refine;
+  PinArena pin;                   // page-locked staging of da_refine's copies
   bool match_ready = false;
   unsigned long long n_match_resident = 0;
   // state carried from da_match_begin to da_match_finish
@@ -376,6 +423,7 @@ void da_destroy(da_ctx* c) {
   for (hipEvent_t e : {c->gemm_e0, c->gemm_e1, c->prep_e0, c->prep_e1, c->feat_e0, c->feat_e1, c->feat_e2, c->feat_e3}) if (e) (void)hipEventDestroy(e);
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  c->pin.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -397,7 +445,7 @@ int da_pcm_upload(da_ctx* c, int side, const int16_t* pcm, int64_t n, int channe
   HIP_TRY(c, s.pcm.ensure(bytes + 64));
   const double t0 = now_ms();
   if (bytes) HIP_TRY(c, hipMemcpyAsync(s.pcm.p, pcm, bytes, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, stream_wait(c->stream));
   c->st.h2d_ms = now_ms() - t0;
   s.upload_pending = false;
   s.n = n; s.channels = channels; s.planar = planar ? 1 : 0;
@@ -483,7 +531,7 @@ int da_pcm_stream_piece(da_pcm_stream* st, const int16_t* frames, int64_t n_fram
     DevBuf bigger;
     STREAM_TRY(st, bigger.ensure((have + add) + (have + add) / 2 + 64));
     if (have) STREAM_TRY(st, hipMemcpyAsync(bigger.p, st->buf.p, have, hipMemcpyDeviceToDevice, st->q));
-    STREAM_TRY(st, hipStreamSynchronize(st->q));
+    STREAM_TRY(st, stream_wait(st->q));
     st->buf.release();
     st->buf = bigger;
   }
@@ -496,7 +544,7 @@ int da_pcm_stream_piece(da_pcm_stream* st, const int16_t* frames, int64_t n_fram
 int da_pcm_stream_sync(da_pcm_stream* st) {
   if (!st) return DA_ERR_ARG;
   STREAM_TRY(st, hipSetDevice(st->device));
-  STREAM_TRY(st, hipStreamSynchronize(st->q));
+  STREAM_TRY(st, stream_wait(st->q));
   return DA_OK;
 }
 
@@ -506,7 +554,7 @@ const char* da_pcm_stream_error(const da_pcm_stream* st) { return st ? st->err.c
 void da_pcm_stream_close(da_pcm_stream* st) {
   if (!st) return;
   (void)hipSetDevice(st->device);
-  if (st->q) { (void)hipStreamSynchronize(st->q); (void)hipStreamDestroy(st->q); }
+  if (st->q) { (void)stream_wait(st->q); (void)hipStreamDestroy(st->q); }
   for (hipEvent_t e : {st->t0, st->landed}) if (e) (void)hipEventDestroy(e);
   st->buf.release();
   delete st;
@@ -577,7 +625,7 @@ int da_features_resident(da_ctx* c, int side, float* feats, int64_t row_stride, 
   if (!c) return DA_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
   if (int rc = features_enqueue(c, side, feats, row_stride, lengths, c->ev0, c->ev1)) return rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, stream_wait(c->stream));
   float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
   c->st.features_ms = ms;
   features_landed(c, side);
@@ -699,7 +747,7 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
         return fail(c, DA_ERR_DEVICE, "da_match: row list compaction failed");
       int32_t* h_cnt = reinterpret_cast<int32_t*>(c->h_pin);
       HIP_TRY(c, hipMemcpyAsync(h_cnt, d_cnt32, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      HIP_TRY(c, stream_wait(c->stream));
       n_v = h_cnt[0]; n_a = h_cnt[2];
     }
   }
@@ -749,7 +797,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
   DbgTimes dbgf("match_finish");
   for (int attempt = 0; attempt < 3; ++attempt) {
     HIP_TRY(c, hipMemcpyAsync(c->h_pin + 2, d_cnt, sizeof n_surv, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, stream_wait(c->stream));
     dbgf.at("GEMM done (survivor count read)");
     n_surv = c->h_pin[2];
     float ms = 0.f; (void)hipEventElapsedTime(&ms, c->gemm_e0, c->gemm_e1); c->st.gemm_ms = ms;
@@ -789,7 +837,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
       HIP_TRY(c, hipGetLastError());
       HIP_TRY(c, hipEventRecord(c->prep_e1, c->stream));
       HIP_TRY(c, hipMemcpyAsync(c->h_pin + 3, d_cnt + 1, sizeof n_match, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      HIP_TRY(c, stream_wait(c->stream));
       dbgf.at("k_verify done (match count read)");
       n_match = c->h_pin[3];
       if (n_match <= mcap) break;
@@ -828,7 +876,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
     if (int rc = enqueue_dense_ranks(c, sl, (int64_t)n_match, c->res_lv, n_used)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     dbgf.at("sort + counts enqueued");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, stream_wait(c->stream));
     dbgf.at("sort + counts done");
     n_rows = c->h_pin[4];
     sl.rows_hint = (int64_t)n_rows;
@@ -875,7 +923,7 @@ extern "C" int da_match_fetch(da_ctx* c, int32_t* out_i, int32_t* out_v, double*
   HIP_TRY(c, hipMemcpyAsync(out_v, d_i + c->n_match_resident, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->copy_stream));
   if (c->res_slot < 0) return fail(c, DA_ERR_STATE, "da_match_fetch: no finished match is resident");
   HIP_TRY(c, hipMemcpyAsync(out_q, c->slots[c->res_slot]->q.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->copy_stream));
-  HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+  HIP_TRY(c, stream_wait(c->copy_stream));
   return DA_OK;
 }
 
@@ -891,7 +939,7 @@ extern "C" int da_match_export_device(da_ctx* c, uint64_t* d_keys, double* d_q, 
   ChainSlot& sl = *c->slots[c->res_slot];
   HIP_TRY(c, hipMemcpyAsync(d_keys, sl.keys.p, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(d_q, sl.q.p, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, stream_wait(c->stream));
   return DA_OK;
 }
 
@@ -940,7 +988,7 @@ extern "C" int da_match_import_commit(da_ctx* c, int64_t n) {
   HIP_TRY(c, hipMemcpyAsync(c->h_pin + 4, d_rows, sizeof n_rows, hipMemcpyDeviceToHost, c->stream));
   int32_t* n_used = reinterpret_cast<int32_t*>(c->h_pin + 5);
   if (int rc = enqueue_dense_ranks(c, sl, n, c->res_lv, n_used)) return rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, stream_wait(c->stream));
   n_rows = c->h_pin[4];
   sl.n = n; sl.n_ranks = *n_used; sl.state = 1;
   sl.rows_hint = (int64_t)n_rows;
@@ -972,8 +1020,8 @@ extern "C" int da_trim(da_ctx* c) {
   if (!c) return DA_ERR_ARG;
   if (c->match_pending) return fail(c, DA_ERR_STATE, "da_trim: a da_match_begin is in flight");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+  HIP_TRY(c, stream_wait(c->stream));
+  HIP_TRY(c, stream_wait(c->copy_stream));
   for (DevBuf* b : {&c->surv, &c->bfv, &c->bfa, &c->q0, &c->sort_tmp, &c->rowscratch, &c->rankmap, &c->band_y, &c->band_q, &c->band_part, &c->band_cl,
                     &c->band_keys, &c->band_ids, &c->band_head, &c->band_out, &c->band_tmp, &c->pair_i, &c->pair_v, &c->pair_c})
     b->release();
@@ -985,7 +1033,7 @@ extern "C" int da_trim(da_ctx* c) {
     HIP_TRY(c, c->keys0.ensure(sizeof(unsigned long long) * (size_t)n));
     launch_unpack_keys(c->slots[c->res_slot]->keys.as<unsigned long long>(), n, c->keys0.as<int32_t>(), c->keys0.as<int32_t>() + n, c->stream);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, stream_wait(c->stream));
   }
   for (HandoverBuf& h : c->handover_free) h.buf.release();
   c->handover_free.clear();
@@ -1010,7 +1058,7 @@ extern "C" int da_match_corr(da_ctx* c, const int32_t* pi, const int32_t* pv, in
   launch_corr(a, c->stream);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(corr, c->pair_c.p, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, stream_wait(c->stream));
   return DA_OK;
 }
 
@@ -1030,7 +1078,7 @@ extern "C" int da_match_dump_tile(da_ctx* c, int64_t video_tile, int64_t audio_t
   HIP_TRY(c, hipMemcpyAsync(acc, c->pair_c.p, sizeof(float) * 3 * 32 * 32, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(video_frames, c->pair_i.p, sizeof(int32_t) * 32, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(audio_frames, c->pair_i.as<int32_t>() + 32, sizeof(int32_t) * 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, stream_wait(c->stream));
   return DA_OK;
 }
 
@@ -1262,7 +1310,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist, bool wide = fa
 
 // wait for a slot's DP and hand the path out; frees the slot unless the caller's buffers were too small
 int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
-  HIP_TRY(c, hipStreamSynchronize(sl.run));
+  HIP_TRY(c, stream_wait(sl.run));
   float ms = 0.f; (void)hipEventElapsedTime(&ms, sl.e0, sl.e1); c->st.chain_ms = ms;
   give_back_handover(c, sl);
   if (std::getenv("DALIGN_DEBUG_STAMPS") && sl.mode == 0 && sl.n > 0) {   // diagnostic builds (-DDA_CHAIN_STAMPS) only
@@ -1317,9 +1365,15 @@ int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int
   if (L > 0) {
     if (!path_i || !path_v) return fail(c, DA_ERR_ARG, "da_chain: null output");
     const size_t nn = (size_t)std::max<int64_t>(1, sl.n);
-    HIP_TRY(c, hipMemcpyAsync(path_i, sl.out_iv.as<int32_t>(), sizeof(int32_t) * L, hipMemcpyDeviceToHost, sl.run));
-    HIP_TRY(c, hipMemcpyAsync(path_v, sl.out_iv.as<int32_t>() + nn, sizeof(int32_t) * L, hipMemcpyDeviceToHost, sl.run));
-    HIP_TRY(c, hipStreamSynchronize(sl.run));
+    // through page-locked staging (PinArena): the caller's arrays are ordinary memory
+    c->pin.reset();
+    int32_t* hi_ = static_cast<int32_t*>(c->pin.take(sizeof(int32_t) * L));
+    int32_t* hv_ = static_cast<int32_t*>(c->pin.take(sizeof(int32_t) * L));
+    if (!hi_ || !hv_) return fail(c, DA_ERR_DEVICE, "da_chain: no page-locked staging memory");
+    HIP_TRY(c, hipMemcpyAsync(hi_, sl.out_iv.as<int32_t>(), sizeof(int32_t) * L, hipMemcpyDeviceToHost, sl.run));
+    HIP_TRY(c, hipMemcpyAsync(hv_, sl.out_iv.as<int32_t>() + nn, sizeof(int32_t) * L, hipMemcpyDeviceToHost, sl.run));
+    HIP_TRY(c, stream_wait(sl.run));
+    std::memcpy(path_i, hi_, sizeof(int32_t) * L); std::memcpy(path_v, hv_, sizeof(int32_t) * L);
   }
   sl.state = 0;
   return DA_OK;
@@ -1356,8 +1410,8 @@ extern "C" int da_chain(da_ctx* c, const int32_t* pi, const int32_t* pv, const d
   sl.n = n; sl.n_ranks = nr;
   { int64_t rows = 0; for (int64_t k = 0; k < n; ++k) rows += (k == 0 || pi[k] != pi[k - 1]); sl.rows_hint = rows; }
   int rc = chain_enqueue(c, sl, false, true);
-  if (rc) { (void)hipStreamSynchronize(c->stream); sl.state = 0; return rc; }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));          // the host staging vectors go out of scope
+  if (rc) { (void)stream_wait(c->stream); sl.state = 0; return rc; }
+  HIP_TRY(c, stream_wait(c->stream));          // the host staging vectors go out of scope
   rc = chain_collect(c, sl, min_len, path_i, path_v, n_path);
   if (rc == DA_ERR_CAPACITY) sl.state = 0;              // one-shot call: nothing stays resident
   return rc;
@@ -1567,8 +1621,20 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
     return fail(c, DA_ERR_ARG, "da_refine: bad argument");
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, c->ascaled.ensure(sizeof(double) * 3 * La)); HIP_TRY(c, c->vscaled.ensure(sizeof(double) * 3 * Lv));
-  HIP_TRY(c, hipMemcpyAsync(c->ascaled.p, a_scaled, sizeof(double) * 3 * La, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->vscaled.p, v_scaled, sizeof(double) * 3 * Lv, hipMemcpyHostToDevice, c->stream));
+  // every copy of this call goes through page-locked staging (see PinArena)
+  c->pin.reset();
+  auto staged = [&](const void* src, size_t bytes) -> void* {
+    void* p = c->pin.take(bytes);
+    if (p && src) std::memcpy(p, src, bytes);
+    return p;
+  };
+  {
+    void* sa = staged(a_scaled, sizeof(double) * 3 * La);
+    void* sv = staged(v_scaled, sizeof(double) * 3 * Lv);
+    if (!sa || !sv) return fail(c, DA_ERR_DEVICE, "da_refine: no page-locked staging memory");
+    HIP_TRY(c, hipMemcpyAsync(c->ascaled.p, sa, sizeof(double) * 3 * La, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->vscaled.p, sv, sizeof(double) * 3 * Lv, hipMemcpyHostToDevice, c->stream));
+  }
   double a_max = -1e300, v_max = -1e300;                                  // (:908-909)
   for (int64_t i = 0; i < La; ++i) a_max = std::max(a_max, a_scaled[3 * i]);
   for (int64_t i = 0; i < Lv; ++i) v_max = std::max(v_max, v_scaled[3 * i]);
@@ -1594,15 +1660,18 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
   float ms = 0.f; double kernel_ms = 0.0;
   if (nj > 0) {
     for (int k = 0; k < nj; ++k) tab[k] = BandCluster{jobs[k].offset, jobs[k].slope, jobs[k].lo, jobs[k].hi, 0, jobs[k].refine ? 1 : 0, 0};
-    HIP_TRY(c, hipMemcpyAsync(c->band_tab.p, tab.data(), sizeof(BandCluster) * nj, hipMemcpyHostToDevice, c->stream));
+    void* stab = staged(tab.data(), sizeof(BandCluster) * nj);
+    const size_t n_part = (size_t)4 * kRefBlocks * nj;
+    double* part = static_cast<double*>(staged(nullptr, sizeof(double) * n_part));
+    if (!stab || !part) return fail(c, DA_ERR_DEVICE, "da_refine: no page-locked staging memory");
+    HIP_TRY(c, hipMemcpyAsync(c->band_tab.p, stab, sizeof(BandCluster) * nj, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, c->band_part.ensure(sizeof(double) * 4 * kRefBlocks * nj));
-    std::vector<double> part((size_t)4 * kRefBlocks * nj);
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     launch_band_refine_all(base, c->band_tab.as<BandCluster>(), nj, c->band_part.as<double>(), kRefBlocks, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(part.data(), c->band_part.p, sizeof(double) * part.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(part, c->band_part.p, sizeof(double) * n_part, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, stream_wait(c->stream));
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); kernel_ms += ms;
     for (int k = 0; k < nj; ++k) {
       Job& j = jobs[k];
@@ -1654,7 +1723,9 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
       return fail(c, DA_ERR_DEVICE, "da_refine: scratch sizing failed");
     size_t tb = std::max(t1, t2);
     HIP_TRY(c, c->band_tmp.ensure(tb + 256));
-    HIP_TRY(c, hipMemcpyAsync(c->band_tab.p, tab.data(), sizeof(BandCluster) * nk, hipMemcpyHostToDevice, c->stream));
+    void* stab2 = staged(tab.data(), sizeof(BandCluster) * std::max(1, nk));
+    if (!stab2) return fail(c, DA_ERR_DEVICE, "da_refine: no page-locked staging memory");
+    HIP_TRY(c, hipMemcpyAsync(c->band_tab.p, stab2, sizeof(BandCluster) * nk, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     launch_band_quality_all(base, c->band_tab.as<BandCluster>(), nk, n_all, c->band_y.as<double>(), c->band_q.as<double>(),
                             c->band_cl.as<int32_t>(), keys, ids, c->stream);
@@ -1669,23 +1740,26 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
     launch_band_gather(kept, d_cnt, c->band_y.as<double>(), c->band_q.as<double>(), c->band_cl.as<int32_t>(), keys, o_j, o_q, o_i, o_cl, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    int32_t n_kept = 0;
-    HIP_TRY(c, hipMemcpyAsync(&n_kept, d_cnt, sizeof n_kept, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int32_t* h_kept = reinterpret_cast<int32_t*>(c->h_pin + 6);
+    HIP_TRY(c, hipMemcpyAsync(h_kept, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, stream_wait(c->stream));
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); kernel_ms += ms;
+    const int32_t n_kept = *h_kept;
     total_points = n_kept;
-    std::vector<double>& hj = S.hj; std::vector<double>& hq = S.hq;
-    std::vector<int32_t>& hi_ = S.hi; std::vector<int32_t>& hcl = S.hcl;
-    hj.resize((size_t)n_kept); hq.resize((size_t)n_kept); hi_.resize((size_t)n_kept); hcl.resize((size_t)n_kept);
+    pts.resize((size_t)std::max(0, n_kept));
     if (n_kept > 0) {
-      HIP_TRY(c, hipMemcpyAsync(hj.data(), o_j, sizeof(double) * n_kept, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipMemcpyAsync(hq.data(), o_q, sizeof(double) * n_kept, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipMemcpyAsync(hi_.data(), o_i, sizeof(int32_t) * n_kept, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipMemcpyAsync(hcl.data(), o_cl, sizeof(int32_t) * n_kept, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      double* hj = static_cast<double*>(staged(nullptr, sizeof(double) * n_kept));
+      double* hq = static_cast<double*>(staged(nullptr, sizeof(double) * n_kept));
+      int32_t* hi_ = static_cast<int32_t*>(staged(nullptr, sizeof(int32_t) * n_kept));
+      int32_t* hcl = static_cast<int32_t*>(staged(nullptr, sizeof(int32_t) * n_kept));
+      if (!hj || !hq || !hi_ || !hcl) return fail(c, DA_ERR_DEVICE, "da_refine: no page-locked staging memory");
+      HIP_TRY(c, hipMemcpyAsync(hj, o_j, sizeof(double) * n_kept, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(hq, o_q, sizeof(double) * n_kept, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(hi_, o_i, sizeof(int32_t) * n_kept, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(hcl, o_cl, sizeof(int32_t) * n_kept, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, stream_wait(c->stream));
+      for (int32_t t = 0; t < n_kept; ++t) pts[t] = BandPoint{hj[t], hi_[t], tab[hcl[t]].pad, hq[t]};
     }
-    pts.resize((size_t)n_kept);
-    for (int32_t t = 0; t < n_kept; ++t) pts[t] = BandPoint{hj[t], hi_[t], tab[hcl[t]].pad, hq[t]};
   }
   c->st.refine_kernel_ms = kernel_ms;
   c->st.refine_points = (double)total_points;
@@ -1753,11 +1827,11 @@ extern "C" int da_replace_segments(da_ctx* c, uint16_t* video, int64_t n_video, 
   std::string err;
   const int rc = da::stretch_replace(c->stretch, c->stream, c->st_video.as<uint16_t>(), n_video, c->st_audio.as<uint16_t>(),
                                      n_audio, channels, audio_times, video_times, n_nodes, no_pitch_correction != 0, t, err);
-  if (rc) { (void)hipStreamSynchronize(c->stream); return fail(c, rc, "%s", err.c_str()); }
+  if (rc) { (void)stream_wait(c->stream); return fail(c, rc, "%s", err.c_str()); }
   stretch_stats(c, t);
   HIP_TRY(c, hipMemcpy2DAsync(video, sizeof(uint16_t) * n_video, c->st_video.p, sizeof(uint16_t) * vs, sizeof(uint16_t) * n_video,
                               channels, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, stream_wait(c->stream));
   return DA_OK;
 }
 
@@ -1788,7 +1862,7 @@ extern "C" int da_stretch_resident(da_ctx* c, const double* audio_times, const d
   da::StretchTimes t;
   rc = da::stretch_replace(c->stretch, c->stream, c->st_video.as<uint16_t>(), sv.n, c->st_audio.as<uint16_t>(), sa.n, C,
                            audio_times, video_times, n_nodes, no_pitch_correction != 0, t, err);
-  if (rc) { (void)hipStreamSynchronize(c->stream); return fail(c, rc, "%s", err.c_str()); }
+  if (rc) { (void)stream_wait(c->stream); return fail(c, rc, "%s", err.c_str()); }
   stretch_stats(c, t);
   float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.stretch_prepare_ms = ms;
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -1796,7 +1870,7 @@ extern "C" int da_stretch_resident(da_ctx* c, const double* audio_times, const d
   if (rc) return fail(c, rc, "%s", err.c_str());
   HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
   HIP_TRY(c, hipMemcpyAsync(out, c->st_out.p, sizeof(int16_t) * (size_t)sv.n * C, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, stream_wait(c->stream));
   (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.stretch_finish_ms = ms;
   return DA_OK;
 }
