@@ -344,6 +344,8 @@ class Context:
     first kernel to the last."""
     outs, lens = [], []
     for side in (SIDE_VIDEO, SIDE_AUDIO):
+      if side not in self._n:
+        raise RuntimeError(f"pair_stage: no PCM uploaded for side {side}")
       le = ((self._n[side] // 105) + 1) // 2
       self._rows.pop(side, None)
       outs.append(self._recycled((5, max(le, 1)), np.float32))

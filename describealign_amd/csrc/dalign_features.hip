@@ -252,10 +252,14 @@ __global__ __launch_bounds__(FeatCfg<C>::kThreads, DA_FEAT_MIN_WAVES) void k_fea
       for (int g = 0; g < 7; ++g) {
         const int gg = 7 * u + g;                 // group within the 70-sample item
         float bb = 0.f;
+#ifdef DA_DBG_FEAT_NOFIR       // ablation (profiles/r05_features_ablation.txt): the 15-tap low-pass for free -- the ceiling of an MFMA formulation of it
+        bb = M(5 + 5 * gg + 2) * T.w15[7];
+#else
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
           for (int i = 0; i < 5; ++i) bb = fmaf(T.w15[i + 5 * kk], M(5 + 5 * (gg + 1 - kk) + i), bb);
+#endif
         float be = 0.f;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
@@ -294,10 +298,14 @@ __global__ __launch_bounds__(FeatCfg<C>::kThreads, DA_FEAT_MIN_WAVES) void k_fea
     if (q >= 1 && q < Cfg::kNQ - 1 && Q >= 0 && Q < nq_band) {
       const float* bp = s_bb1 + 7 * (q - 1);
       float bb2 = 0.f;
+#ifdef DA_DBG_FEAT_NOFIR
+      bb2 = bp[7 + 3] * T.w21[10];
+#else
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
         for (int i = 0; i < 7; ++i) bb2 = fmaf(T.w21[i + 7 * kk], bp[7 * (2 - kk) + i], bb2);
+#endif
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         const float d = bp[7 + i] - bb2;

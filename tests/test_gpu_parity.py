@@ -1180,3 +1180,37 @@ def test_one_call_pair_stage_equals_the_five_calls(ctx_bf16, native):
     got = list(pipe.run([lambda ctx_: A.RESIDENT_PCM] * 3, expected=3))
   for g in got:
     assert np.array_equal(g[0], want[0]) and np.array_equal(g[1], want[1]) and g[2] == want[2] and np.array_equal(g[3], want[3])
+
+
+def test_pair_stage_edge_cases(native):
+  """da_pair_stage on inputs the batch loop can meet: no PCM uploaded (error, not a crash), clips shorter than the 41-frame
+  window (no rows, no matches: an empty DP whose collection reports the reference's mismatch error once a minimum length is
+  asked for), and silence (every frame quiet: empty row lists)."""
+  c = native.Context(0, native.PREC_BF16)
+  try:
+    with pytest.raises(RuntimeError, match="no PCM"):
+      c.pair_stage()
+    rng = np.random.default_rng(3)
+    short = rng.integers(-3000, 3000, size=(1, 4410), dtype=np.int16)          # 0.1 s: 21 frames
+    c.pcm_upload(0, short); c.pcm_upload(1, short)
+    vf, af, n, t = c.pair_stage()
+    assert n == 0 and len(vf[0]) == 21 and len(af[1]) == 21
+    pi, pv = c.chain_finish(t)
+    assert len(pi) == 0 and len(pv) == 0
+    vf, af, n, t = c.pair_stage()
+    with pytest.raises(RuntimeError, match="mismatched"):
+      c.chain_finish(t, min_len=1050.0)
+    quiet = np.zeros((2, 44100 * 20), dtype=np.int16)
+    c.pcm_upload(0, quiet); c.pcm_upload(1, quiet)
+    vf, af, n, t = c.pair_stage()
+    assert n == 0 and float(np.max(vf[0])) == 0.0
+    assert len(c.chain_finish(t)[0]) == 0
+    # and a normal pair right after, on the same context
+    pair = cases.align_case("a40")
+    c.pcm_upload(0, pair.video); c.pcm_upload(1, pair.audio)
+    vf, af, n, t = c.pair_stage()
+    g = np.load(os.path.join(GOLD, "align_a40.npz"))
+    pi, pv = c.chain_finish(t)
+    assert n > 0 and len(pi) > 100
+  finally:
+    c.close()
