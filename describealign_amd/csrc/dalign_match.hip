@@ -728,7 +728,8 @@ void launch_match_f32(const MatchArgs& a, hipStream_t s) {
   MatchArgs b = a;
   const int64_t bx = (a.n_v + kFdRowsPerBlock - 1) / kFdRowsPerBlock;
   const int64_t atiles = (a.n_a + 31) / 32;
-  const int64_t tpb = stripe_tiles(atiles, 192, "DALIGN_F32_STRIPE_TILES");     // 192 x 16 KiB = 3 MB
+  // 96 x 16 KiB = 1.5 MB (round 5 sweep on the configs[1] pair, same box: 32 tiles 40.08 ms, 48-128: 39.90-39.94, 192: 40.25, 768: 40.93, 1536: 46.9)
+  const int64_t tpb = stripe_tiles(atiles, 96, "DALIGN_F32_STRIPE_TILES");
   b.audio_tiles_per_block = (int)tpb;
   hipLaunchKernelGGL(k_f32_video_frags, dim3((unsigned)b.bfv_tiles), dim3(64), 0, s, b);
   hipLaunchKernelGGL(k_f32_audio_frags, dim3((unsigned)b.bfa_tiles), dim3(64), 0, s, b);
@@ -739,10 +740,11 @@ void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   MatchArgs b = a;
   const int64_t bx = (a.n_v + kBdRowsPerBlock - 1) / kBdRowsPerBlock;
   const int64_t atiles = (a.n_a + 31) / 32;
-  // 384 tiles x 9 KiB = 3.5 MB.  With 6 700-tile stripes (62 MB) the workgroups of an XCD drift apart and 41 % of the stream
+  // (round 4: 384 tiles x 9 KiB = 3.5 MB.)  With 6 700-tile stripes (62 MB) the workgroups of an XCD drift apart and 41 % of the stream
   // misses L2 (FETCH_SIZE 89 GB per launch against 13 GB, +4.5 % time); 96 tiles: 27.9 GB, 192: 15.9, 384: 12.8, 768: 9.7,
   // 1536: 9.6, 3072: 20.4; kernel time equal within 0.5 % from 192 to 1536 (the MALL catches what a 3.5-7 MB stripe loses in L2).
-  const int64_t tpb = stripe_tiles(atiles, 384, "DALIGN_BF16_STRIPE_TILES");
+  // round 5 (2 h stereo pair, GEMM alone, same box): 64 tiles 120.4 ms, 96: 119.6, 128: 119.3, 192: 119.2, 256: 119.0, 384: 119.4 -> 256 = 2.3 MB
+  const int64_t tpb = stripe_tiles(atiles, 256, "DALIGN_BF16_STRIPE_TILES");
   b.audio_tiles_per_block = (int)tpb;
   hipLaunchKernelGGL(k_bf16_video_frags, dim3((unsigned)b.bfv_tiles), dim3(64), 0, s, b);
   hipLaunchKernelGGL(k_bf16_audio_frags, dim3((unsigned)b.bfa_tiles), dim3(64), 0, s, b);
