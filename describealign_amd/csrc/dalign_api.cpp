@@ -155,19 +155,6 @@ double now_ms() {
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-// Wait for a stream by POLLING its completion (hipStreamQuery reads the signal in memory) with 50 us naps, instead of
-// hipStreamSynchronize's blocked wait, whose wake-up travels interrupt -> kernel worker -> this thread and arrived up to 13 ms
-// late on a host whose cores are busy with the LP workers of a batch (profiles/r05_pipeline_stalls.txt): the GPU-feeding thread
-// then launched everything behind that wait late.  DALIGN_BLOCKING_SYNC=1: the runtime's own wait.
-hipError_t stream_wait(hipStream_t s) {
-  static const bool blocking = std::getenv("DALIGN_BLOCKING_SYNC") != nullptr;
-  if (blocking) return hipStreamSynchronize(s);
-  for (;;) {
-    const hipError_t e = hipStreamQuery(s);
-    if (e != hipErrorNotReady) return e;
-    std::this_thread::sleep_for(std::chrono::microseconds(50));     // (a tight spin is WORSE: 94 of 207 stages late -- the naps leave the core to the runtime's own threads)
-  }
-}
 
 struct DbgTimes {
   bool on; double t0, last; const char* who;
@@ -445,7 +432,7 @@ int da_pcm_upload(da_ctx* c, int side, const int16_t* pcm, int64_t n, int channe
   HIP_TRY(c, s.pcm.ensure(bytes + 64));
   const double t0 = now_ms();
   if (bytes) HIP_TRY(c, hipMemcpyAsync(s.pcm.p, pcm, bytes, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, stream_wait(c->stream));
+  HIP_TRY(c, da::stream_wait(c->stream));
   c->st.h2d_ms = now_ms() - t0;
   s.upload_pending = false;
   s.n = n; s.channels = channels; s.planar = planar ? 1 : 0;
@@ -531,7 +518,7 @@ int da_pcm_stream_piece(da_pcm_stream* st, const int16_t* frames, int64_t n_fram
     DevBuf bigger;
     STREAM_TRY(st, bigger.ensure((have + add) + (have + add) / 2 + 64));
     if (have) STREAM_TRY(st, hipMemcpyAsync(bigger.p, st->buf.p, have, hipMemcpyDeviceToDevice, st->q));
-    STREAM_TRY(st, stream_wait(st->q));
+    STREAM_TRY(st, da::stream_wait(st->q));
     st->buf.release();
     st->buf = bigger;
   }
@@ -544,7 +531,7 @@ int da_pcm_stream_piece(da_pcm_stream* st, const int16_t* frames, int64_t n_fram
 int da_pcm_stream_sync(da_pcm_stream* st) {
   if (!st) return DA_ERR_ARG;
   STREAM_TRY(st, hipSetDevice(st->device));
-  STREAM_TRY(st, stream_wait(st->q));
+  STREAM_TRY(st, da::stream_wait(st->q));
   return DA_OK;
 }
 
@@ -554,7 +541,7 @@ const char* da_pcm_stream_error(const da_pcm_stream* st) { return st ? st->err.c
 void da_pcm_stream_close(da_pcm_stream* st) {
   if (!st) return;
   (void)hipSetDevice(st->device);
-  if (st->q) { (void)stream_wait(st->q); (void)hipStreamDestroy(st->q); }
+  if (st->q) { (void)da::stream_wait(st->q); (void)hipStreamDestroy(st->q); }
   for (hipEvent_t e : {st->t0, st->landed}) if (e) (void)hipEventDestroy(e);
   st->buf.release();
   delete st;
@@ -625,7 +612,7 @@ int da_features_resident(da_ctx* c, int side, float* feats, int64_t row_stride, 
   if (!c) return DA_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
   if (int rc = features_enqueue(c, side, feats, row_stride, lengths, c->ev0, c->ev1)) return rc;
-  HIP_TRY(c, stream_wait(c->stream));
+  HIP_TRY(c, da::stream_wait(c->stream));
   float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
   c->st.features_ms = ms;
   features_landed(c, side);
@@ -747,7 +734,7 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
         return fail(c, DA_ERR_DEVICE, "da_match: row list compaction failed");
       int32_t* h_cnt = reinterpret_cast<int32_t*>(c->h_pin);
       HIP_TRY(c, hipMemcpyAsync(h_cnt, d_cnt32, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, stream_wait(c->stream));
+      HIP_TRY(c, da::stream_wait(c->stream));
       n_v = h_cnt[0]; n_a = h_cnt[2];
     }
   }
@@ -797,7 +784,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
   DbgTimes dbgf("match_finish");
   for (int attempt = 0; attempt < 3; ++attempt) {
     HIP_TRY(c, hipMemcpyAsync(c->h_pin + 2, d_cnt, sizeof n_surv, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, stream_wait(c->stream));
+    HIP_TRY(c, da::stream_wait(c->stream));
     dbgf.at("GEMM done (survivor count read)");
     n_surv = c->h_pin[2];
     float ms = 0.f; (void)hipEventElapsedTime(&ms, c->gemm_e0, c->gemm_e1); c->st.gemm_ms = ms;
@@ -837,7 +824,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
       HIP_TRY(c, hipGetLastError());
       HIP_TRY(c, hipEventRecord(c->prep_e1, c->stream));
       HIP_TRY(c, hipMemcpyAsync(c->h_pin + 3, d_cnt + 1, sizeof n_match, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, stream_wait(c->stream));
+      HIP_TRY(c, da::stream_wait(c->stream));
       dbgf.at("k_verify done (match count read)");
       n_match = c->h_pin[3];
       if (n_match <= mcap) break;
@@ -876,7 +863,7 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
     if (int rc = enqueue_dense_ranks(c, sl, (int64_t)n_match, c->res_lv, n_used)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     dbgf.at("sort + counts enqueued");
-    HIP_TRY(c, stream_wait(c->stream));
+    HIP_TRY(c, da::stream_wait(c->stream));
     dbgf.at("sort + counts done");
     n_rows = c->h_pin[4];
     sl.rows_hint = (int64_t)n_rows;
@@ -923,7 +910,7 @@ extern "C" int da_match_fetch(da_ctx* c, int32_t* out_i, int32_t* out_v, double*
   HIP_TRY(c, hipMemcpyAsync(out_v, d_i + c->n_match_resident, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->copy_stream));
   if (c->res_slot < 0) return fail(c, DA_ERR_STATE, "da_match_fetch: no finished match is resident");
   HIP_TRY(c, hipMemcpyAsync(out_q, c->slots[c->res_slot]->q.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->copy_stream));
-  HIP_TRY(c, stream_wait(c->copy_stream));
+  HIP_TRY(c, da::stream_wait(c->copy_stream));
   return DA_OK;
 }
 
@@ -939,7 +926,7 @@ extern "C" int da_match_export_device(da_ctx* c, uint64_t* d_keys, double* d_q, 
   ChainSlot& sl = *c->slots[c->res_slot];
   HIP_TRY(c, hipMemcpyAsync(d_keys, sl.keys.p, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(d_q, sl.q.p, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(c, stream_wait(c->stream));
+  HIP_TRY(c, da::stream_wait(c->stream));
   return DA_OK;
 }
 
@@ -988,7 +975,7 @@ extern "C" int da_match_import_commit(da_ctx* c, int64_t n) {
   HIP_TRY(c, hipMemcpyAsync(c->h_pin + 4, d_rows, sizeof n_rows, hipMemcpyDeviceToHost, c->stream));
   int32_t* n_used = reinterpret_cast<int32_t*>(c->h_pin + 5);
   if (int rc = enqueue_dense_ranks(c, sl, n, c->res_lv, n_used)) return rc;
-  HIP_TRY(c, stream_wait(c->stream));
+  HIP_TRY(c, da::stream_wait(c->stream));
   n_rows = c->h_pin[4];
   sl.n = n; sl.n_ranks = *n_used; sl.state = 1;
   sl.rows_hint = (int64_t)n_rows;
@@ -1020,8 +1007,8 @@ extern "C" int da_trim(da_ctx* c) {
   if (!c) return DA_ERR_ARG;
   if (c->match_pending) return fail(c, DA_ERR_STATE, "da_trim: a da_match_begin is in flight");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, stream_wait(c->stream));
-  HIP_TRY(c, stream_wait(c->copy_stream));
+  HIP_TRY(c, da::stream_wait(c->stream));
+  HIP_TRY(c, da::stream_wait(c->copy_stream));
   for (DevBuf* b : {&c->surv, &c->bfv, &c->bfa, &c->q0, &c->sort_tmp, &c->rowscratch, &c->rankmap, &c->band_y, &c->band_q, &c->band_part, &c->band_cl,
                     &c->band_keys, &c->band_ids, &c->band_head, &c->band_out, &c->band_tmp, &c->pair_i, &c->pair_v, &c->pair_c})
     b->release();
@@ -1033,7 +1020,7 @@ extern "C" int da_trim(da_ctx* c) {
     HIP_TRY(c, c->keys0.ensure(sizeof(unsigned long long) * (size_t)n));
     launch_unpack_keys(c->slots[c->res_slot]->keys.as<unsigned long long>(), n, c->keys0.as<int32_t>(), c->keys0.as<int32_t>() + n, c->stream);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, stream_wait(c->stream));
+    HIP_TRY(c, da::stream_wait(c->stream));
   }
   for (HandoverBuf& h : c->handover_free) h.buf.release();
   c->handover_free.clear();
@@ -1058,7 +1045,7 @@ extern "C" int da_match_corr(da_ctx* c, const int32_t* pi, const int32_t* pv, in
   launch_corr(a, c->stream);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(corr, c->pair_c.p, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, stream_wait(c->stream));
+  HIP_TRY(c, da::stream_wait(c->stream));
   return DA_OK;
 }
 
@@ -1078,7 +1065,7 @@ extern "C" int da_match_dump_tile(da_ctx* c, int64_t video_tile, int64_t audio_t
   HIP_TRY(c, hipMemcpyAsync(acc, c->pair_c.p, sizeof(float) * 3 * 32 * 32, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(video_frames, c->pair_i.p, sizeof(int32_t) * 32, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(audio_frames, c->pair_i.as<int32_t>() + 32, sizeof(int32_t) * 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, stream_wait(c->stream));
+  HIP_TRY(c, da::stream_wait(c->stream));
   return DA_OK;
 }
 
@@ -1310,7 +1297,7 @@ int chain_enqueue(da_ctx* c, ChainSlot& sl, bool rank_from_vlist, bool wide = fa
 
 // wait for a slot's DP and hand the path out; frees the slot unless the caller's buffers were too small
 int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {
-  HIP_TRY(c, stream_wait(sl.run));
+  HIP_TRY(c, da::stream_wait(sl.run));
   float ms = 0.f; (void)hipEventElapsedTime(&ms, sl.e0, sl.e1); c->st.chain_ms = ms;
   give_back_handover(c, sl);
   if (std::getenv("DALIGN_DEBUG_STAMPS") && sl.mode == 0 && sl.n > 0) {   // diagnostic builds (-DDA_CHAIN_STAMPS) only
@@ -1372,7 +1359,7 @@ int chain_collect(da_ctx* c, ChainSlot& sl, double min_len, int32_t* path_i, int
     if (!hi_ || !hv_) return fail(c, DA_ERR_DEVICE, "da_chain: no page-locked staging memory");
     HIP_TRY(c, hipMemcpyAsync(hi_, sl.out_iv.as<int32_t>(), sizeof(int32_t) * L, hipMemcpyDeviceToHost, sl.run));
     HIP_TRY(c, hipMemcpyAsync(hv_, sl.out_iv.as<int32_t>() + nn, sizeof(int32_t) * L, hipMemcpyDeviceToHost, sl.run));
-    HIP_TRY(c, stream_wait(sl.run));
+    HIP_TRY(c, da::stream_wait(sl.run));
     std::memcpy(path_i, hi_, sizeof(int32_t) * L); std::memcpy(path_v, hv_, sizeof(int32_t) * L);
   }
   sl.state = 0;
@@ -1410,8 +1397,8 @@ extern "C" int da_chain(da_ctx* c, const int32_t* pi, const int32_t* pv, const d
   sl.n = n; sl.n_ranks = nr;
   { int64_t rows = 0; for (int64_t k = 0; k < n; ++k) rows += (k == 0 || pi[k] != pi[k - 1]); sl.rows_hint = rows; }
   int rc = chain_enqueue(c, sl, false, true);
-  if (rc) { (void)stream_wait(c->stream); sl.state = 0; return rc; }
-  HIP_TRY(c, stream_wait(c->stream));          // the host staging vectors go out of scope
+  if (rc) { (void)da::stream_wait(c->stream); sl.state = 0; return rc; }
+  HIP_TRY(c, da::stream_wait(c->stream));          // the host staging vectors go out of scope
   rc = chain_collect(c, sl, min_len, path_i, path_v, n_path);
   if (rc == DA_ERR_CAPACITY) sl.state = 0;              // one-shot call: nothing stays resident
   return rc;
@@ -1671,7 +1658,7 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipMemcpyAsync(part, c->band_part.p, sizeof(double) * n_part, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, stream_wait(c->stream));
+    HIP_TRY(c, da::stream_wait(c->stream));
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); kernel_ms += ms;
     for (int k = 0; k < nj; ++k) {
       Job& j = jobs[k];
@@ -1742,7 +1729,7 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     int32_t* h_kept = reinterpret_cast<int32_t*>(c->h_pin + 6);
     HIP_TRY(c, hipMemcpyAsync(h_kept, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, stream_wait(c->stream));
+    HIP_TRY(c, da::stream_wait(c->stream));
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); kernel_ms += ms;
     const int32_t n_kept = *h_kept;
     total_points = n_kept;
@@ -1757,7 +1744,7 @@ extern "C" int da_refine(da_ctx* c, const double* a_scaled, int64_t La, const do
       HIP_TRY(c, hipMemcpyAsync(hq, o_q, sizeof(double) * n_kept, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipMemcpyAsync(hi_, o_i, sizeof(int32_t) * n_kept, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipMemcpyAsync(hcl, o_cl, sizeof(int32_t) * n_kept, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, stream_wait(c->stream));
+      HIP_TRY(c, da::stream_wait(c->stream));
       for (int32_t t = 0; t < n_kept; ++t) pts[t] = BandPoint{hj[t], hi_[t], tab[hcl[t]].pad, hq[t]};
     }
   }
@@ -1827,11 +1814,11 @@ extern "C" int da_replace_segments(da_ctx* c, uint16_t* video, int64_t n_video, 
   std::string err;
   const int rc = da::stretch_replace(c->stretch, c->stream, c->st_video.as<uint16_t>(), n_video, c->st_audio.as<uint16_t>(),
                                      n_audio, channels, audio_times, video_times, n_nodes, no_pitch_correction != 0, t, err);
-  if (rc) { (void)stream_wait(c->stream); return fail(c, rc, "%s", err.c_str()); }
+  if (rc) { (void)da::stream_wait(c->stream); return fail(c, rc, "%s", err.c_str()); }
   stretch_stats(c, t);
   HIP_TRY(c, hipMemcpy2DAsync(video, sizeof(uint16_t) * n_video, c->st_video.p, sizeof(uint16_t) * vs, sizeof(uint16_t) * n_video,
                               channels, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, stream_wait(c->stream));
+  HIP_TRY(c, da::stream_wait(c->stream));
   return DA_OK;
 }
 
@@ -1862,7 +1849,7 @@ extern "C" int da_stretch_resident(da_ctx* c, const double* audio_times, const d
   da::StretchTimes t;
   rc = da::stretch_replace(c->stretch, c->stream, c->st_video.as<uint16_t>(), sv.n, c->st_audio.as<uint16_t>(), sa.n, C,
                            audio_times, video_times, n_nodes, no_pitch_correction != 0, t, err);
-  if (rc) { (void)stream_wait(c->stream); return fail(c, rc, "%s", err.c_str()); }
+  if (rc) { (void)da::stream_wait(c->stream); return fail(c, rc, "%s", err.c_str()); }
   stretch_stats(c, t);
   float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.stretch_prepare_ms = ms;
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -1870,7 +1857,7 @@ extern "C" int da_stretch_resident(da_ctx* c, const double* audio_times, const d
   if (rc) return fail(c, rc, "%s", err.c_str());
   HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
   HIP_TRY(c, hipMemcpyAsync(out, c->st_out.p, sizeof(int16_t) * (size_t)sv.n * C, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, stream_wait(c->stream));
+  HIP_TRY(c, da::stream_wait(c->stream));
   (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); c->st.stretch_finish_ms = ms;
   return DA_OK;
 }

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <chrono>
+#include <cstdlib>
+#include <thread>
 
 namespace da {
 
@@ -230,5 +233,19 @@ size_t dense_ranks_temp_bytes(int64_t lv);
 int launch_dense_ranks(const unsigned long long* keys, int64_t n, int64_t lv, int32_t* used, int32_t* excl, void* temp, size_t temp_bytes, hipStream_t s);
 // distinct audio rows of a sorted key list, ADDED to *d_count (zero it first)
 void launch_count_rows(const unsigned long long* keys, int64_t n, unsigned long long* d_count, hipStream_t s);
+
+// Wait for a stream by POLLING its completion (hipStreamQuery reads the signal in memory) with 50 us naps, instead of
+// hipStreamSynchronize's blocked wait, whose wake-up travels interrupt -> kernel worker -> this thread and arrived up to 13 ms
+// late on a host whose cores are busy with the LP workers of a batch (profiles/r05_pipeline_stalls.txt): the GPU-feeding thread
+// then launched everything behind that wait late.  DALIGN_BLOCKING_SYNC=1: the runtime's own wait.
+inline hipError_t stream_wait(hipStream_t s) {
+  static const bool blocking = std::getenv("DALIGN_BLOCKING_SYNC") != nullptr;
+  if (blocking) return hipStreamSynchronize(s);
+  for (;;) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e != hipErrorNotReady) return e;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));     // (a tight spin is WORSE: 94 of 207 stages late -- the naps leave the core to the runtime's own threads)
+  }
+}
 
 }  // namespace da

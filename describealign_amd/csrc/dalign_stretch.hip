@@ -19,6 +19,7 @@
 //
 // All of it is HBM/latency-bound byte and fp64 work; nothing here is GEMM-shaped.
 #include "dalign_stretch.h"
+#include "dalign_common.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1002,7 +1003,7 @@ int ensure_hann(StretchState* s, hipStream_t stream, std::string& err) {
   for (int k = 0; k < 2 * kSW; ++k) w[k] = 0.5 + 0.5 * std::cos((double)k * step + (-pi));
   S_TRY(s->hann.ensure(sizeof(double) * 2 * kSW));
   S_TRY(hipMemcpyAsync(s->hann.p, w.data(), sizeof(double) * 2 * kSW, hipMemcpyHostToDevice, stream));
-  S_TRY(hipStreamSynchronize(stream));
+  S_TRY(da::stream_wait(stream));
   s->hann_ready = true;
   return 0;
 }
@@ -1029,7 +1030,7 @@ int stretch_prepare(StretchState* s, hipStream_t stream, const int16_t* d_pcm_vi
   S_TRY(hipGetLastError());
   std::vector<double> h(3 * blocks * 2);
   S_TRY(hipMemcpyAsync(h.data(), pv, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream));
-  S_TRY(hipStreamSynchronize(stream));
+  S_TRY(da::stream_wait(stream));
   auto spread = [&](const double* p, int64_t n, double* out) {           // low_ram_std (:1137-1139)
     double sum = 0, q[2] = {0, 0};
     for (int b = 0; b < blocks; ++b) { sum += p[3 * b]; q[0] += p[3 * b + 1]; q[1] += p[3 * b + 2]; }
@@ -1148,7 +1149,7 @@ int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, in
       }
       S_TRY(hipGetLastError());
       S_TRY(hipEventRecord(s->e1, stream));
-      S_TRY(hipStreamSynchronize(stream));
+      S_TRY(da::stream_wait(stream));
       tm.resample_ms = elapsed(s->e0, s->e1);
     }
   }
@@ -1209,7 +1210,7 @@ int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, in
                      s->eps.as<double>(), s->where.as<int16_t>(), s->loss.as<double>());
   S_TRY(hipGetLastError());
   S_TRY(hipEventRecord(s->e1, stream));
-  S_TRY(hipStreamSynchronize(stream));
+  S_TRY(da::stream_wait(stream));
   tm.correlate_ms = elapsed(s->e0, s->e1); tm.correlate_windows = windows; tm.correlate_bytes = cbytes;
 
   const size_t lds_bytes = sizeof(double) * (3 * kRow + 2 * kMaxLags) + sizeof(int32_t) * kMaxLags;
@@ -1222,7 +1223,7 @@ int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, in
   S_TRY(hipEventRecord(s->e1, stream));
   std::vector<int32_t> counts(2 * NS);
   S_TRY(hipMemcpyAsync(counts.data(), s->counts.p, sizeof(int32_t) * 2 * NS, hipMemcpyDeviceToHost, stream));
-  S_TRY(hipStreamSynchronize(stream));
+  S_TRY(da::stream_wait(stream));
   tm.viterbi_ms = elapsed(s->e0, s->e1);
   for (int k = 0; k < NS; ++k) {
     if (counts[2 * k + 1]) return sfail(err, DA_ERR_STATE, "replace: drift left the +/-%d sample window while back-tracking interval %d", kMaxDrift, k);
@@ -1253,7 +1254,7 @@ int stretch_replace(StretchState* s, hipStream_t stream, uint16_t* d_video_u, in
       S_TRY(hipMemcpyAsync(s->schedules[k].data(), s->sched.as<int64_t>() + 2 * segs[k].plan_off,
                            sizeof(int64_t) * 2 * (size_t)counts[2 * k], hipMemcpyDeviceToHost, stream));
   }
-  S_TRY(hipStreamSynchronize(stream));
+  S_TRY(da::stream_wait(stream));
   tm.splice_ms = elapsed(s->e0, s->e1); tm.splice_points = spoints;
   return 0;
 }
