@@ -11,6 +11,7 @@
 // (i, v, quality).
 #include "dalign_common.h"
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <string>
@@ -400,6 +401,14 @@ __global__ __launch_bounds__(64) void k_bf16_audio_frags(MatchArgs a) {
 // barriers.  A wave keeps kBdRowTiles x 32 video rows resident (216 AGPRs for six tiles) and streams 32-column
 // tiles of the audio operand: nine 1 KiB loads per tile, issued one whole tile (54 MFMAs) ahead into a second
 // register set, every fragment feeding six MFMAs.
+#ifdef DA_DBG_BF_CLOCK
+// Diagnostic build (make variant NAME=clock EXTRA=-DDA_DBG_BF_CLOCK): the SHIPPED kernel's own clock.  Every wave stamps s_memtime
+// (shader cycles) and s_memrealtime (100 MHz) around its whole tile loop and adds the two differences to these words, which
+// nothing else reads; launch_match_bf16 prints sum(cycles) / sum(ticks) x 100 MHz after the launch (MI355X_MICROARCH.md, DVFS
+// give-back item 6).  The stamps cost two scalar instructions per wave LIFETIME (a wave runs ~0.5 ms).
+__device__ unsigned long long g_bf_clock[2];
+#endif
+
 __global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
 #ifdef DA_DBG_BF_FAKEVOTE
   __shared__ unsigned long long s_surv[kBdWaves][kBdSurv + 64 + 1024];           // + 8 KiB of stand-in hash records per wave
@@ -417,6 +426,10 @@ __global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
   if (vt0 >= a.n_v || t_begin >= t_end) return;
   SurvSink sk{s_surv[wave], 0, kBdSurv};
   const int64_t vtile0 = vt0 >> 5;
+#ifdef DA_DBG_BF_CLOCK
+  unsigned long long clk_t0, clk_r0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t0), "=s"(clk_r0) :: "memory");
+#endif
   // The resident operand goes from memory straight into AGPRs: only MFMAs read it, and the VGPR half of
   // the register file belongs to the accumulators and the streamed fragments.
   bf16x8 A[kBdRowTiles][3][3];
@@ -495,6 +508,13 @@ __global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
     bf_emit(sk, h, vtile0 + kBdRowTiles - 1, codes, acol_prev);
   }
   sink_flush(sk, a, lane);
+#ifdef DA_DBG_BF_CLOCK
+  {
+    unsigned long long clk_t1, clk_r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t1), "=s"(clk_r1) :: "memory");
+    if (lane == 0) { atomicAdd(&g_bf_clock[0], clk_t1 - clk_t0); atomicAdd(&g_bf_clock[1], clk_r1 - clk_r0); }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -749,7 +769,18 @@ void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   b.audio_tiles_per_block = (int)tpb;
   hipLaunchKernelGGL(k_bf16_video_frags, dim3((unsigned)b.bfv_tiles), dim3(64), 0, s, b);
   hipLaunchKernelGGL(k_bf16_audio_frags, dim3((unsigned)b.bfa_tiles), dim3(64), 0, s, b);
+#ifdef DA_DBG_BF_CLOCK
+  { const unsigned long long z[2] = {0ull, 0ull}; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_bf_clock), z, sizeof z, 0, hipMemcpyHostToDevice, s); }
+#endif
   hipLaunchKernelGGL(k_match_bf16, dim3((unsigned)bx, (unsigned)((atiles + tpb - 1) / tpb)), dim3(64 * kBdWaves), 0, s, b);
+#ifdef DA_DBG_BF_CLOCK
+  {
+    unsigned long long h[2] = {0ull, 0ull};
+    if (hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bf_clock), sizeof h) == hipSuccess && h[1] > 0)
+      std::fprintf(stderr, "[k_match_bf16 clock] %.3f GHz in-kernel (sum of shader cycles %llu / sum of 100 MHz ticks %llu over all waves)\n",
+                   (double)h[0] / (double)h[1] * 0.1, h[0], h[1]);
+  }
+#endif
 }
 
 // diagnostics: the raw MFMA accumulators of ONE (32 video rows x 32 audio columns) tile, formed from the very fragment
