@@ -183,7 +183,10 @@ __device__ inline void sink_flush(SurvSink& sk, const MatchArgs& a, int lane) {
 #define DA_BD_ROWTILES 6
 #endif
 constexpr int kBdRowTiles = DA_BD_ROWTILES;       // even: the two accumulator sets alternate
-constexpr int kBdWaves = 4;
+#ifndef DA_BD_WAVES
+#define DA_BD_WAVES 4
+#endif
+constexpr int kBdWaves = DA_BD_WAVES;
 constexpr int kBdRows = 32 * kBdRowTiles;
 constexpr int kBdRowsPerBlock = kBdRows * kBdWaves;
 static_assert(kBdRowTiles % 2 == 0 && kBdRowTiles >= 4 && kBfVideoTileGroup % (kBdRowTiles * kBdWaves) == 0, "row tiling");
@@ -538,7 +541,10 @@ __global__ __launch_bounds__(64 * kBdWaves, 1) void k_match_bf16(MatchArgs a) {
 #define DA_FD_ROWTILES 4
 #endif
 constexpr int kFdRowTiles = DA_FD_ROWTILES;       // even: the two accumulator sets alternate; 4 x 64 = all 256 AGPRs
-constexpr int kFdWaves = 4;
+#ifndef DA_FD_WAVES
+#define DA_FD_WAVES 4
+#endif
+constexpr int kFdWaves = DA_FD_WAVES;
 constexpr int kFdRows = 32 * kFdRowTiles;
 constexpr int kFdRowsPerBlock = kFdRows * kFdWaves;
 constexpr int kFdTileBytes = 16 * 64 * 16;        // 16 KiB per 32 rows / columns
