@@ -279,7 +279,11 @@ hipError_t create_stream(hipStream_t* s, bool chain) {
   uint32_t mask[8];
   if (chain_cu_mask(mask)) {
     const char* m = std::getenv("DALIGN_MAIN_CUS");
-    if (chain) return hipExtStreamCreateWithCUMask(s, 8, mask);
+    if (chain) {
+      if (hipExtStreamCreateWithCUMask(s, 8, mask) == hipSuccess) return hipSuccess;
+      (void)hipGetLastError();                                   // a runtime that refuses the mask: an ordinary stream (slower GEMM beside a DP, same results)
+      return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    }
     if (m && std::strcmp(m, "rest") == 0) {
       for (uint32_t& w : mask) w = ~w;
       return hipExtStreamCreateWithCUMask(s, 8, mask);
