@@ -101,11 +101,11 @@ constexpr size_t kHandoverKeep = 3;
 constexpr size_t kHandoverKeepBytes = (size_t)64 << 30;
 
 // Page-locked staging for the host <-> device copies of a call whose caller hands in ordinary (pageable) memory (da_refine: the
-// scaled feature stacks of a worker process, the points coming back).  A copy straight from / to pageable memory makes the
-// runtime pin and unpin those pages around it -- page-table updates on the device that the dispatches of OTHER contexts wait
-// for: with four refine threads beside it, 40 % of the feeding thread's GEMMs started 5-15 ms late
-// (tests/gpu_probe_refine_beside.py, profiles/r05_pipeline_stalls.txt).  One block per context, grown by replacement; regions
-// are handed out by bumping an offset and all given back by reset() at the next call.
+// scaled feature stacks of a worker process, the points coming back; the path of a chain DP).  A copy straight from / to pageable
+// memory is staged by the runtime through the null stream, which waits for every BLOCKING stream of the device -- the CU-masked
+// streams of the chain DPs in flight -- and has the pages pinned and unpinned around it; through this arena the copies are plain
+// DMA on the context's own stream.  One block per context, grown by replacement; regions are handed out by bumping an offset
+// and all given back by reset() at the next call.
 struct PinArena {
   char* base = nullptr; size_t cap = 0, used = 0;
   std::vector<void*> retired;                     // superseded blocks: freed by release() (never in the steady state)
