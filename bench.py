@@ -305,7 +305,9 @@ class Bench:
                              "the same over every launch of the stream, lead-in and tail included: the figure a rocprofv3 --stats average of this command "
                              "supports (profiles/r05_bench_cfg2_bf16_kernel_stats.csv). "
                              "bf16: the kernel is bound by board power, not by its schedule -- a loop of nothing but its MFMAs on random operands holds "
-                             "1.86 GHz on 256 CUs (2.38 on one) = 0.60-0.66 of the 2.4 GHz dense peak (profiles/r04_issue_microbench.txt, DESIGN.md 4.3)"},
+                             "1.86-1.90 GHz on 256 CUs (2.38 on one) = 0.60-0.67 of the 2.4 GHz dense peak, the shipped kernel runs at 1.81-1.84 GHz in-kernel "
+                             "with its MFMAs 77 % of the wave cycles (profiles/r05_issue_microbench.txt, r05_pmc_mfma_bf16.json, DESIGN.md 4.3); the devices "
+                             "of a pool differ by ~10 % in this kernel's time (alone_launch_ms_same_device is the reference for THIS device)"},
         "feature_stage": {"bound": "hbm", "achieved": acc["feat_bytes"] / (acc["feat_ms"] * 1e-3) / 1e9 if acc.get("feat_ms") else 0.0,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_step": acc["feat_bytes"] / k,
                           "ms_per_step": acc["feat_ms"] / k},
@@ -382,9 +384,10 @@ class Bench:
                 "operand_streams_over_algorithmic": round(max(0.0, res["roofline"]["traffic"] - surv_bytes) / alg, 2) if alg > 0 else None}
             res["roofline"]["traffic_note"] = (
                 "requests of the L2s to the fabric (mostly served by the 256 MB MALL), per launch: the survivor records of the prefilter "
-                "(8 B each, 11 per verified match) and the two explicit operand streams where they miss an XCD's 4 MB L2 (the streamed "
-                "side once per XCD and stripe); traffic / launch time = ~0.3 TB/s of 8 TB/s -- the kernel is bound by the matrix cores and "
-                "board power, and the stripe length was chosen by a FETCH_SIZE sweep (profiles/r04_match_bf16_stripes.txt)")
+                "(8 B each, 11 per verified match) and the two explicit operand streams where they miss an XCD's 4 MB L2 (the resident "
+                "side once per stripe, the streamed side once per XCD and stripe); traffic / launch time = ~0.2-0.3 TB/s of 8 TB/s -- the kernel is "
+                "bound by the matrix cores and board power; voting inside the GEMM (11 -> 1.2 records per match) was measured and moves the "
+                "work without saving any (profiles/r05_vote_in_gemm.txt)")
             break
         except Exception:
           pass

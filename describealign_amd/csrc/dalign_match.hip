@@ -769,8 +769,10 @@ void launch_match_bf16(const MatchArgs& a, hipStream_t s) {
   // 384 tiles x 9 KiB = 3.5 MB.  With 6 700-tile stripes (62 MB) the workgroups of an XCD drift apart and 41 % of the stream
   // misses L2 (FETCH_SIZE 89 GB per launch against 13 GB, +4.5 % time); 96 tiles: 27.9 GB, 192: 15.9, 384: 12.8, 768: 9.7,
   // 1536: 9.6, 3072: 20.4; kernel time equal within 0.5 % from 192 to 1536 (the MALL catches what a 3.5-7 MB stripe loses in L2).
-  // round 5 (2 h stereo pair, GEMM alone, same box): 64 tiles 120.4 ms, 96: 119.6, 128: 119.3, 192: 119.2, 256: 119.0, 384: 119.4: flat within the
-  // run-to-run noise from 128 to 384, while the resident operand's re-reads (FETCH_SIZE) fall with the length -- 384 stays
+  // round 5 (2 h stereo pair, GEMM alone, same box): 64 tiles 120.4 ms, 96: 119.6, 128: 119.3, 192: 119.2, 256: 119.0, 384: 119.0-119.4,
+  // 768: 119.3-119.6, 1024: 119.7, 1536: 120.0 -- flat within 0.3 % from 128 to 768.  768 tiles (6.9 MB: beyond an XCD's L2) were
+  // tried for their halved re-reads of the resident operand: FETCH_SIZE of the stereo pair stayed at 15.2e6 KB (384: 14.8e6) -- what
+  // the resident side saves, the streamed side now misses -- so 384 stays.
   const int64_t tpb = stripe_tiles(atiles, 384, "DALIGN_BF16_STRIPE_TILES");
   b.audio_tiles_per_block = (int)tpb;
   hipLaunchKernelGGL(k_bf16_video_frags, dim3((unsigned)b.bfv_tiles), dim3(64), 0, s, b);
