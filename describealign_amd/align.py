@@ -747,6 +747,7 @@ class AlignPipeline:
     # not migrate between domains from pair to pair (round 4: the same binary ran the second DP 65 % slower on one host).
     self._old_affinity = None
     self._aux_cores, self._aux_next, self._pin_lock = [], 0, threading.Lock()
+    self._floating, self._pinned_tids = None, set()
     if pin and int(os.environ.get("DALIGN_PIN_MAIN", "1")):
       try:
         cpus = sorted(os.sched_getaffinity(0))
@@ -758,6 +759,13 @@ class AlignPipeline:
             os.sched_setaffinity(0, rest)
           if int(os.environ.get("DALIGN_PIN_THREADS", "1")):
             self._aux_cores = mine_aux
+            # everything else of this process -- the caller's thread, the HIP runtime's helper threads -- floats over the cores
+            # that are NEITHER an LP worker's NOR one of the pinned threads' (_float_others, called again once the contexts exist:
+            # a helper thread that the runtime starts from a pinned thread inherits that thread's single core)
+            n_pinned = len(self.gpu_ctxs) + max(1, int(refine_threads)) + 2
+            floating = set(rest) - set(mine_aux[:n_pinned])
+            if local_world == 1 and len(floating) >= 8:
+              self._floating = floating
       except Exception:
         self._old_affinity = None
     self.gpu_threads = [cf.ThreadPoolExecutor(max_workers=1, initializer=self._pin_thread) for _ in self.gpu_ctxs]
@@ -795,8 +803,26 @@ class AlignPipeline:
       self._aux_next += 1
     try:
       os.sched_setaffinity(threading.get_native_id(), {core})
+      with self._pin_lock:
+        self._pinned_tids.add(threading.get_native_id())
     except Exception:
       pass
+
+  def _float_others(self):
+    """Every thread of this process that is not one of the pinned pool threads goes onto the floating cores."""
+    if not self._floating:
+      return
+    try:
+      tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except Exception:
+      return
+    for tid in tids:
+      if tid in self._pinned_tids:
+        continue
+      try:
+        os.sched_setaffinity(tid, self._floating)
+      except Exception:
+        pass
 
   def _thread_ctx(self):
     c = getattr(self._local, "ctx", None)
@@ -812,6 +838,10 @@ class AlignPipeline:
     x = np.arange(40.0)
     list(self.pool.map(_lp_worker, [(x, x + 0.25 * np.sin(x))] * self.depth))
     list(self.refine_pool.map(lambda _: self._thread_ctx(), range(self.refine_pool._max_workers)))
+    for g in self.gpu_threads:                      # start (and pin) the GPU threads, then move every other thread off their cores
+      g.submit(lambda: None).result()
+    list(self.handoff_pool.map(lambda _: time.sleep(0.01), range(2)))
+    self._float_others()
 
   def __enter__(self):
     return self
@@ -879,6 +909,9 @@ class AlignPipeline:
         ticket = ctx.chain_begin()
         tm["chain_begin_s"] = time.perf_counter() - t2
       tm["t_gpu_stage_end"] = time.perf_counter()
+      self._stages_done = getattr(self, "_stages_done", 0) + 1
+      if self._stages_done in (1, 4, 16):             # helper threads the runtime started from this (pinned) thread meanwhile
+        self._float_others()
       self._chains.setdefault(id(ctx), []).append((ticket, vf, af, tm, fname, done, time.perf_counter()))
     except BaseException as e:
       with self._lock:

@@ -33,3 +33,21 @@ print("GEMM (events)   ", stat("gemm"))
 print("idle after stage", stat("idle_after"))
 late = [r for r in rows if r.get("gemm_wait", 0) - r.get("gemm", 0) > 3]
 print("stages whose GEMM started > 3 ms late:", len(late), "of", len(rows), "; by slot:", {s: sum(1 for r in late if r.get("slot") == s) for s in (0, 1, 2, 3)})
+
+# where the long stages lose their time: per stage the four waits of da_match_finish (stamps in order)
+import collections
+segs = collections.defaultdict(list)
+cur = []
+for line in open(sys.argv[1], errors="replace"):
+  m = re.search(r"\[match_finish\] (.*?)\s+\+\s*([\d.]+) ms", line)
+  if m:
+    cur.append((m.group(1).strip(), float(m.group(2))))
+  m = re.search(r"\[pair_stage\] total\s+([\d.]+) ms", line)
+  if m:
+    segs[float(m.group(1)) > 48.0].append(cur); cur = []
+for long_, rows_ in segs.items():
+  agg = collections.defaultdict(list)
+  for r in rows_[first if not long_ else 0:]:
+    for name, v in r:
+      agg[name].append(v)
+  print("LONG stages (> 48 ms):" if long_ else "normal stages:", len(rows_), {k: round(sum(v) / len(v), 2) for k, v in agg.items()})
