@@ -1214,3 +1214,50 @@ def test_pair_stage_edge_cases(native):
     assert n > 0 and len(pi) > 100
   finally:
     c.close()
+
+
+_SWITCH_WORKER = r"""
+import os, sys, json
+import numpy as np
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+
+def main():
+  import cases
+  from describealign_amd import _native as native, align as A
+  c = native.Context(0, native.PREC_BF16)
+  pair = cases.align_case("e180")
+  c.pcm_upload(0, pair.video); c.pcm_upload(1, pair.audio)
+  vf, af, n, t = c.pair_stage()
+  pi, pv = c.chain_finish(t)
+  x, y, sim, path, med = A.align(vf, af, vf[0], af[0], ctx=c)
+  with A.AlignPipeline(c, lp_workers=2) as pipe:
+    got = list(pipe.run([lambda ctx_: A.RESIDENT_PCM] * 2, expected=2))
+  same = all(np.array_equal(g[0], x) and np.array_equal(g[1], y) and np.array_equal(g[3], path) for g in got)
+  print(json.dumps(dict(n=int(n), path=int(len(pi)), x=[float(v) for v in x], y=[float(v) for v in y], sim=float(sim), rows=int(path.shape[0]), pipeline_same=bool(same),
+                        cols=int(c.stats()["chain_columns"]))))
+  c.close()
+
+if __name__ == "__main__":          # the pipeline's worker processes are spawned: they import this file
+  main()
+"""
+
+
+def test_runtime_switches_do_not_change_results(tmp_path):
+  """The round-5 mechanisms are about WHEN things run, never about what they compute: without the chain DP's CU mask
+  (DALIGN_CHAIN_CUS=0), with other masks, with the runtime's blocking wait instead of polling (DALIGN_BLOCKING_SYNC=1) and with
+  unpinned pipeline threads the same pair gives the same matches, path, nodes and pass-2 rows -- and the reference's nodes."""
+  import subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  script = tmp_path / "w.py"; script.write_text(_SWITCH_WORKER)
+  outs = []
+  for extra in ({}, {"DALIGN_CHAIN_CUS": "0"}, {"DALIGN_CHAIN_CUS": "2"}, {"DALIGN_BLOCKING_SYNC": "1"}, {"DALIGN_PIN_THREADS": "0", "DALIGN_PIN_WORKERS": "0"}):
+    env = dict(os.environ, **extra)
+    res = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, (extra, res.stderr[-2000:])
+    outs.append(json.loads(res.stdout.strip().splitlines()[-1]))
+  for o in outs[1:]:
+    assert o == outs[0], (o, outs[0])
+  assert outs[0]["pipeline_same"] and outs[0]["n"] > 0
+  g = np.load(os.path.join(GOLD, "align_e180.npz"))
+  assert np.max(np.abs(np.array(outs[0]["x"]) - g["x"])) < HOP_S and np.max(np.abs(np.array(outs[0]["y"]) - g["y"])) < HOP_S
