@@ -618,19 +618,69 @@ def _pin_worker(slot_counter, lock, first_slot, order):
     pass
 
 
+def cpu_quota():
+  """CPUs' worth of run time per second that this process's cgroup may use (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us` /
+  `cpu.cfs_period_us`; the tightest limit on the path from the process's cgroup to the root), or None without a limit.
+  The GPU box is a 2 x 64-core host, but its container runs under `cpu.max = 1600000 100000`: 16 CPUs' worth of time however
+  many of the 256 hardware threads it spreads over (profiles/r06_host_cpu_quota_probe.txt: a pure register loop on 32 pinned
+  processes already takes 1.8 x as long as on 16, on 128 10 x).  That quota -- not the L3 domains rounds 2-5 blamed -- is
+  what flattened every worker sweep: the host stage delivers  quota / (CPU-seconds per pair)  pairs per second."""
+  best = None
+
+  def take(q):
+    nonlocal best
+    if q is not None and q > 0:
+      best = q if best is None else min(best, q)
+
+  def v2(d):
+    try:
+      a, b = open(os.path.join(d, "cpu.max")).read().split()[:2]
+      return None if a == "max" else float(a) / float(b)
+    except Exception:
+      return None
+
+  def v1(d):
+    try:
+      q = float(open(os.path.join(d, "cpu.cfs_quota_us")).read())
+      per = float(open(os.path.join(d, "cpu.cfs_period_us")).read())
+      return None if q <= 0 else q / per
+    except Exception:
+      return None
+
+  rel2, rel1 = "", ""
+  try:
+    for line in open("/proc/self/cgroup"):
+      _, ctrl, path = line.strip().split(":", 2)
+      if ctrl == "":
+        rel2 = path
+      elif "cpu" in ctrl.split(","):
+        rel1 = path
+  except Exception:
+    pass
+  for root, rel, read in (("/sys/fs/cgroup", rel2, v2), ("/sys/fs/cgroup/cpu", rel1, v1), ("/sys/fs/cgroup/cpu,cpuacct", rel1, v1)):
+    parts = [p for p in rel.split("/") if p]
+    for k in range(len(parts), -1, -1):
+      take(read(os.path.join(root, *parts[:k])))
+  return best
+
+
 def default_worker_count(local_world: int = 1) -> int:
-  """LP worker processes per rank, from the host's cache topology.  One HiGHS solve of a long pair
-  wants a whole L3 slice: on the GPU box's host (2 x 64 cores, 16 L3 domains) the 2 h pairs' LP runs
-  at 2.5-2.7 solves/s whether 16, 24, 32 or 48 workers share the domains (time per solve grows in proportion:
-  6.3, 9.4, 13.9, 21.8 s -- profiles/r04_worker_sweep_cfg2.jsonl),
-  and the 22 min pairs' LP peaks between 32 and 48 workers (30-31 solves/s; 128 workers: 26).  So: 1.5
-  workers per L3 domain for a rank on its own (24 there), 3 per domain split between ranks that share
-  a host (48 there), never more than one per physical core."""
-  primary, _, domain = _cpu_topology()
-  n_l3 = max(1, len({domain[c] for c in primary}))
+  """LP worker processes per rank.  The host stage (pass 1 + HiGHS LP + clustering, one thread per pair) is bound by CPU TIME:
+  `budget` = the cgroup's CPU quota (cpu_quota) or, without one, the physical cores this process may use; a rank's share is
+  budget / ranks on the host.  Under a quota the share is oversubscribed by a quarter (the workers are the only consumers
+  that matter -- GPU feeder, refine and hand-off threads take ~0.3 CPU-seconds of a 2 h pair's 6.4 -- and a worker that waits
+  for its next pair leaves quota unused), on the GPU box 16 -> 20.  Without a quota: three workers per four cores of the
+  share, at most 64 per rank (every worker in flight pins a /dev/shm block of 10-70 MB and the pipeline window is two pairs
+  per worker).  Never fewer than 2, never more than one per physical core of the share."""
+  primary, _, _ = _cpu_topology()
   local_world = max(1, int(local_world))
-  want = (3 * n_l3 + 1) // 2 if local_world == 1 else max(2, (3 * n_l3) // local_world)
-  return int(max(2, min(want, max(1, len(primary) // local_world))))
+  cores = max(1, len(primary))
+  quota = cpu_quota()
+  if quota is not None and quota < cores:
+    want = int(np.ceil(1.25 * quota / local_world))
+  else:
+    want = min(64, (3 * cores) // (4 * local_world))
+  return int(max(2, min(want, max(1, cores // local_world))))
 
 
 # ---- worker-process side of the batch pipeline ---------------------------------------------------

@@ -669,19 +669,33 @@ def test_cli_accepts_the_reference_flags():
   assert "v.mp4" in flat and "a.mp3" in flat and "x_" in flat and True in flat
 
 
-def test_worker_count_follows_the_l3_topology(monkeypatch):
-  """1.5 LP workers per L3 domain for a rank on its own, 3 per domain split between ranks sharing the host,
-  never more than one per physical core: the GPU box's host (2 x 64 cores, 16 CCDs, SMT) gives 24 / 6."""
+def test_worker_count_follows_the_cpu_time_budget(monkeypatch, tmp_path):
+  """The host stage is bound by CPU time: under a cgroup quota (the GPU box: cpu.max = 16 CPUs on a 2 x 64-core host) a rank
+  gets a quarter more workers than its share of the quota; without a quota three per four physical cores, at most 64."""
   from describealign_amd import align as A
   primary = list(range(128)); secondary = list(range(128, 256))
   domain = {c: (c % 128) // 8 for c in range(256)}
   monkeypatch.setattr(A, "_cpu_topology", lambda cpus=None: (primary, secondary, domain))
-  assert A.default_worker_count(1) == 24
-  assert A.default_worker_count(8) == 6
-  assert A.default_worker_count(2) == 24
+  monkeypatch.setattr(A, "cpu_quota", lambda: 16.0)
+  assert A.default_worker_count(1) == 20
+  assert A.default_worker_count(8) == 3
+  assert A.default_worker_count(2) == 10
+  monkeypatch.setattr(A, "cpu_quota", lambda: None)
+  assert A.default_worker_count(1) == 64
+  assert A.default_worker_count(8) == 12
+  monkeypatch.setattr(A, "cpu_quota", lambda: 512.0)          # a quota above the core count is no limit
+  assert A.default_worker_count(1) == 64
   small = ([0, 1, 2, 3], [4, 5, 6, 7], {c: 0 for c in range(8)})
   monkeypatch.setattr(A, "_cpu_topology", lambda cpus=None: small)
-  assert A.default_worker_count(1) == 2 and A.default_worker_count(4) == 2
+  monkeypatch.setattr(A, "cpu_quota", lambda: None)
+  assert A.default_worker_count(1) == 3 and A.default_worker_count(4) == 2
+
+
+def test_cpu_quota_reads_the_cgroup_files():
+  """cpu_quota() returns None or a positive number of CPUs, whatever cgroup layout the test host has."""
+  from describealign_amd import align as A
+  q = A.cpu_quota()
+  assert q is None or q > 0
 
 
 def test_cpu_order_is_a_permutation_with_physical_cores_first():
