@@ -30,7 +30,7 @@ EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm
            "da_pcm_stream_open", "da_pcm_stream_piece", "da_pcm_stream_sync", "da_pcm_stream_frames", "da_pcm_stream_error", "da_pcm_adopt",
            "da_pcm_stream_close",
            "da_features_resident", "da_features", "da_match", "da_match_begin", "da_match_finish", "da_match_fetch",
-           "da_match_corr", "da_trim", "da_match_dump_tile", "da_match_export_device", "da_match_import_device", "da_match_import_reserve", "da_match_import_commit", "da_chain", "da_chain_begin", "da_chain_begin_exclusive", "da_pair_stage", "da_chain_finish", "da_chain_resident", "da_chain_poll",
+           "da_match_corr", "da_trim", "da_match_dump_tile", "da_match_export_device", "da_match_import_device", "da_match_import_reserve", "da_match_import_commit", "da_chain", "da_chain_begin", "da_chain_begin_exclusive", "da_pair_stage", "da_chain_finish", "da_chain_resident", "da_chain_poll", "da_chain_masked",
            "da_refine", "da_stats", "da_replace_segments", "da_stretch_resident", "da_stretch_schedule"]
 
 
@@ -113,6 +113,7 @@ def load():
     lib.da_chain_finish.argtypes = [vp, C.c_uint64, C.c_double, vp, vp, P(i64)]
     lib.da_chain_resident.argtypes = [vp, C.c_double, vp, vp, P(i64)]
     lib.da_chain_poll.argtypes = [vp, C.c_uint64]
+    lib.da_chain_masked.argtypes = [vp]
     lib.da_refine.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, vp, i32, C.c_double, vp, P(i64), P(i64)]
     lib.da_stats.argtypes = [vp, P(Stats)]
     lib.da_replace_segments.argtypes = [vp, vp, i64, vp, i64, i32, vp, vp, i32, i32]
@@ -373,24 +374,36 @@ class Context:
     import sys
     count = int(np.prod(shape))
     pool = self._pool
+    # any free buffer at least this large will do (a directory's files all differ in length: exact sizes would never be
+    # reused), the tightest first and none more than a quarter too large
+    best = None
     for base in pool:
-      if base.size == count and base.dtype == dtype and sys.getrefcount(base) == 3:    # the pool, `base`, getrefcount's argument
-        return base.reshape(shape)
-    base = pinned_empty((count,), dtype)
+      if base.dtype == dtype and count <= base.size <= count + count // 4 + 65536 and sys.getrefcount(base) == 3:    # the pool, `base`, getrefcount's argument
+        if best is None or base.size < best.size:
+          best = base
+    if best is not None:
+      return best[:count].reshape(shape)
+    # new buffers are rounded up (6 % + to a multiple of 64 Ki elements), so that the next file of about this length fits too
+    room = ((count + count // 16 + 65535) // 65536) * 65536
+    base = pinned_empty((room,), dtype)
     base = base.base if isinstance(base.base, np.ndarray) else base     # the flat array every view's `base` collapses to
     pool.append(base)
     # The pool has to hold every buffer a batch pipeline keeps in flight (window x 2 sides: ~100), or each pair allocates two
     # page-locked buffers and frees two -- and hipHostFree waits for the whole device to go idle, with the runtime's lock held:
     # the GPU-feeding thread's next launch then sits behind the chain DP in flight (measured: 40 % of a configs[1] batch's GEMMs
-    # started 13 ms late, profiles/r05_pipeline_stalls.txt).  So: nothing is dropped below a byte budget, and then only FREE
-    # buffers of shapes other than the one just asked for.
+    # started 13 ms late, profiles/r05_pipeline_stalls.txt).  So nothing is dropped below a byte budget; above it only as many
+    # FREE buffers go as it takes to get back under it (the ones that fit the current request worst first), never all at once.
     budget = int(os.environ.get("DALIGN_ROW_POOL_BYTES", str(8 << 30)))
-    if sum(b.nbytes for b in pool) > budget:
-      keep = [b for b in pool if sys.getrefcount(b) > 3 or b.size == count]
-      if sum(b.nbytes for b in keep) > budget:                           # still over: free buffers of this shape go as well
-        keep = [b for b in keep if sys.getrefcount(b) > 3 or b is base]
-      pool[:] = keep
-    return base.reshape(shape)
+    total = sum(b.nbytes for b in pool)
+    if total > budget:
+      free = [b for b in pool if b is not base and sys.getrefcount(b) == 3]     # the pool, `b`, getrefcount's argument
+      free.sort(key=lambda b: -abs(b.size - room))
+      for b in free:
+        if total <= budget:
+          break
+        pool[:] = [q for q in pool if q is not b]
+        total -= b.nbytes
+    return base[:count].reshape(shape)
 
   def features(self, pcm: np.ndarray, side: int = SIDE_VIDEO):
     """Upload + feature kernel: the five feature rows as a list of float32 arrays."""
@@ -539,6 +552,10 @@ class Context:
     if rc < 0:
       self._check(rc)
     return rc == 1
+
+  def chain_masked(self) -> bool:
+    """True when the streams of chain_begin()'s DPs are confined to their CU mask (see da_chain_masked)."""
+    return self._lib.da_chain_masked(self._h) == 1
 
   def chain_resident(self, min_len: float = 0.0):
     """Stage-2 chain DP on the matches still resident from the last match (describealign.py:654-698)."""

@@ -797,7 +797,7 @@ class AlignPipeline:
     # not migrate between domains from pair to pair (round 4: the same binary ran the second DP 65 % slower on one host).
     self._old_affinity = None
     self._aux_cores, self._aux_next, self._pin_lock = [], 0, threading.Lock()
-    self._floating, self._pinned_tids = None, set()
+    self._floating, self._pinned_tids, self._moved = None, set(), {}
     if pin and int(os.environ.get("DALIGN_PIN_MAIN", "1")):
       try:
         cpus = sorted(os.sched_getaffinity(0))
@@ -807,6 +807,7 @@ class AlignPipeline:
           self._old_affinity = set(cpus)
           if local_world == 1:
             os.sched_setaffinity(0, rest)
+            self._rest = set(rest)
           if int(os.environ.get("DALIGN_PIN_THREADS", "1")):
             self._aux_cores = mine_aux
             # everything else of this process -- the caller's thread, the HIP runtime's helper threads -- floats over the cores
@@ -851,12 +852,14 @@ class AlignPipeline:
         return
       core = self._aux_cores[self._aux_next]
       self._aux_next += 1
+    tid = threading.get_native_id()
+    with self._pin_lock:
+      self._pinned_tids.add(tid)          # BEFORE the mask changes: _float_others must never move a pinned thread back
     try:
-      os.sched_setaffinity(threading.get_native_id(), {core})
-      with self._pin_lock:
-        self._pinned_tids.add(threading.get_native_id())
+      os.sched_setaffinity(tid, {core})
     except Exception:
-      pass
+      with self._pin_lock:
+        self._pinned_tids.discard(tid)
 
   def _float_others(self):
     """Every thread of this process that is not one of the pinned pool threads goes onto the floating cores."""
@@ -867,9 +870,12 @@ class AlignPipeline:
     except Exception:
       return
     for tid in tids:
-      if tid in self._pinned_tids:
-        continue
+      with self._pin_lock:
+        if tid in self._pinned_tids:
+          continue
       try:
+        if tid not in self._moved:          # remembered once, restored by __exit__: the embedding application's threads are not ours to keep confined
+          self._moved[tid] = os.sched_getaffinity(tid)
         os.sched_setaffinity(tid, self._floating)
       except Exception:
         pass
@@ -899,6 +905,14 @@ class AlignPipeline:
   def __exit__(self, *exc):
     import shutil
     import sys
+    for tid, mask in list(getattr(self, "_moved", {}).items()):       # threads _float_others moved (runtime helpers, the caller's own)
+      if getattr(self, "_old_affinity", None) and mask == getattr(self, "_rest", None):
+        mask = self._old_affinity                                   # it had inherited this pipeline's own narrowing of the caller's mask
+      try:
+        os.sched_setaffinity(tid, mask)
+      except Exception:
+        pass                                                        # the thread has ended meanwhile
+    self._moved = {}
     if getattr(self, "_old_affinity", None):
       try:
         os.sched_setaffinity(0, self._old_affinity)
@@ -991,8 +1005,8 @@ class AlignPipeline:
       waited = True
       self._collect_chains(ctx)                          # finished DPs are still handed on while waiting
       time.sleep(min(wait, 0.004))
-    if waited and os.environ.get("DALIGN_CHAIN_CUS", "") == "0":
-      # (only without the chain DP's CU mask, i.e. DALIGN_CHAIN_CUS=0)  host-bound: the GPU has time to spare, so the chain DPs
+    if waited and not ctx.chain_masked():
+      # (only when the chain DPs' streams carry no CU mask: DALIGN_CHAIN_CUS = 0 / off, or a runtime that refused it)  host-bound: the GPU has time to spare, so the chain DPs
       # still in flight are let finish before the next similarity GEMM starts -- spread over the chip, a DP's column waves keep
       # whole CUs from taking GEMM workgroups (+25 % GEMM time).  Confined to 8 CUs per XCD (the default) a DP costs the GEMM
       # nothing, and waiting for it here only serialised the two: in a batch near the balance of GPU and LP stage (configs[1])

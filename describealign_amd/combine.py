@@ -423,24 +423,20 @@ def process_batch(todo, ctx, prepend="ad_", no_pitch_correction=False, output_di
       if stretch_audio:
         held.acquire()         # released when pair k's track has been written (below)
       fv, fa = decoded.pop(k)
+      from .align import RESIDENT_PCM
       if not stretch_audio:
         sv, sa = fv.result(), fa.result()
         c.pcm_adopt(_native.SIDE_VIDEO, sv)
         c.pcm_adopt(_native.SIDE_AUDIO, sa)
         with streams_lock:
           streams.extend((sv, sa))                 # they now hold the buffers of the pair before: the next files' targets
-        return c.features_resident(_native.SIDE_VIDEO), c.features_resident(_native.SIDE_AUDIO)
+        return RESIDENT_PCM                        # features + matching + chain enqueue: ONE native call (da_pair_stage)
       video_arr, audio_desc_arr = fv.result(), fa.result()
-      if stretch_audio:
-        kept[k] = (video_arr, audio_desc_arr)
+      kept[k] = (video_arr, audio_desc_arr)        # uploaded again to the second context when the pair's nodes arrive
       # both uploads are enqueued before the first feature kernel: the second copy runs under it
       c.pcm_upload_async(_native.SIDE_VIDEO, video_arr)
       c.pcm_upload_async(_native.SIDE_AUDIO, audio_desc_arr)
-      vf = c.features_resident(_native.SIDE_VIDEO)
-      af = c.features_resident(_native.SIDE_AUDIO)
-      if not stretch_audio:
-        pool.release(video_arr); pool.release(audio_desc_arr)
-      return vf, af
+      return RESIDENT_PCM
     return job
 
   quiet = contextlib.redirect_stdout(io.StringIO())          # align()'s progress lines would interleave

@@ -6,6 +6,7 @@
 #include "dalign_stretch.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -275,13 +276,17 @@ bool chain_cu_mask(uint32_t (&mask)[8]) {
   for (int b = 0; b < 8 * k; ++b) mask[b / 32] |= 1u << (b % 32);
   return true;
 }
+// 1 once a chain DP stream has been created WITH its CU mask, 0 once one had to be created without (no mask asked for, or
+// the runtime refused it), -1 before the first chain stream exists: what da_chain_masked reports
+std::atomic<int> g_chain_masked{-1};
 hipError_t create_stream(hipStream_t* s, bool chain) {
   uint32_t mask[8];
   if (chain_cu_mask(mask)) {
     const char* m = std::getenv("DALIGN_MAIN_CUS");
     if (chain) {
-      if (hipExtStreamCreateWithCUMask(s, 8, mask) == hipSuccess) return hipSuccess;
+      if (hipExtStreamCreateWithCUMask(s, 8, mask) == hipSuccess) { g_chain_masked.store(1); return hipSuccess; }
       (void)hipGetLastError();                                   // a runtime that refuses the mask: an ordinary stream (slower GEMM beside a DP, same results)
+      g_chain_masked.store(0);
       return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     }
     if (m && std::strcmp(m, "rest") == 0) {
@@ -289,6 +294,7 @@ hipError_t create_stream(hipStream_t* s, bool chain) {
       return hipExtStreamCreateWithCUMask(s, 8, mask);
     }
   }
+  if (chain) g_chain_masked.store(0);
   return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
@@ -1493,6 +1499,14 @@ extern "C" int da_chain_poll(da_ctx* c, uint64_t ticket) {
       return fail(c, DA_ERR_DEVICE, "da_chain_poll: %s", hipGetErrorString(e));
     }
   return fail(c, DA_ERR_STATE, "da_chain_poll: unknown ticket %llu", (unsigned long long)ticket);
+}
+
+extern "C" int da_chain_masked(const da_ctx* c) {
+  (void)c;
+  const int seen = g_chain_masked.load();
+  if (seen >= 0) return seen;
+  uint32_t mask[8];
+  return chain_cu_mask(mask) ? 1 : 0;          // no chain stream yet: what the environment asks for
 }
 
 extern "C" int da_chain_resident(da_ctx* c, double min_len, int32_t* path_i, int32_t* path_v, int64_t* n_path) {

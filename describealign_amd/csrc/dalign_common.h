@@ -234,17 +234,23 @@ int launch_dense_ranks(const unsigned long long* keys, int64_t n, int64_t lv, in
 // distinct audio rows of a sorted key list, ADDED to *d_count (zero it first)
 void launch_count_rows(const unsigned long long* keys, int64_t n, unsigned long long* d_count, hipStream_t s);
 
-// Wait for a stream by POLLING its completion (hipStreamQuery reads the signal in memory) with 50 us naps, instead of
-// hipStreamSynchronize's blocked wait, whose wake-up travels interrupt -> kernel worker -> this thread and arrived up to 13 ms
-// late on a host whose cores are busy with the LP workers of a batch (profiles/r05_pipeline_stalls.txt): the GPU-feeding thread
-// then launched everything behind that wait late.  DALIGN_BLOCKING_SYNC=1: the runtime's own wait.
+// Wait for a stream by POLLING its completion (hipStreamQuery reads the signal in memory) instead of hipStreamSynchronize's
+// blocked wait, whose wake-up travels interrupt -> kernel worker -> this thread and arrived up to 13 ms late on a host whose
+// cores are busy with the LP workers of a batch (profiles/r05_pipeline_stalls.txt): the GPU-feeding thread then launched
+// everything behind that wait late.  The naps back off: 50 us for the first 5 ms (the per-pair waits that evidence is about),
+// then 200 us, and from 50 ms on 1 ms -- a multi-second wait (an 8 h pair's GEMM, the stretch path, da_pcm_stream_close) makes
+// ~1 000 calls a second instead of 10-20 000, on cores it shares with the runtime's helper threads and (under a container's
+// CPU quota) with the LP workers.  DALIGN_BLOCKING_SYNC=1: the runtime's own wait.
 inline hipError_t stream_wait(hipStream_t s) {
   static const bool blocking = std::getenv("DALIGN_BLOCKING_SYNC") != nullptr;
   if (blocking) return hipStreamSynchronize(s);
+  const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     const hipError_t e = hipStreamQuery(s);
     if (e != hipErrorNotReady) return e;
-    std::this_thread::sleep_for(std::chrono::microseconds(50));     // (a tight spin is WORSE: 94 of 207 stages late -- the naps leave the core to the runtime's own threads)
+    const auto waited = std::chrono::steady_clock::now() - t0;
+    const int nap_us = waited < std::chrono::milliseconds(5) ? 50 : waited < std::chrono::milliseconds(50) ? 200 : 1000;
+    std::this_thread::sleep_for(std::chrono::microseconds(nap_us));     // (a tight spin is WORSE: 94 of 207 stages late -- the naps leave the core to the runtime's own threads)
   }
 }
 

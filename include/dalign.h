@@ -211,6 +211,12 @@ int da_chain_resident(da_ctx* ctx, double min_len, int32_t* path_i, int32_t* pat
  * negative on error.  Lets the thread that feeds the context collect finished DPs between its own
  * calls; a context is still used by one thread at a time. */
 int da_chain_poll(da_ctx* ctx, uint64_t ticket);
+/* 1 when the streams da_chain_begin's DPs run on are confined to their compute-unit mask (a few CUs per XCD, see
+ * da_chain_begin_exclusive), 0 when they are ordinary streams -- no mask asked for (DALIGN_CHAIN_CUS = 0 / off / out of
+ * range) or the runtime refused it.  A batch pipeline lets unmasked DPs finish before the next similarity GEMM (spread over
+ * the chip they cost it +25 %).  Masked streams are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags): work an
+ * embedding application puts on the legacy null stream serialises with the DPs in flight. */
+int da_chain_masked(const da_ctx* ctx);
 
 /* ---- stage 4: banded line extension + second DP ---------------------------------------------
  * describealign.py:895-993.  a_scaled [La][3], v_scaled [Lv][3] (the scaled feature stacks of

@@ -884,7 +884,33 @@ def test_directory_batch_is_pipelined_and_identical_to_sequential(ctx, tmp_path)
     os.makedirs(d / "out"); os.makedirs(d / "plots")
   seq = [combine.process_pair(v, a, alt, ctx, output_dir=str(seq_dir / "out"), alignment_dir=str(seq_dir / "plots"))
          for v, a, alt in todo]
-  bat = combine.process_batch(todo, ctx, output_dir=str(bat_dir / "out"), alignment_dir=str(bat_dir / "plots"), lp_workers=2)
+  # the shipped batch takes the fused device stage (da_pair_stage: one native call per pair), not the five separate calls
+  from describealign_amd import _native
+  calls = {"pair_stage": 0, "match_begin": 0}
+  real_stage, real_begin = _native.Context.pair_stage, _native.Context.match_begin
+
+  def counted_stage(self, *a, **k):
+    calls["pair_stage"] += 1
+    return real_stage(self, *a, **k)
+
+  def counted_begin(self, *a, **k):
+    calls["match_begin"] += 1
+    return real_begin(self, *a, **k)
+
+  _native.Context.pair_stage, _native.Context.match_begin = counted_stage, counted_begin
+  try:
+    bat = combine.process_batch(todo, ctx, output_dir=str(bat_dir / "out"), alignment_dir=str(bat_dir / "plots"), lp_workers=2)
+    st_dir = tmp_path / "st"
+    os.makedirs(st_dir / "out"); os.makedirs(st_dir / "plots")
+    stretched = combine.process_batch([(v, a, True) for v, a, _ in todo[:3]], ctx, output_dir=str(st_dir / "out"), alignment_dir=str(st_dir / "plots"), lp_workers=2,
+                                      stretch_audio=True)
+  finally:
+    _native.Context.pair_stage, _native.Context.match_begin = real_stage, real_begin
+  assert calls == {"pair_stage": 7, "match_begin": 0}, calls
+  assert len(stretched) == 3
+  for s_, b_ in zip(seq, stretched):               # --stretch_audio aligns the stereo decode of the same files: same jumps found
+    assert len(s_["audio_desc_times"]) == len(b_["audio_desc_times"])
+    assert np.max(np.abs(np.asarray(s_["video_times"]) - np.asarray(b_["video_times"]))) < 0.023
   assert len(bat) == len(seq) == 4
   for s_, b_ in zip(seq, bat):
     assert np.array_equal(s_["audio_desc_times"], b_["audio_desc_times"]) and np.array_equal(s_["video_times"], b_["video_times"])

@@ -758,8 +758,25 @@ def test_result_buffers_are_handed_out_again_once_dropped(monkeypatch):
   del keep
   d = _native.Context._recycled(h, (5, 100), np.float32)
   assert d.ctypes.data == addr and d.shape == (5, 100) and len(h._pool) == 3
-  e = _native.Context._recycled(h, (5, 64), np.float32)           # another shape: its own buffer
+  e = _native.Context._recycled(h, (5, 64), np.float32)           # every buffer is held: a new one
   assert e.shape == (5, 64) and len(h._pool) == 4
+  # a directory's files all differ in length: a free buffer that is large enough (and not wastefully so) is reused
+  e_addr = e.ctypes.data
+  del e
+  f = _native.Context._recycled(h, (5, 70), np.float32)
+  assert f.ctypes.data == e_addr and f.shape == (5, 70) and f.flags.c_contiguous and len(h._pool) == 4
+  g = _native.Context._recycled(h, (5, 400000), np.float32)       # far larger: its own buffer, rounded up for the next file of about this size
+  assert len(h._pool) == 5 and h._pool[-1].size >= 2000000 and h._pool[-1].size % 65536 == 0
+  g_addr = g.ctypes.data
+  del g
+  g2 = _native.Context._recycled(h, (5, 410000), np.float32)
+  assert g2.ctypes.data == g_addr and len(h._pool) == 5
+  # over the byte budget only as many FREE buffers go as it takes, never one that is in use
+  del f, g2
+  monkeypatch.setenv("DALIGN_ROW_POOL_BYTES", str(10 << 20))
+  big = _native.Context._recycled(h, (5, 600000), np.float32)     # 12 MB: over budget whatever is dropped; both free buffers go
+  held = {b.ctypes.data, c.ctypes.data, d.ctypes.data}
+  assert {q.ctypes.data for q in h._pool} == held | {big.ctypes.data}
 
 
 def test_command_lines_equal_what_the_reference_compiles():
