@@ -496,37 +496,52 @@ def _worker(gpu, indices, pairs, kwargs, precision, n_workers=1):
   ctx.close()
 
 
+_ABORT_HINT = "If not, press ctrl+c to kill this script."
+
+
+def _checkpoint(question, go_on, lead_blank=False):
+  """One of the reference's interactive stops (:1035-1040, :1058-1062): the question, how to abort, Enter to go on."""
+  lines = ([""] if lead_blank else []) + [question, _ABORT_HINT]
+  for line in lines:
+    print(line)
+  input(go_on)
+  print("")
+
+
+def _paired_inputs(video, audio, interactive):
+  """Both input paths resolved and paired (:1033-1046): [(video file, audio description file, video side is an audio file)].
+  Audio files on the video side are legal (--stretch_audio) but worth a question; unequal counts are an error."""
+  video_files, is_audio = get_sorted_filenames(video, VIDEO_EXTENSIONS, AUDIO_EXTENSIONS)
+  if interactive and any(is_audio):
+    _checkpoint("One or more audio files found in video input. Was this intentional?",
+                "If this was intended, press Enter to continue...", lead_blank=True)
+  audio_desc_files, _ = get_sorted_filenames(audio, AUDIO_EXTENSIONS)
+  counts = (len(video_files), len(audio_desc_files))
+  if counts[0] != counts[1]:
+    raise RuntimeError("Number of valid files in input paths are not the same.\n"
+                       f"The video path has {counts[0]} files\nThe audio path has {counts[1]} files")
+  return list(zip(video_files, audio_desc_files, is_audio))
+
+
+def _list_pairs(pairs, interactive):
+  """The pairing shown to the user, file names only, and the second stop (:1053-1062)."""
+  print("")
+  for video_file, audio_desc_file, _ in pairs:
+    print("\n".join(os.path.split(f)[1] for f in (video_file, audio_desc_file)) + "\n")
+  if interactive:
+    _checkpoint("Are the above input file pairings correct?", "If they are correct, press Enter to continue...")
+
+
 def combine(video, audio, stretch_audio=False, yes=False, prepend="ad_", no_pitch_correction=False,
             output_dir=default_output_dir, alignment_dir=default_alignment_dir, gpus=1, precision="f32", device=0):
   """Same signature as the reference's combine() (:1031-1032) plus gpus/precision/device."""
   from . import _native
-  video_files, has_audio_extensions = get_sorted_filenames(video, VIDEO_EXTENSIONS, AUDIO_EXTENSIONS)
-  if yes == False and sum(has_audio_extensions) > 0:
-    print("")
-    print("One or more audio files found in video input. Was this intentional?")
-    print("If not, press ctrl+c to kill this script.")
-    input("If this was intended, press Enter to continue...")
-    print("")
-  audio_desc_files, _ = get_sorted_filenames(audio, AUDIO_EXTENSIONS)
-  if len(video_files) != len(audio_desc_files):
-    raise RuntimeError("\n".join(["Number of valid files in input paths are not the same.",
-                                  f"The video path has {len(video_files)} files",
-                                  f"The audio path has {len(audio_desc_files)} files"]))
+  pairs = _paired_inputs(video, audio, interactive=not yes)
   print("")
   ensure_folders_exist([output_dir, alignment_dir])
-  print("")
-  for v, a in zip(video_files, audio_desc_files):
-    print(os.path.split(v)[1])
-    print(os.path.split(a)[1])
-    print("")
-  if yes == False:
-    print("Are the above input file pairings correct?")
-    print("If not, press ctrl+c to kill this script.")
-    input("If they are correct, press Enter to continue...")
-    print("")
+  _list_pairs(pairs, interactive=not yes)
   print(f"Processing files with describealign_amd v{__version__} (reproducing describealign v{REFERENCE_VERSION}):")
   prec = _native.PREC_F32 if precision == "f32" else _native.PREC_BF16
-  pairs = list(zip(video_files, audio_desc_files, has_audio_extensions))
   kwargs = dict(stretch_audio=stretch_audio, prepend=prepend, no_pitch_correction=no_pitch_correction,
                 output_dir=output_dir, alignment_dir=alignment_dir)
   if gpus <= 1 or len(pairs) <= 1:

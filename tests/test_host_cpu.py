@@ -208,6 +208,41 @@ def test_file_pairing_errors_and_alt_extensions(tmp_path):
   assert msg[5] == "valid extensions for this input are:" and len(msg) == 7
 
 
+def test_combine_preamble_asks_what_the_reference_asks(tmp_path, monkeypatch, capsys):
+  """combine()'s interactive preamble (describealign.py:1033-1062): an audio file on the video side and the listed pairing are
+  each confirmed with Enter (skipped by yes=True); the pairing is listed by file name; unequal counts are the reference's error."""
+  from describealign_amd import combine as Cb
+  vids, auds = tmp_path / "v", tmp_path / "a"
+  vids.mkdir(); auds.mkdir()
+  for n in ("ep2.mkv", "ep1.flac"):
+    (vids / n).write_bytes(b"x")
+  for n in ("ep1.mp3", "ep2.mp3"):
+    (auds / n).write_bytes(b"x")
+  asked, ran = [], []
+  monkeypatch.setattr("builtins.input", lambda prompt="": asked.append(prompt) or "")
+  monkeypatch.setattr(Cb, "_worker", lambda device, idx, pairs, kwargs, prec, *a: ran.append([(os.path.basename(v), os.path.basename(a_), alt) for v, a_, alt in pairs]))
+  out_dir, plot_dir = str(tmp_path / "out"), str(tmp_path / "plots")
+  Cb.combine(str(vids), str(auds), output_dir=out_dir, alignment_dir=plot_dir)
+  assert asked == ["If this was intended, press Enter to continue...", "If they are correct, press Enter to continue..."]
+  assert ran == [[("ep1.flac", "ep1.mp3", 1), ("ep2.mkv", "ep2.mp3", 0)]]
+  lines = capsys.readouterr().out.split("\n")
+  a = lines.index("One or more audio files found in video input. Was this intentional?")
+  assert lines[a - 1] == "" and lines[a + 1] == "If not, press ctrl+c to kill this script." and lines[a + 2] == ""
+  b = lines.index("ep1.flac")
+  assert lines[b:b + 6] == ["ep1.flac", "ep1.mp3", "", "ep2.mkv", "ep2.mp3", ""]
+  assert lines[b + 6:b + 9] == ["Are the above input file pairings correct?", "If not, press ctrl+c to kill this script.", ""]
+  assert lines[b + 9].startswith("Processing files with") and lines[-2].startswith("All files processed.")
+  assert os.path.isdir(out_dir) and os.path.isdir(plot_dir)
+  asked.clear()
+  Cb.combine(str(vids), str(auds), yes=True, output_dir=out_dir, alignment_dir=plot_dir)
+  assert asked == [] and "Was this intentional" not in capsys.readouterr().out
+  (auds / "ep3.mp3").write_bytes(b"x")
+  with pytest.raises(RuntimeError) as e:
+    Cb.combine(str(vids), str(auds), yes=True, output_dir=out_dir, alignment_dir=plot_dir)
+  assert str(e.value).split("\n") == ["Number of valid files in input paths are not the same.", "The video path has 2 files",
+                                       "The audio path has 3 files"]
+
+
 def test_key_frame_time_follows_the_reference():
   """get_closest_key_frame_time (:451-458): expectations recorded from the reference's function fed
   the same key-frame tables; the parser reads what `ffprobe -of json -show_frames` prints."""
