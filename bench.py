@@ -57,18 +57,20 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # dense MFMA peaks, MI355X_MICR
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(channels, workload_seconds, sample_seconds=None):
-  """The oracle (numpy restatement of the reference algorithm) on ONE host core, on a bounded sample
-  of the workload's shape (same generator, same channel count, same jump density).  Stage 2 of the
-  reference is quadratic in the duration, so the sample's audio-hours/s is an
-  UPPER bound for the CPU path at the workload's duration; the quadratic extrapolation is printed
-  beside it."""
+def cpu_baseline(channels, workload_seconds, sample_seconds=None, n_jumps=10, first_gap=200.0, golden_case=None):
+  """The oracle (numpy restatement of the reference algorithm) on ONE host core.  The STATED value is the rate at the
+  workload's own duration: measured when the sample IS the workload (configs[1]: 1320 s, ~10 s of CPU), otherwise the bounded
+  sample (configs[2]: 3600 s of the 7200 s stereo pair, ~2 min of CPU) extrapolated -- features linearly, align() quadratically
+  (stage 2 of the reference is quadratic in the duration).  The sample's own rate (an UPPER bound for the
+  workload's) is kept as `sample_value`."""
   from describealign_amd import synth
   from oracle import dalign_oracle as O
   if sample_seconds is None:
-    sample_seconds = 900.0 if channels == 2 else 600.0
-  n_jumps = max(2, int(round(10 * sample_seconds / 1320.0)))
-  pair = synth.make_pair(3, sample_seconds, n_jumps=n_jumps, first_gap=60.0, channels=channels)
+    sample_seconds = min(workload_seconds, 3600.0)
+  full = sample_seconds >= workload_seconds
+  sample_seconds = min(sample_seconds, workload_seconds)
+  n_j = n_jumps if full else max(2, int(round(n_jumps * sample_seconds / workload_seconds)))
+  pair = synth.make_pair(3, sample_seconds, n_jumps=n_j, first_gap=first_gap if full else min(first_gap, 60.0), channels=channels)
   t0 = time.perf_counter()
   vf, af = O.features(pair.video), O.features(pair.audio)
   t1 = time.perf_counter()
@@ -81,17 +83,31 @@ def cpu_baseline(channels, workload_seconds, sample_seconds=None):
     model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
   except Exception:
     model = "unknown"
-  return pair, (x, y), dict(
-      value=(sample_seconds / 3600.0) / dt, unit="audio-hours/s", cores=1, kind="port",
+  out = dict(
+      value=(workload_seconds / 3600.0) / est, unit="audio-hours/s", cores=1, kind="port",
+      value_is="measured at the workload's duration" if full else "extrapolated from the sample to the workload's duration",
       note="the numpy restatement of the reference algorithm (oracle/dalign_oracle.py), about 7x faster than the reference's own "
            "Python (describealign.py measured in the survey container: 65.6 s for a 1320 s pair, 0.0056 audio-hours/s); one core, "
-           "as the reference is single-threaded",
+           "as the reference is single-threaded.  `value` is the rate AT THE WORKLOAD'S DURATION; `sample_value` is the bounded "
+           "sample's own rate, an upper bound for it",
       sample=f"{sample_seconds:.0f} s video / {pair.audio_seconds:.0f} s AD synthetic {'stereo' if channels == 2 else 'mono'} pair, "
-             f"{n_jumps} jumps; features {t1 - t0:.1f} s + align {t2 - t1:.1f} s through oracle/dalign_oracle.py on one core",
-      seconds=round(dt, 2), host_cpu=model, host_cores=os.cpu_count(),
-      extrapolated_to_workload=dict(
-          seconds=round(est, 1), value=(workload_seconds / 3600.0) / est,
-          how=f"features x{ratio:.1f} (linear) + align x{ratio * ratio:.0f} (stage 2 is quadratic in the duration)"))
+             f"{n_j} jumps; features {t1 - t0:.1f} s + align {t2 - t1:.1f} s through oracle/dalign_oracle.py on one core",
+      sample_value=(sample_seconds / 3600.0) / dt, sample_seconds_of_audio=sample_seconds,
+      seconds=round(dt, 2), workload_seconds_estimated=round(est, 1), host_cpu=model, host_cores=os.cpu_count(),
+      extrapolation=None if full else f"features x{ratio:.1f} (linear) + align x{ratio * ratio:.0f} (stage 2 is quadratic in the duration)")
+  if golden_case:
+    # what the REFERENCE ITSELF took on this very pair when its fixture was recorded (build container, one core)
+    try:
+      idx = json.load(open(os.path.join(ROOT, "tests", "golden", "index.json")))
+      ref_s = idx["align"][golden_case].get("seconds_reference_total")
+      if ref_s:
+        out["reference_python_build_container_s"] = ref_s
+        out["reference_python_build_container_value"] = (workload_seconds / 3600.0) / ref_s
+        out["reference_python_note"] = (f"describealign.py v2.0.8 run on this pair (tests/golden/make_golden.py {golden_case}, features + align, "
+                                        "in the build container, not on this host)")
+    except Exception:
+      pass
+  return pair, (x, y), out
 
 
 class Bench:
@@ -285,7 +301,7 @@ class Bench:
                    "video_seconds": wl["seconds"], "audio_seconds": round(pair.audio_seconds, 1),
                    "channels": wl["channels"], "parallelism": f"pairs sharded over {world} GPU(s), no collectives"},
         "realtime_factor": wl["seconds"] * world * steps / elapsed,
-        "lead_in_pairs_actual": warmup,
+        "lead_in_pairs_actual": warmup, "warmup_effective": warmup,
         "whole_stream_value": hours * world * total / (t_end - t_start),
         "timed_region": {"kind": "steady state of one primed pipeline" if pipe is not None else "sequential align() calls",
                          "pairs_streamed": total, "untimed_lead_in_pairs": warmup, "tail_pairs": tail,
@@ -328,10 +344,10 @@ class Bench:
                                            "match_finish_call": round(acc.get("match_finish_s", 0.0) / k, 4)},
                             "intervals": {n[3:]: round(acc[n] / k, 4) for n in sorted(acc) if n.startswith("iv_")}},
         "pipeline": {"lp_worker_processes": workers, "gpu_streams": len(gpu_ctxs), "host_cores": os.cpu_count(),
-                     "worker_count_rationale": "1.5 worker processes per L3 domain of the host (align.default_worker_count): one HiGHS solve of a long pair "
-                                               "wants a whole L3 slice, so the host's solves/s do not grow beyond one worker per domain (configs[2] sweep, "
-                                               "profiles/r04_worker_sweep_cfg2.jsonl: the time per solve grows in proportion to the count), and the half "
-                                               "worker more per domain keeps every domain busy while its neighbour's result is being handed off",
+                     "worker_count_rationale": "a quarter more worker processes than this rank's share of the container's CPU quota (align.default_worker_count; "
+                                               "without a quota: three per four physical cores): the host stage is CPU-time bound -- the GPU box's container "
+                                               "runs under cpu.max = 16 CPUs, which is why every earlier worker sweep was flat beyond 16 "
+                                               "(profiles/r06_host_cpu_quota_probe.txt, r06_lp_host_scaling.jsonl)",
                      "note": "GPU stages of pair k+1 and the device chain DPs of earlier pairs overlap the host LP of pair k; "
                              "results identical to sequential align()"},
         "counts": {"gemm_pairs": acc["gemm_pairs"] / k, "survivors": acc["survivors"] / k, "matches": acc["matches"] / k,
@@ -356,9 +372,19 @@ class Bench:
         # share of the timed region this rank's worker processes spent inside pass 1 + LP + clustering
         res["lp_worker_utilisation"] = round((steps / elapsed) * (acc["worker_s"] / k) / workers, 3)
       res["bound"] = "host_lp" if lp_rate < 0.9 * min(gpu_rate, gpu_rate_wall) else "gpu"
+      # The host stage is bound by CPU TIME: under a cgroup quota (the GPU box: cpu.max = 16 CPUs of a 2 x 64-core host,
+      # profiles/r06_host_cpu_quota_probe.txt) it delivers quota / (CPU-seconds per pair) pairs a second, whatever the worker count
+      quota = A.cpu_quota()
+      res["host_cpu_budget"] = {
+          "cgroup_quota_cpus": quota, "logical_cpus": os.cpu_count(),
+          "worker_busy_s_per_pair": round(acc.get("worker_s", 0.0) / k, 3),
+          "note": "cgroup cpu.max of this container (None: no quota).  worker_busy_s_per_pair is wall time inside a worker process: with more "
+                  "workers than quota CPUs it includes the time the worker was throttled; the CPU-seconds a pair costs are host_lp.solve_s_alone "
+                  "(+ ~0.3 s of pass 1, hand-off and refine); quota / that = the host's capacity in pairs/s (2 h pairs: 16 / 6.4 = 2.5)"}
       res["bound_note"] = (f"GPU stage {gpu_stage_ms:.1f} ms of kernels per pair ({gpu_rate:.2f} pairs/s; {gpu_rate_wall:.2f} pairs/s by the feeding "
                            f"thread's wall clock); host LP {acc['lp_s'] / k:.2f} s per solve x {max(1, workers)} worker processes = {lp_rate:.2f} solves/s on "
-                           f"this rank's share of the host ({os.cpu_count()} logical CPUs, {world} rank(s): the host's LP capacity does not grow with the GPU count)")
+                           f"this rank's share of the host ({os.cpu_count()} logical CPUs, cgroup CPU quota {A.cpu_quota()}, {world} rank(s): the host stage is "
+                           f"CPU-time bound, its capacity is the quota / CPU-seconds per pair)")
       # HBM traffic of the dominant kernel from the committed PMC profile of this workload (PMC
       # collection needs its own rocprofv3 passes; bench.py itself only times with HIP events)
       for prof_name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
@@ -406,8 +432,8 @@ class Bench:
                             "solves_per_s_one_worker_alone": round(1.0 / tm1["lp_s"], 3), "solves_per_s_under_load_all_workers": round(lp_rate, 3),
                             "fit_points": int(tm1["n_fit_points"]), "sequential_pair_s_idle_host": round(tm1["total_s"], 3),
                             "note": "one sequential align() of this rank's pair after the pipeline has drained (host and GPU otherwise idle): its "
-                                    "scipy.optimize.linprog solve beside the mean solve time of the timed pairs inside the worker pool (the solves "
-                                    "share L3 slices and memory bandwidth)"}
+                                    "scipy.optimize.linprog solve beside the mean solve time of the timed pairs inside the worker pool (more workers "
+                                    "than quota CPUs: the difference is time spent throttled, not slower solves)"}
         except Exception as e:
           res["host_lp"] = {"error": str(e)}
       if with_stretch:
@@ -429,7 +455,8 @@ class Bench:
         except Exception as e:            # never let the auxiliary measurement cost the headline line
           res["stretch_audio_stage"] = {"error": str(e)}
       if with_cpu_baseline:
-        spair, (ox, oy), cb = cpu_baseline(wl["channels"], wl["seconds"], args.cpu_sample_seconds)
+        spair, (ox, oy), cb = cpu_baseline(wl["channels"], wl["seconds"], args.cpu_sample_seconds, wl["n_jumps"], wl["first_gap"],
+                                           golden_case={"cfg2": "e7200s", "cfg1": "e1320"}.get(workload) if rank == 0 else None)
         # same sample through the GPU path: max |node time| difference vs the CPU reference port
         with quiet:
           vf = ctx.features(spair.video, _native.SIDE_VIDEO); af = ctx.features(spair.audio, _native.SIDE_AUDIO)
@@ -445,6 +472,153 @@ class Bench:
       c.close()
     ctx.close()
     return res
+
+
+def _offset_error_ms(meta, x, y):
+  """Every recovered segment's (audio - video) offset against the injected truth at its middle (ms)."""
+  err = 0.0
+  for k in range(0, len(x) - 1, 2):
+    want = meta.true_offset_at(0.5 * (y[k] + y[k + 1]))
+    err = max(err, abs((x[k] - y[k]) - want), abs((x[k + 1] - y[k + 1]) - want))
+  return 1e3 * err
+
+
+def finite_batch(bench, workload, seeds):
+  """What a STATED batch gets: `seeds` distinct pairs of the workload's shape, their PCM resident in HBM, COLD through one fresh
+  pipeline -- no lead-in, no tail; the clock runs from the first submission to the last result (rank-local, then max over ranks).
+  With N ranks the seeds are dealt round-robin (describealign.py:1077's directory batch, sharded): configs[3] is seeds 0..31."""
+  import contextlib, io
+  from describealign_amd import _native, synth
+  from describealign_amd import align as A
+  args, grp = bench.args, bench.grp
+  wl = WORKLOADS[workload]
+  prec_name = args.precision or wl["precision"]
+  prec = _native.PREC_F32 if prec_name == "f32" else _native.PREC_BF16
+  workers = args.pipeline if args.pipeline > 0 else A.default_worker_count(int(os.environ.get("LOCAL_WORLD_SIZE", grp.world)))
+  mine = list(seeds)[grp.rank::grp.world]
+  ctx = _native.Context(bench.device, prec)
+  streams, metas = [], []
+  t_gen = time.perf_counter()
+  for sd in mine:
+    pair = synth.make_pair(sd, wl["seconds"], n_jumps=wl["n_jumps"], first_gap=wl["first_gap"], channels=wl["channels"])
+    sides = []
+    for pcm in (pair.video, pair.audio):
+      st = _native.PcmStream(bench.device, wl["channels"], pcm.shape[1])
+      frames = np.ascontiguousarray(pcm.T)                    # interleaved (n, C), as a decoder delivers it
+      for at in range(0, len(frames), 1 << 24):
+        st.piece(frames[at:at + (1 << 24)])
+      st.sync()
+      sides.append(st)
+    streams.append(sides)
+    metas.append(synth.SynthPair(video=np.empty((wl["channels"], 0), np.int16), audio=np.empty((wl["channels"], 0), np.int16),
+                                 jump_video_times=pair.jump_video_times, jump_lengths=pair.jump_lengths, seed=sd))
+    del pair, frames
+  t_gen = time.perf_counter() - t_gen
+
+  def make_job(k):
+    def job(c):
+      c.pcm_adopt(_native.SIDE_VIDEO, streams[k][0])          # no copy: the context takes the device buffer over
+      c.pcm_adopt(_native.SIDE_AUDIO, streams[k][1])
+      return A.RESIDENT_PCM
+    return job
+
+  tms, errs, lens = [], [], []
+  t_p = time.perf_counter()
+  pipe = A.AlignPipeline([ctx], lp_workers=workers)
+  pipe.warm()
+  t_p = time.perf_counter() - t_p
+  bench.sync()
+  t0 = time.perf_counter()
+  with contextlib.redirect_stdout(io.StringIO()):
+    for k, out in enumerate(pipe.run((make_job(k) for k in range(len(mine))), timings=tms)):
+      errs.append(_offset_error_ms(metas[k], out[0], out[1])); lens.append(len(out[0]))
+  t1 = time.perf_counter()
+  bench.sync()
+  pipe.__exit__()
+  for sides in streams:
+    for st in sides:
+      st.close()
+  ctx.close()
+  elapsed = grp.max_over_ranks(t1 - t0)
+  worst = grp.max_over_ranks(max(errs) if errs else 0.0)
+  n_all = len(list(seeds))
+  if grp.rank != 0:
+    return None
+  hours = wl["seconds"] / 3600.0
+  return {"workload": wl["desc"] + f", {prec_name} similarity GEMM", "pairs": n_all, "seeds": [int(min(seeds)), int(max(seeds))], "distinct_pairs": True,
+          "pairs_this_rank": len(mine), "ranks": grp.world, "wall_s": round(elapsed, 3), "value": hours * n_all / elapsed, "unit": "audio-hours/s",
+          "realtime_factor": wl["seconds"] * n_all / elapsed, "pairs_per_s": round(n_all / elapsed, 3),
+          "lead_in_pairs": 0, "tail_pairs": 0, "lp_worker_processes": workers,
+          "mean_lp_s": round(float(np.mean([tm["lp_s"] for tm in tms])), 3) if tms else None,
+          "mean_gpu_stage_s": round(float(np.mean([tm["match_s"] for tm in tms])), 4) if tms else None,
+          "max_offset_err_vs_injected_ms": round(worst, 3),
+          "nodes_per_pair": sorted(set(lens)),
+          "untimed": {"synthesis_and_upload_s": round(t_gen, 1), "pipeline_start_s": round(t_p, 2)},
+          "timed_region": "first pair submitted to a fresh, started pipeline -> last result delivered; PCM of every pair resident in HBM "
+                          "(PcmStream buffers adopted by the context, no copy); nothing primed, nothing discarded"}
+
+
+class _FileLock:
+  """Ranks that SHARE one device (gloo launch tests) take turns in the matching stage of a tiled pair."""
+
+  def __init__(self, path):
+    self.path = path
+
+  def __enter__(self):
+    import fcntl
+    self.f = open(self.path, "w")
+    fcntl.flock(self.f, fcntl.LOCK_EX)
+
+  def __exit__(self, *a):
+    import fcntl
+    fcntl.flock(self.f, fcntl.LOCK_UN)
+    self.f.close()
+
+
+def tiled_long_pair(bench):
+  """BASELINE configs[4]'s path -- the ONE place the alignment path has an exchange step: a single long pair, its matching stage
+  tiled over the ranks by audio rows (align.align_tiled), the verified match lists gathered on rank 0 over RCCL / xGMI
+  (distrib.Group._gather_device), chain DP + LP + pass 2 on rank 0, result broadcast.  Duration min(8 h, 1 h per rank)."""
+  import contextlib, io
+  from describealign_amd import _native, synth
+  from describealign_amd import align as A
+  grp = bench.grp
+  secs = float(os.environ.get("DALIGN_BENCH_TILED_SECONDS", min(28800.0, 3600.0 * grp.world)))
+  ctx = _native.Context(bench.device, _native.PREC_BF16)
+  t0 = time.perf_counter()
+  pair = synth.make_pair(13, secs, n_jumps=max(2, int(round(secs / 720.0))), first_gap=min(300.0, secs / 6.0), channels=1)
+  t_gen = time.perf_counter() - t0
+  vf = ctx.features(pair.video, _native.SIDE_VIDEO); af = ctx.features(pair.audio, _native.SIDE_AUDIO)
+  meta_err = None
+  lock = None
+  if grp.backend != "nccl" and grp.world > 1:
+    lock = _FileLock(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dalign_bench_tiled_{os.environ.get('MASTER_PORT', '0')}.lock"))
+  tm = {}
+  bench.sync()
+  t1 = time.perf_counter()
+  with contextlib.redirect_stdout(io.StringIO()):
+    x, y, sim, path, med = A.align_tiled(vf, af, vf[0], af[0], grp, ctx=ctx, timings=tm, match_lock=lock)
+  bench.sync()
+  el = grp.max_over_ranks(time.perf_counter() - t1)
+  match_s = grp.max_over_ranks(tm.get("match_s", 0.0))
+  n_local = tm.get("device", {}).get("matches", 0.0)
+  ctx.close()
+  if grp.rank != 0:
+    return None
+  total = float(tm["n_matches"])
+  moved = 16.0 * max(0.0, total - n_local)                 # packed key + float64 quality per match, rank 0's own block stays put
+  return {"workload": f"configs[4] path: ONE synthetic {secs:.0f} s mono pair, {len(pair.jump_lengths)} injected offsets, matching tiled over "
+                      f"{grp.world} rank(s) by audio rows, bf16 similarity GEMM", "video_seconds": secs, "ranks": grp.world, "backend": grp.backend,
+          "value": (secs / 3600.0) / el, "unit": "audio-hours/s", "realtime_factor": secs / el, "align_s": round(el, 2),
+          "match_s_max_over_ranks": round(match_s, 3), "gather_s": round(tm.get("gather_s", 0.0), 3), "chain_s": round(tm.get("chain_s", 0.0), 3),
+          "lp_s": round(tm.get("lp_s", 0.0), 2), "refine_s": round(tm.get("refine_s", 0.0), 3), "fit_points": int(tm.get("n_fit_points", 0)),
+          "matches": int(total), "gathered_bytes": moved, "gather_GBps": round(moved / max(tm.get("gather_s", 0.0), 1e-9) / 1e9, 2),
+          "nodes": int(len(x)), "segments_expected": len(pair.jump_lengths),
+          "max_offset_err_vs_injected_ms": round(_offset_error_ms(pair, x, y), 3), "similarity": round(float(sim), 2),
+          "untimed": {"synthesis_s": round(t_gen, 1)},
+          "note": "the exchange: all-gather of the per-rank match counts, then exact-size point-to-point transfers that land in rank 0's "
+                  "context (RCCL: device to device over xGMI; gloo, launch tests only: staged through the host).  The LP of one long pair is ONE "
+                  "scipy.optimize.linprog solve on one core (time ~ fit_points^1.8): it, not the GPUs, sets this figure"}
 
 
 def launch_ranks(n):
@@ -508,6 +682,9 @@ def main():
   ap.add_argument("--no-pcie", action="store_true", help="skip the short PCIe-inclusive measurement reported as `pcie_inclusive`")
   ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[3] measurements reported as `secondary` / `secondary_cfg3`")
   ap.add_argument("--no-cfg3", action="store_true", help="skip only the configs[3] measurement")
+  ap.add_argument("--no-finite", action="store_true", help="skip the cold finite-batch measurements (`finite_batch_cfg3`: 32 distinct 30 min pairs, "
+                                                            "`finite_batch_cfg2`: 8 distinct 2 h pairs)")
+  ap.add_argument("--no-tiled", action="store_true", help="N > 1 only: skip the single long pair tiled over the ranks (`secondary_tiled`, the RCCL exchange)")
   ap.add_argument("--include-h2d", action="store_true",
                   help="diagnostic: re-upload the PCM over PCIe inside every step (the PCIe-inclusive rate; never the headline value)")
   ap.add_argument("--gpu-streams", type=int, default=1,
@@ -555,6 +732,22 @@ def main():
       sec = b.run("cfg3", max(args.steps, 192), max(args.warmup, 8), with_cpu_baseline=False, with_stretch=False)
       if res is not None and sec is not None:
         res["secondary_cfg3"] = {k: sec[k] for k in SECONDARY_KEYS if k in sec}
+  if args.workload == "cfg2" and not args.no_secondary and args.precision is None and not args.no_finite:
+    # what a stated batch gets, cold (every rank takes part: the seeds are dealt over the ranks)
+    for key, wlname, seeds in (("finite_batch_cfg3", "cfg3", range(0, 32)), ("finite_batch_cfg2", "cfg2", range(5, 13))):
+      try:
+        fb = finite_batch(b, wlname, seeds)
+      except Exception as e:            # never let an auxiliary measurement cost the headline line
+        fb = {"error": f"{type(e).__name__}: {e}"}
+      if res is not None:
+        res[key] = fb
+  if not single and not args.no_tiled:
+    try:
+      tl = tiled_long_pair(b)
+    except Exception as e:
+      tl = {"error": f"{type(e).__name__}: {e}"}
+    if res is not None:
+      res["secondary_tiled"] = tl
   if grp.rank == 0:
     print(json.dumps(res))
   grp.close()

@@ -573,7 +573,7 @@ from describealign_amd import align as A
 backend = sys.argv[4] if len(sys.argv) > 4 else "gloo"   # gloo: all ranks share GPU 0 on the test box; RCCL needs one GPU per rank
 import torch
 g = distrib.Group(backend, init_single=True)
-ctx = _native.Context(0, _native.PREC_F32)
+ctx = _native.Context(g.local_rank if (backend == "nccl" and g.world > 1) else 0, _native.PREC_F32)
 name = sys.argv[3]
 pair = cases.align_case(name) if name != "half_hour" else synth.make_pair(9, 1800.0, n_jumps=10, first_gap=120.0)
 vf = ctx.features(pair.video, 0); af = ctx.features(pair.audio, 1)
@@ -633,6 +633,23 @@ def test_tiled_over_rccl_one_rank_equals_untiled_exactly(ctx, tmp_path):
   (n,) = _run_tiled(tmp_path, 1, "half_hour", 29571, backend="nccl")
   assert np.array_equal(n["x"], x) and np.array_equal(n["y"], y)
   assert float(n["sim"]) == sim and float(n["med"]) == med and np.array_equal(n["path"], path)
+
+
+def test_tiled_over_rccl_two_gpus_equals_untiled_exactly(ctx, tmp_path):
+  """The one RCCL data path with MORE than one real rank (distrib.Group._gather_device: rank 0 reserves the gathered list in
+  its context and posts the receives, rank 1 exports its block and sends it over xGMI): two ranks, one GPU each, on the
+  1800 s pair -- nodes, similarity, slope and the whole path identical to the untiled align().  Skipped on a one-GPU box
+  (RCCL refuses two ranks on one device); there the same code runs with one rank (test above) and under gloo."""
+  import torch
+  if torch.cuda.device_count() < 2:
+    pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+  from describealign_amd import align as A, synth
+  pair = synth.make_pair(9, 1800.0, n_jumps=10, first_gap=120.0)
+  vf = ctx.features(pair.video, 0); af = ctx.features(pair.audio, 1)
+  x, y, sim, path, med = A.align(vf, af, vf[0], af[0], ctx=ctx)
+  for n in _run_tiled(tmp_path, 2, "half_hour", 29573, backend="nccl"):
+    assert np.array_equal(n["x"], x) and np.array_equal(n["y"], y)
+    assert float(n["sim"]) == sim and float(n["med"]) == med and np.array_equal(n["path"], path)
 
 
 @pytest.mark.slow
@@ -1168,12 +1185,18 @@ def test_plain_bench_command_starts_its_own_ranks():
   env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
   cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--pipeline", "2",
          "--no-cpu-baseline", "--workload", "cfg-small"]
-  res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, DALIGN_DIST_BACKEND="gloo", DALIGN_BENCH_DEVICE="0"), cwd=root)
+  res = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                       env=dict(env, DALIGN_DIST_BACKEND="gloo", DALIGN_BENCH_DEVICE="0", DALIGN_BENCH_TILED_SECONDS="600"), cwd=root)
   assert res.returncode == 0, res.stderr[-2000:]
   lines = [l for l in res.stdout.splitlines() if l.strip()]
   assert len(lines) == 1 and lines[0].startswith("{"), res.stdout[-2000:]
   d = json.loads(lines[0])
   assert d["n_gpus"] == 2 == d["ranks_in_group"] and d["steps"] == 4 and d["value"] > 0
+  # with more than one rank the line also carries the one workload that has an exchange step: a single pair tiled over the ranks
+  t = d["secondary_tiled"]
+  assert "error" not in t, t
+  assert t["ranks"] == 2 and t["backend"] == "gloo" and t["video_seconds"] == 600.0 and t["matches"] > 1e5
+  assert t["nodes"] == 2 * t["segments_expected"] and t["max_offset_err_vs_injected_ms"] < 23.0 and t["gathered_bytes"] > 0
   import torch
   if torch.cuda.device_count() < 8:
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "cfg-small"],
