@@ -368,6 +368,13 @@ class Bench:
       res["lp_solves_per_s_rank"] = round(lp_rate, 3)                               # this rank's worker processes
       res["lp_solves_per_s_host"] = round(lp_rate * world, 3)                       # all ranks of the node share the host: rank 0's rate x ranks
       res["measured_pairs_per_s"] = round(world * steps / elapsed, 3)
+      methods = {}
+      for tm in sel:
+        m = str(tm.get("lp_method", "?")).split(" (")[0]
+        methods[m] = methods.get(m, 0) + 1
+      res["lp_method"] = {"timed_pairs": methods,
+                          "note": "tree = the reference's LP solved by HiGHS from the bases of sub-LPs (describealign_amd/lp_tree.py), accepted only with "
+                                  "its optimality certificate for the LP as posed; reference = scipy.optimize.linprog(method='highs-ds') from the slack basis"}
       if workers > 0 and acc.get("worker_s"):
         # share of the timed region this rank's worker processes spent inside pass 1 + LP + clustering
         res["lp_worker_utilisation"] = round((steps / elapsed) * (acc["worker_s"] / k) / workers, 3)

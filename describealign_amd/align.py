@@ -120,49 +120,17 @@ def compress_path(x, y, run=70, tol=3):
   return ux, uy
 
 
+def trend_jump_cost(x, y):
+  """Cost per unit of `jump` on every segment (:778-779): 10, less where the path is already discontinuous."""
+  return np.full(len(x) - 1, 10.0) / np.maximum(1, np.sqrt(continuity_error(x, y, deriv=True) / 3.0))
+
+
 def build_trend_lp(x, y):
-  """The reference's L1 trend-filter LP (:773-840; variable layout SURVEY appendix A.6),
-  assembled directly as COO triplets.  Returns (c, A_eq csc, b_eq, bounds)."""
+  """The reference's L1 trend-filter LP (:773-840; variable layout SURVEY appendix A.6), assembled directly as COO triplets
+  (lp_tree.assemble).  Returns (c, A_eq csc, b_eq, bounds) as the reference hands them to linprog."""
+  from . import lp_tree
   n = len(x)
-  dx = np.diff(x); dy = np.diff(y)
-  inv = 1.0 / dx
-  jump_cost = np.full(n - 1, 10.0) / np.maximum(1, np.sqrt(continuity_error(x, y, deriv=True) / 3.0))
-  c = np.concatenate([np.ones(2 * n), jump_cost, jump_cost, np.full(2 * n, 0.01), np.full(2 * n - 2, 3.0),
-                      np.full(2 * n - 2, 0.001), np.full(2 * n - 4, 10.0 * 4000), [0.0]])
-  o_fe_p, o_fe_m = 0, n
-  o_j_p, o_j_m = 2 * n, 3 * n - 1
-  o_s_p, o_s_m = 4 * n - 2, 5 * n - 2
-  o_sj_p, o_sj_m = 6 * n - 2, 7 * n - 3
-  o_rj_p, o_rj_m = 8 * n - 4, 9 * n - 5
-  o_rc_p, o_rc_m = 10 * n - 6, 11 * n - 8
-  o_med = 12 * n - 10
-  r1 = np.arange(n - 1)
-  r2 = np.arange(n - 2)
-  rows, cols, vals = [], [], []
-
-  def put(r, col, v):
-    rows.append(r); cols.append(col); vals.append(np.broadcast_to(v, r.shape))
-
-  # block 1: slope of every segment
-  put(r1, o_fe_p + r1, -inv); put(r1, o_fe_p + r1 + 1, inv)
-  put(r1, o_fe_m + r1, inv); put(r1, o_fe_m + r1 + 1, -inv)
-  for op, om in ((o_j_p, o_j_m), (o_sj_p, o_sj_m), (o_rj_p, o_rj_m)):
-    put(r1, op + r1, inv); put(r1, om + r1, -inv)
-  put(r1, np.full(n - 1, o_med), 1.0)
-  # block 2: shot-noise differences
-  b2 = (n - 1) + r1
-  put(b2, o_s_p + r1, -1.0); put(b2, o_s_p + r1 + 1, 1.0)
-  put(b2, o_s_m + r1, 1.0); put(b2, o_s_m + r1 + 1, -1.0)
-  put(b2, o_sj_p + r1, -1.0); put(b2, o_sj_m + r1, 1.0)
-  # block 3: changes of the rate-jump slope
-  b3 = (2 * n - 2) + r2
-  put(b3, o_rj_p + r2, -inv[:-1]); put(b3, o_rj_p + r2 + 1, inv[1:])
-  put(b3, o_rj_m + r2, inv[:-1]); put(b3, o_rj_m + r2 + 1, -inv[1:])
-  put(b3, o_rc_p + r2, -1.0); put(b3, o_rc_m + r2, 1.0)
-  A = scipy.sparse.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
-                              shape=(3 * n - 4, 12 * n - 9))
-  A.sort_indices()
-  b = np.concatenate([dy / dx, np.zeros(2 * n - 3)])
+  c, A, b, _, _ = lp_tree.assemble(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64), trend_jump_cost(x, y))
   bounds = [[0, None]] * (4 * n - 2) + [[0, 2.0]] * (2 * n) + [[0, None]] * (6 * n - 8) + [[None, None]]
   return c, A, b, bounds
 
@@ -208,7 +176,7 @@ def _solve_without_rate_terms(c, A, b, bounds, n, dx):
   return sol
 
 
-def solve_trend_lp(x, y, pricing=None, reduce=None):
+def solve_trend_lp(x, y, pricing=None, reduce=None, tree=None):
   """The reference's scipy.optimize.linprog call (:841-858): HiGHS dual simplex, IPM retry on
   status 4.
 
@@ -232,7 +200,14 @@ def solve_trend_lp(x, y, pricing=None, reduce=None):
   if reduce is None:
     env = os.environ.get("DALIGN_LP_REDUCE", "")
     reduce = (env == "1")
-  s = _solve_without_rate_terms(c, A, b, bounds, n, np.diff(x)) if (reduce and n >= 4) else None
+  if tree is None:
+    tree = os.environ.get("DALIGN_LP_TREE", "1") != "0"
+  s, how, tree_stats = None, "reference", {}
+  if tree and pricing in (None, "reference") and not reduce:
+    s = _solve_by_tree(x, y, c, A, b, tree_stats)
+    how = "tree" if s is not None else ("reference (tree: " + tree_stats.get("declined", "unavailable") + ")")
+  if s is None and reduce and n >= 4:
+    s = _solve_without_rate_terms(c, A, b, bounds, n, np.diff(x))
   if s is None:
     s = _solve_full_lp(c, A, b, bounds, pricing)
   fit_err = s[:n] - s[n:2 * n]
@@ -240,7 +215,42 @@ def solve_trend_lp(x, y, pricing=None, reduce=None):
   median_slope = s[-1]
   slopes = median_slope + rate_jump / np.diff(x)
   return dict(solution=s, fit_err=fit_err, slopes=slopes, median_slope=median_slope,
-              smooth_x=np.asarray(x, dtype=np.float64), smooth_y=np.asarray(y) - fit_err)
+              smooth_x=np.asarray(x, dtype=np.float64), smooth_y=np.asarray(y) - fit_err, method=how, tree=tree_stats)
+
+
+def _solve_by_tree(x, y, c, A, b, stats):
+  """The same LP -- the reference's, whole -- solved by the same HiGHS dual simplex, started from the bases of sub-LPs instead
+  of from the slack basis (lp_tree: leaves of ~300 fit points solved cold, merged four at a time, the last merge is the full LP).
+  A 2 h pair's solve takes a third of the CPU time, an 8 h pair's a tenth.  What HiGHS returns at the root is accepted only if
+  it passes the optimality conditions of the LP as the reference poses it (lp_tree.kkt_certificate: primal and dual
+  feasibility and a closed gap, checked on the original c, A, b and bounds); otherwise -- scipy without the binding, fewer
+  than lp_tree.MIN_POINTS fit points, any status but optimal, any exception -- None: the caller makes the reference's call."""
+  from . import lp_tree
+  n = len(x)
+  if n < lp_tree.MIN_POINTS:
+    stats["declined"] = "fewer than %d fit points" % lp_tree.MIN_POINTS
+    return None
+  if not lp_tree.available():
+    stats["declined"] = "scipy.optimize._highspy._core not usable"
+    return None
+  try:
+    got = lp_tree.solve(x, y, c[2 * n:3 * n - 1], stats=stats)
+    if got is None:
+      stats["declined"] = "a sub-LP did not end optimal"
+      return None
+    sol, row_dual, _ = got
+    lb = np.zeros(len(c)); ub = np.full(len(c), np.inf)
+    ub[4 * n - 2:6 * n - 2] = 2.0
+    lb[-1] = -np.inf
+    ok, worst = lp_tree.kkt_certificate(c, A, b, lb, ub, sol, row_dual)
+    stats["certificate"] = worst
+    if not ok:
+      stats["declined"] = "optimality certificate failed"
+      return None
+    return sol
+  except Exception as e:                                    # noqa: BLE001 -- whatever it was, the reference's call is the answer
+    stats["declined"] = f"{type(e).__name__}: {e}"
+    return None
 
 
 def _solve_full_lp(c, A, b, bounds, pricing=None):
@@ -414,6 +424,7 @@ def align(video_features, audio_desc_features, video_energy, audio_desc_energy, 
   t1 = time.perf_counter()
   lp = solve_trend_lp(fx, fy)
   tm["lp_s"] = time.perf_counter() - t1
+  tm["lp_method"] = lp["method"]
   print("  refining match: pass 2 of 2...\r", end='')
   out = _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm)
   tm["total_s"] = time.perf_counter() - t0
@@ -474,6 +485,7 @@ def align_tiled(video_features, audio_desc_features, video_energy, audio_desc_en
       t3 = time.perf_counter()
       lp = solve_trend_lp(fx, fy)
       tm["lp_s"] = time.perf_counter() - t3
+      tm["lp_method"] = lp["method"]
       out = _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm)
     except BaseException as e:                               # whatever it is, the other ranks are waiting in the broadcast
       err = f"{type(e).__name__}: {e}" if not isinstance(e, RuntimeError) else str(e)
@@ -497,6 +509,7 @@ def _lp_worker(args):
   t0 = time.perf_counter()
   lp = solve_trend_lp(fx, fy)
   lp.pop("solution", None)
+  lp.pop("tree", None)
   return lp, time.perf_counter() - t0
 
 
@@ -721,6 +734,7 @@ def _proc_mid(fname, fsize, n, le_v, lo_v, le_a, lo_a):
   t0 = time.perf_counter()
   lp = solve_trend_lp(fx, fy)
   tm["lp_s"] = time.perf_counter() - t0
+  tm["lp_method"] = lp["method"]
   t1 = time.perf_counter()
   clusters = cluster_lines(lp["smooth_x"], lp["smooth_y"], lp["slopes"])
   tm["cluster_s"] = time.perf_counter() - t1

@@ -20,6 +20,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
+OPTIONS = {}          # linprog options of the variant under test (set from the command line before the pool forks)
+
+
 def worker(args):
   cpu, fx, fy, t_start, deadline = args
   import scipy.optimize
@@ -36,7 +39,7 @@ def worker(args):
     t0 = time.time()
     if t0 >= deadline and n > 0:
       break
-    fit = scipy.optimize.linprog(c, A_eq=Am, b_eq=b, bounds=bounds, method="highs-ds")
+    fit = scipy.optimize.linprog(c, A_eq=Am, b_eq=b, bounds=bounds, method="highs-ds", options=OPTIONS)
     assert fit.success
     busy += time.time() - t0
     n += 1
@@ -52,6 +55,13 @@ def main():
   order = A.cpu_order()
   ncpu = len(order)
   plan = [(1, [16, 32, 64]), (2, [16, 32, 64, 128]), (4, [32, 64, 128]), (8, [32, 64, 128]), (16, [64, 128]), (32, [64, 128])]
+  if len(sys.argv) > 3:
+    # variant mode: `... instance seconds workers name=value ...` -- the full-size LP only, with these linprog options
+    # (e.g. simplex_dual_edge_weight_strategy=devex presolve=False); the CPU-seconds per solve are what the quota-bound host stage pays
+    plan = [(1, [int(sys.argv[3])])]
+    for kv in sys.argv[4:]:
+      k, v = kv.split("=", 1)
+      OPTIONS[k] = {"True": True, "False": False}.get(v, v)
   for div, workers in plan:
     n = len(fx) // div
     for w in sorted(set(min(w, ncpu) for w in workers)):
@@ -64,7 +74,7 @@ def main():
       elapsed = max(r[2] for r in res) - t_start
       print(json.dumps(dict(fit_points=n, columns=12 * n - 9, workers=w, solves=solves, elapsed_s=round(elapsed, 2),
                             solves_per_s=round(solves / elapsed, 3), s_per_solve=round(busy / solves, 4),
-                            fit_points_per_s=round(n * solves / elapsed, 1), host_cpus=ncpu)), flush=True)
+                            fit_points_per_s=round(n * solves / elapsed, 1), host_cpus=ncpu, options=OPTIONS)), flush=True)
 
 
 if __name__ == "__main__":
