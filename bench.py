@@ -60,13 +60,15 @@ HBM_PEAK_GBS = 8000.0
 def cpu_baseline(channels, workload_seconds, sample_seconds=None, n_jumps=10, first_gap=200.0, golden_case=None):
   """The oracle (numpy restatement of the reference algorithm) on ONE host core.  The STATED value is the rate at the
   workload's own duration: measured when the sample IS the workload (configs[1]: 1320 s, ~10 s of CPU), otherwise the bounded
-  sample (configs[2]: 3600 s of the 7200 s stereo pair, ~2 min of CPU) extrapolated -- features linearly, align() quadratically
+  sample (configs[2]: 2400 s of the 7200 s stereo pair, ~100 s of CPU) extrapolated -- features linearly, align() quadratically
   (stage 2 of the reference is quadratic in the duration).  The sample's own rate (an UPPER bound for the
   workload's) is kept as `sample_value`."""
   from describealign_amd import synth
   from oracle import dalign_oracle as O
   if sample_seconds is None:
-    sample_seconds = min(workload_seconds, 3600.0)
+    # the whole workload when that is ~10 s of CPU (configs[1]); else a third of it: 2 400 s of the 2 h stereo pair is ~100 s on
+    # one core of the GPU box's host (3 600 s measured: 230 s, profiles/r06_bench_default_first.json) and is extrapolated x 9
+    sample_seconds = workload_seconds if workload_seconds <= 1500.0 else min(workload_seconds, 2400.0)
   full = sample_seconds >= workload_seconds
   sample_seconds = min(sample_seconds, workload_seconds)
   n_j = n_jumps if full else max(2, int(round(n_jumps * sample_seconds / workload_seconds)))
@@ -671,7 +673,7 @@ def launch_ranks(n):
 SECONDARY_KEYS = ("value", "unit", "steps", "warmup", "lead_in_pairs_actual", "whole_stream_value", "ms_per_step", "dtype", "config",
                   "realtime_factor", "roofline", "feature_stage", "stage_ms_per_step", "host_s_per_step", "counts", "bound",
                   "gpu_stage_pairs_per_s", "lp_solves_per_s_host", "measured_pairs_per_s", "single_pair_latency_s",
-                  "max_offset_err_vs_injected_ms", "timed_region", "host_lp", "lp_worker_utilisation")
+                  "max_offset_err_vs_injected_ms", "timed_region", "host_lp", "lp_worker_utilisation", "lp_method", "cpu_baseline", "warmup_effective")
 
 
 def main():
@@ -732,7 +734,7 @@ def main():
                                      "(da_pcm_upload_async) in every step; value = whole-step rate including that transfer"}
   if single and args.workload == "cfg2" and not args.no_secondary and args.precision is None:
     # timed regions of >= 10 s (cfg1: ~47 ms per pair, cfg3: ~70 ms): a 3-5 s region reads +-10 % from one host to the next
-    sec = b.run("cfg1", max(args.steps, 256), max(args.warmup, 8), with_cpu_baseline=False, with_stretch=False)
+    sec = b.run("cfg1", max(args.steps, 256), max(args.warmup, 8), with_cpu_baseline=not args.no_cpu_baseline, with_stretch=False)
     if res is not None and sec is not None:
       res["secondary"] = {k: sec[k] for k in SECONDARY_KEYS if k in sec}
     if not args.no_cfg3:
