@@ -396,7 +396,7 @@ class Bench:
                            f"CPU-time bound, its capacity is the quota / CPU-seconds per pair)")
       # HBM traffic of the dominant kernel from the committed PMC profile of this workload (PMC
       # collection needs its own rocprofv3 passes; bench.py itself only times with HIP events)
-      for prof_name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+      for prof_name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
           prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
           key = workload + "_" + prec_name

@@ -175,13 +175,14 @@ struct da_ctx {
   std::string err;
   Side side[2];
   DevBuf tables, hann41;
-  DevBuf vlist, alist, surv, counters, keys0, q0, sort_tmp, rankmap, rowscratch, bfv, bfa;
+  DevBuf vlist, alist, surv, counters, keys0, q0, keys1, q1, sort_tmp, rankmap, rowscratch, bfv, bfa;
   std::vector<ChainSlot*> slots;  // sorted match lists live in slots (see ChainSlot)
   std::vector<HandoverBuf> handover_free;   // hand-over buffers not in use by a DP (see HandoverBuf)
   int res_slot = -1;              // slot holding the results of the last finished match
   int import_slot = -1;           // slot reserved by da_match_import_reserve (state 3) until da_match_import_commit
   unsigned long long next_ticket = 1;
   int64_t res_lv = 0;             // video frames of the last match (rank map size)
+  int64_t res_la = 0;             // audio frames of the last match (with res_lv: the key bits the match sort has to look at)
   DevBuf pair_i, pair_v, pair_c;
   DevBuf ascaled, vscaled, band_y, band_q, band_part, band_tab, band_cl, band_keys, band_ids, band_head, band_out, band_tmp;
   RefineScratch refine;
@@ -402,7 +403,7 @@ void da_destroy(da_ctx* c) {
     s.hash.release();
   }
   DevBuf* all[] = {&c->tables, &c->hann41, &c->vlist, &c->alist, &c->surv, &c->bfv, &c->bfa, &c->counters, &c->keys0,
-                   &c->q0, &c->sort_tmp, &c->rankmap, &c->rowscratch, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
+                   &c->q0, &c->keys1, &c->q1, &c->sort_tmp, &c->rankmap, &c->rowscratch, &c->pair_i, &c->pair_v, &c->pair_c, &c->ascaled, &c->vscaled,
                    &c->band_y, &c->band_q, &c->band_part, &c->band_tab, &c->band_cl, &c->band_keys, &c->band_ids, &c->band_head,
                    &c->band_out, &c->band_tmp};
   for (DevBuf* b : all) b->release();
@@ -718,6 +719,7 @@ extern "C" int da_match_begin(da_ctx* c, const float* vfeat, int64_t v_stride, c
   c->match_ready = false; c->match_pending = false;       // fetch_ready is untouched: the previous results stay fetchable
   c->rows_of_resident = false;                            // ... but the video row list is about to become the next pair's
   c->res_lv = v_lengths[0];
+  c->res_la = a_lengths[0];
   Side& V = c->side[0]; Side& A = c->side[1];
   HIP_TRY(c, hipEventRecord(c->prep_e0, c->stream));
   int rc = upload_and_prep(c, V, vfeat, v_stride, v_lengths, 1, resident_rows); if (rc) return rc;
@@ -850,12 +852,21 @@ extern "C" int da_match_finish(da_ctx* c, int64_t* n_out) {
     sl.rows_hint = c->last_match.n_a;
     c->res_slot = si;
     if (n_match > 0) {
+      // keys are (audio frame << 32 | video frame): a stable sort on the video field's bits, then one on the audio field's, touches
+      // only the bits that can differ -- 3 + 3 eight-bit passes for a 2 h pair (2^21 frames a side) against the 8 of all 64 bits
+      auto field_bits = [](int64_t len) { int b = 1; while (b < 32 && (int64_t(1) << b) < len) ++b; return b; };
+      const int vbits = field_bits(c->res_lv), ibits = field_bits(c->res_la);
       size_t tmp_bytes = 0;
-      if (sort_pairs(nullptr, nullptr, nullptr, nullptr, (int64_t)n_match, nullptr, &tmp_bytes, c->stream) != 0)
+      if (sort_pairs(nullptr, nullptr, nullptr, nullptr, (int64_t)n_match, nullptr, &tmp_bytes, 0, 64, c->stream) != 0)
         return fail(c, DA_ERR_DEVICE, "da_match: sort sizing failed");
       HIP_TRY(c, c->sort_tmp.ensure(tmp_bytes + 256));
-      if (sort_pairs(c->keys0.as<unsigned long long>(), sl.keys.as<unsigned long long>(), c->q0.as<double>(),
-                     sl.q.as<double>(), (int64_t)n_match, c->sort_tmp.p, &tmp_bytes, c->stream) != 0)
+      HIP_TRY(c, c->keys1.ensure(sizeof(unsigned long long) * n_match));
+      HIP_TRY(c, c->q1.ensure(sizeof(double) * n_match));
+      size_t tb1 = c->sort_tmp.cap, tb2 = c->sort_tmp.cap;
+      if (sort_pairs(c->keys0.as<unsigned long long>(), c->keys1.as<unsigned long long>(), c->q0.as<double>(), c->q1.as<double>(),
+                     (int64_t)n_match, c->sort_tmp.p, &tb1, 0, vbits, c->stream) != 0 ||
+          sort_pairs(c->keys1.as<unsigned long long>(), sl.keys.as<unsigned long long>(), c->q1.as<double>(), sl.q.as<double>(),
+                     (int64_t)n_match, c->sort_tmp.p, &tb2, 32, 32 + ibits, c->stream) != 0)
         return fail(c, DA_ERR_DEVICE, "da_match: device sort failed");
       // keys0 is free again after the sort: unpack the sorted keys into two int32 arrays there
       launch_unpack_keys(sl.keys.as<unsigned long long>(), (int64_t)n_match, c->keys0.as<int32_t>(),
@@ -1019,7 +1030,7 @@ extern "C" int da_trim(da_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, da::stream_wait(c->stream));
   HIP_TRY(c, da::stream_wait(c->copy_stream));
-  for (DevBuf* b : {&c->surv, &c->bfv, &c->bfa, &c->q0, &c->sort_tmp, &c->rowscratch, &c->rankmap, &c->band_y, &c->band_q, &c->band_part, &c->band_cl,
+  for (DevBuf* b : {&c->surv, &c->bfv, &c->bfa, &c->q0, &c->keys1, &c->q1, &c->sort_tmp, &c->rowscratch, &c->rankmap, &c->band_y, &c->band_q, &c->band_part, &c->band_cl,
                     &c->band_keys, &c->band_ids, &c->band_head, &c->band_out, &c->band_tmp, &c->pair_i, &c->pair_v, &c->pair_c})
     b->release();
   { RefineScratch none; std::swap(c->refine, none); }       // host arrays of da_refine

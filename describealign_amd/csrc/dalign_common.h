@@ -125,7 +125,7 @@ void launch_unpack_keys(const unsigned long long* keys, int64_t n, int32_t* out_
 
 // device radix sort of (key, qual) pairs (hipCUB); returns 0 on success
 int sort_pairs(unsigned long long* keys_in, unsigned long long* keys_out, double* vals_in, double* vals_out,
-               int64_t n, void* temp, size_t* temp_bytes, hipStream_t s);
+               int64_t n, void* temp, size_t* temp_bytes, int begin_bit, int end_bit, hipStream_t s);
 
 // row lists on the device: frames i in [lo, hi) with energy[i] > 0.5 (optionally every 4th of them) -> out,
 // count -> d_count[0] (d_count[1] is scratch); `scratch` holds hi - lo ints when every_fourth

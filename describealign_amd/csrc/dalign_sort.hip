@@ -6,11 +6,13 @@
 
 namespace da {
 
+// stable LSD radix sort on key bits [begin_bit, end_bit): two calls -- video bits first, audio bits second -- sort (i << 32 | v)
+// keys in as many 8-bit passes as the two fields need (2 h pair: 3 + 3) instead of the 8 of a full 64-bit sort
 int sort_pairs(unsigned long long* keys_in, unsigned long long* keys_out, double* vals_in, double* vals_out,
-               int64_t n, void* temp, size_t* temp_bytes, hipStream_t s) {
+               int64_t n, void* temp, size_t* temp_bytes, int begin_bit, int end_bit, hipStream_t s) {
   if (n > 0x7fffffffLL) return -1;
   hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, *temp_bytes, keys_in, keys_out, vals_in, vals_out,
-                                                    (int)n, 0, 64, s);
+                                                    (int)n, begin_bit, end_bit, s);
   return e == hipSuccess ? 0 : -1;
 }
 

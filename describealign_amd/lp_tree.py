@@ -221,9 +221,14 @@ def solve(x, y, jump_cost, leaf_points=None, stats=None):
   n = len(x)
   x = np.asarray(x, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
   jump_cost = np.asarray(jump_cost, dtype=np.float64)
-  leaf = int(leaf_points or LEAF_POINTS)
-  k = max(1, n // max(leaf, 16))
-  if k < 2:
+  leaf = max(16, int(leaf_points or LEAF_POINTS))
+  fan = max(2, int(os.environ.get("DALIGN_LP_FAN", "4")))
+  # the tree is laid out from the top: two halves under the root (where the held slope is re-centred most reliably), `fan`
+  # children under every other node, as many levels as bring the leaves closest to `leaf` points
+  k = 2
+  while (n / (k * fan)) * np.sqrt(fan) >= leaf and n // (k * fan) >= 16:
+    k *= fan
+  if n // k < 8:
     return None
   m_c = estimate_slope(x, y)
   cuts = [int(round(i * n / k)) for i in range(k)] + [n]
@@ -269,13 +274,12 @@ def solve(x, y, jump_cost, leaf_points=None, stats=None):
     level.append(nd)
   pivots.append(sum(nd.pivots for nd in level))
   seconds = [time.perf_counter() - t_begin]
-  fan = max(2, int(os.environ.get("DALIGN_LP_FAN", "4")))
   while len(level) > 1:
     t_level = time.perf_counter()
     if recentre and not recentre_level(level):
       return None
     nxt, spent = [], 0
-    root = len(level) <= fan
+    root = len(level) == 2
     for i in range(0, len(level), fan):
       group = level[i:i + fan]
       if len(group) == 1:
