@@ -242,7 +242,15 @@ def _solve_by_tree(x, y, c, A, b, stats):
     lb = np.zeros(len(c)); ub = np.full(len(c), np.inf)
     ub[4 * n - 2:6 * n - 2] = 2.0
     lb[-1] = -np.inf
+    basis = stats.pop("_basis", None)
     ok, worst = lp_tree.kkt_certificate(c, A, b, lb, ub, sol, row_dual)
+    if not ok and basis is not None and worst["primal_infeasibility"] <= 1e-6 and worst["relative_gap"] <= 1e-6:
+      # only the multipliers are off (update error of a long warm-started run): the same basis, freshly factorised
+      again = lp_tree.refactor(x, y, c[2 * n:3 * n - 1], basis)
+      if again is not None:
+        sol, row_dual, _ = again
+        ok, worst = lp_tree.kkt_certificate(c, A, b, lb, ub, sol, row_dual)
+        stats["refactored"] = True
     stats["certificate"] = worst
     if not ok:
       stats["declined"] = "optimality certificate failed"

@@ -4,18 +4,20 @@ What is solved is the reference's LP, whole, by the HiGHS dual simplex that `sci
 drives (scipy's own build, reached through the binding scipy itself uses, `scipy.optimize._highspy._core`); what changes is
 where the simplex STARTS.  From the slack basis HiGHS needs ~4.6 pivots per fit point on this LP and every pivot costs O(n)
 (the rows are first differences, so the basis inverse is a cumulative sum: dense): a 2 h pair's 10 282 points take 47 000
-pivots of ~130 us.  Here the fit points are cut into leaves of ~320 points whose sub-LPs (the same rows and columns, restricted)
-are solved cold -- the same 4.6 pivots per point, but each 30 x cheaper -- and neighbouring sub-LPs are then merged pairwise:
-the merged LP starts from the two optimal bases plus the four variables of the cut (jump, shot jump, two rate changes, signed
-so that the start is primal feasible) and needs a few hundred to a few thousand pivots; the last merge IS the full LP.
-Every level is an exact HiGHS solve; the root's model status, primal and dual solution are HiGHS' own for the reference's LP.
+pivots of ~130 us.  Here the fit points are cut into leaves of a few hundred points whose sub-LPs (the same rows and columns,
+restricted) are solved cold -- the same pivots per point, each ~30 x cheaper -- and neighbouring sub-LPs are merged, four at a
+time and the two halves at the root: a merged LP starts from its children's optimal bases with the rows of the cuts between
+them left to their logicals (a dual feasible start, see _merge_basis) and needs a few hundred to a few thousand pivots; the
+last merge IS the full LP.  Every level is an exact HiGHS solve; the root's model status, primal and dual solution are HiGHS'
+own for the reference's LP.
 
 Two details:
-  * median_slope is shared by all rows.  Below the root it is held at an estimate m_c (sub-LPs with different slopes cannot
-    be stitched); the rows are written for m' = median_slope - m_c, so that the root can free m' from its non-basic value 0.
-    The optimum does not depend on m_c, only the number of pivots at the root does.
-  * warm-started levels use devex pricing: steepest-edge weights of a user basis have to be computed from scratch, and with
-    them the same merges take 3-4 x the pivots (profiles/r06_lp_decomposition.txt).
+  * median_slope is shared by all rows.  Below the root it is held at m_c (sub-LPs with different slopes cannot be stitched);
+    the rows are written for m' = median_slope - m_c, so that the root can free m' from its non-basic value 0.  The optimum
+    does not depend on m_c, only the number of pivots at the root does: m_c starts from a data estimate and is re-centred level
+    by level on the weighted median of the level's own plateau slopes (recentre_level in solve()).
+  * devex pricing at every level: steepest-edge weights of a user basis have to be computed from scratch, and with them the
+    same merges take 3-4 x the pivots (profiles/r06_lp_decomposition.txt).
 
 Exactness: windows are NOT independent (the optimum inside a window depends on the rest of the file through the slope, the rate
 chain's duals and shot levels that persist for hundreds of points), which is why nothing is taken from a sub-LP but a
@@ -300,6 +302,8 @@ def solve(x, y, jump_cost, leaf_points=None, stats=None):
   sol = top.x.copy()
   sol[-1] += m_c
   if stats is not None:
+    stats["_basis"] = (top.col_status, top.row_status, m_c)      # for refactor()
+  if stats is not None:
     stats.update(leaves=k, slope_held=m_c, pivots_per_level=pivots, recentre_pivots=recentred, seconds_per_level=[round(t, 3) for t in seconds])
   return sol, top.row_dual, top.col_dual
 
@@ -330,3 +334,21 @@ def kkt_certificate(c, A, b, lb, ub, sol, row_dual, tol=1e-6):
   worst = dict(primal_infeasibility=max(p_inf, below, above), dual_infeasibility=d_inf, relative_gap=gap)
   ok = p_inf <= tol * max(1.0, float(np.max(np.abs(b)))) and below <= tol and above <= tol and d_inf <= tol and gap <= tol
   return bool(ok), worst
+
+
+def refactor(x, y, jump_cost, basis):
+  """The full LP once more from the root's optimal basis (`stats["_basis"]` of solve()): no pivots, but a fresh factorisation.
+  The duals that come back after thousands of basis updates are good to HiGHS' tolerance on ITS scaled LP, not always to 1e-6
+  on the LP as posed (seen once: a rate jump's reduced cost off by 1.7e-6 of its 0.001 on the 1 h golden pair); the reference's
+  call ends with such a clean-up too, after its postsolve.  Costs 0.1-0.3 s at 2 h (mostly moving 150 000 basis statuses
+  through the binding), so the caller asks for it only when the certificate objects to the dual side.  Returns
+  (solution, row duals, column duals) or None."""
+  col_status, row_status, m_c = basis
+  x = np.asarray(x, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
+  c, A, b, lb, ub = assemble(x, y, np.asarray(jump_cost, dtype=np.float64), m_c)
+  got = _run(c, A, b, lb, ub, (col_status, row_status), free_slope=True)
+  if got is None:
+    return None
+  sol = got[0].copy()
+  sol[-1] += m_c
+  return sol, got[3], got[4]

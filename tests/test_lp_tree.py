@@ -132,9 +132,13 @@ def test_tree_steps_aside_for_the_reference_call(monkeypatch):
   assert "did not end optimal" in lp["method"] and np.array_equal(lp["solution"], ref.x)
   monkeypatch.undo()
   monkeypatch.setattr(T, "MIN_POINTS", 100)
-  monkeypatch.setattr(T, "kkt_certificate", lambda *a, **k: (False, {"relative_gap": 1.0}))
+  refused = {"primal_infeasibility": 0.0, "dual_infeasibility": 1.0, "relative_gap": 0.0}       # the multipliers: one refactorisation is tried first
+  monkeypatch.setattr(T, "kkt_certificate", lambda *a, **k: (False, dict(refused)))
   lp = A.solve_trend_lp(x, y)
-  assert "certificate failed" in lp["method"] and np.array_equal(lp["solution"], ref.x)
+  assert "certificate failed" in lp["method"] and np.array_equal(lp["solution"], ref.x) and lp["tree"].get("refactored") is True
+  refused["relative_gap"] = 1.0                                                                  # a gap: no second chance
+  lp = A.solve_trend_lp(x, y)
+  assert "certificate failed" in lp["method"] and np.array_equal(lp["solution"], ref.x) and "refactored" not in lp["tree"]
   monkeypatch.setattr(T, "solve", lambda *a, **k: (_ for _ in ()).throw(ValueError("boom")))
   lp = A.solve_trend_lp(x, y)
   assert "ValueError: boom" in lp["method"] and np.array_equal(lp["solution"], ref.x)
@@ -147,8 +151,8 @@ def test_tree_steps_aside_for_the_reference_call(monkeypatch):
 
 @needs_binding
 def test_tree_on_a_rate_changed_pair_and_odd_tree_shapes():
-  """The slope held below the root starts from a data estimate (here ~1.003) and is re-centred level by level; leaf sizes that
-  leave an odd node out, fan-ins 2 and 3: same optimum every time."""
+  """The slope held below the root starts from a data estimate (here ~1.003) and is re-centred level by level; other leaf
+  sizes and fan-ins 2 and 3 (the tree is laid out from the top: 2 x fan^k leaves): same optimum every time."""
   x, y = _instance("r7200")
   x, y = x[:4100], y[:4100]
   c, Am, b, bounds = A.build_trend_lp(x, y)
@@ -166,4 +170,4 @@ def test_tree_on_a_rate_changed_pair_and_odd_tree_shapes():
     lb, ub = _bounds_arrays(len(x), len(c))
     ok, worst = T.kkt_certificate(c, Am, b, lb, ub, sol, row_dual)
     assert ok, (leaf, fan, worst)
-    assert st["leaves"] == len(x) // leaf and len(st["pivots_per_level"]) >= 3
+    assert st["leaves"] in (2 * fan, 2 * fan * fan, 2 * fan ** 3) and len(st["pivots_per_level"]) >= 3 and "_basis" in st
