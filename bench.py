@@ -559,6 +559,9 @@ def finite_batch(bench, workload, seeds):
           "realtime_factor": wl["seconds"] * n_all / elapsed, "pairs_per_s": round(n_all / elapsed, 3),
           "lead_in_pairs": 0, "tail_pairs": 0, "lp_worker_processes": workers,
           "mean_lp_s": round(float(np.mean([tm["lp_s"] for tm in tms])), 3) if tms else None,
+          "lp_s_per_pair": [round(float(tm["lp_s"]), 3) for tm in tms],          # distinct pairs: how the host LP's time varies with the content
+          "lp_fit_points_per_pair": [int(tm.get("n_fit_points", 0)) for tm in tms],
+          "lp_method": sorted(set(str(tm.get("lp_method", "?")).split(" (")[0] for tm in tms)),
           "mean_gpu_stage_s": round(float(np.mean([tm["match_s"] for tm in tms])), 4) if tms else None,
           "max_offset_err_vs_injected_ms": round(worst, 3),
           "nodes_per_pair": sorted(set(lens)),
