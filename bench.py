@@ -259,6 +259,8 @@ class Bench:
       add("lp_s", tm["lp_s"]); add("match_s", tm["match_s"]); add("chain_s", tm["chain_s"])
       add("n_path1", tm["n_path1"]); add("n_fit_points", tm["n_fit_points"])
       add("align_s", tm["match_s"] + tm["chain_s"] + tm["pass1_host_s"] + tm["lp_s"] + tm["cluster_s"] + tm["refine_s"] + tm["nodes_s"])
+      for name in ("worker_cpu_s", "gpu_thread_cpu_s", "refine_cpu_s", "handoff_cpu_s"):
+        add(name, tm.get(name, 0.0))
       for name in ("pass1_host_s", "cluster_s", "refine_s", "nodes_s", "worker_s", "features_s", "pace_s", "chain_begin_s",
                    "match_begin_s", "collect_under_gemm_s", "match_finish_s"):
         add(name, tm.get(name, 0.0))
@@ -387,9 +389,15 @@ class Bench:
       res["host_cpu_budget"] = {
           "cgroup_quota_cpus": quota, "logical_cpus": os.cpu_count(),
           "worker_busy_s_per_pair": round(acc.get("worker_s", 0.0) / k, 3),
-          "note": "cgroup cpu.max of this container (None: no quota).  worker_busy_s_per_pair is wall time inside a worker process: with more "
-                  "workers than quota CPUs it includes the time the worker was throttled; the CPU-seconds a pair costs are host_lp.solve_s_alone "
-                  "(+ ~0.3 s of pass 1, hand-off and refine); quota / that = the host's capacity in pairs/s (2 h pairs: 16 / 6.4 = 2.5)"}
+          "cpu_s_per_pair": {"worker_process": round(acc.get("worker_cpu_s", 0.0) / k, 4), "gpu_feeding_thread": round(acc.get("gpu_thread_cpu_s", 0.0) / k, 4),
+                             "refine_thread": round(acc.get("refine_cpu_s", 0.0) / k, 4), "hand_off_thread": round(acc.get("handoff_cpu_s", 0.0) / k, 4),
+                             "sum": round(sum(acc.get(n, 0.0) for n in ("worker_cpu_s", "gpu_thread_cpu_s", "refine_cpu_s", "handoff_cpu_s")) / k, 4)},
+          "capacity_pairs_per_s": (round(quota / max(1e-9, sum(acc.get(n, 0.0) for n in ("worker_cpu_s", "gpu_thread_cpu_s", "refine_cpu_s", "handoff_cpu_s")) / k), 2)
+                                   if quota else None),
+          "note": "cgroup cpu.max of this container (None: no quota).  worker_busy_s_per_pair is WALL time inside a worker process (with more "
+                  "workers than quota CPUs it includes time spent throttled); cpu_s_per_pair is CPU time (process_time / thread_time) of the pair's "
+                  "host work by where it runs (the runtime's helper threads and the interpreter's main thread are not in it); "
+                  "capacity_pairs_per_s = quota / that sum: what the host stage can deliver"}
       res["bound_note"] = (f"GPU stage {gpu_stage_ms:.1f} ms of kernels per pair ({gpu_rate:.2f} pairs/s; {gpu_rate_wall:.2f} pairs/s by the feeding "
                            f"thread's wall clock); host LP {acc['lp_s'] / k:.2f} s per solve x {max(1, workers)} worker processes = {lp_rate:.2f} solves/s on "
                            f"this rank's share of the host ({os.cpu_count()} logical CPUs, cgroup CPU quota {A.cpu_quota()}, {world} rank(s): the host stage is "

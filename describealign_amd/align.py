@@ -738,6 +738,7 @@ def _proc_mid(fname, fsize, n, le_v, lo_v, le_a, lo_a):
   px, py, vf, af, a_out, v_out = _block_views(mm, lay, le_v, lo_v, le_a, lo_a)
   tm = {}
   t_in = time.perf_counter()
+  c_in = time.process_time()
   fx, fy, a_s, v_s = _stage_pass1(px, py, vf, af, tm)
   t0 = time.perf_counter()
   lp = solve_trend_lp(fx, fy)
@@ -751,6 +752,7 @@ def _proc_mid(fname, fsize, n, le_v, lo_v, le_a, lo_a):
   mm.flush()
   del mm
   tm["worker_s"] = time.perf_counter() - t_in
+  tm["worker_cpu_s"] = time.process_time() - c_in          # CPU time, not wall: what the pair costs of the host's CPU-time budget
   return clusters, float(lp["median_slope"]), tm
 
 
@@ -961,6 +963,7 @@ class AlignPipeline:
       with self._lock:
         self._queued[id(ctx)] = self._queued.get(id(ctx), 0) - 1
       tp = time.perf_counter()
+      c_gpu = time.thread_time()
       self._pace(ctx)
       t0 = time.perf_counter()
       tm["pace_s"] = t0 - tp
@@ -995,6 +998,7 @@ class AlignPipeline:
         ticket = ctx.chain_begin()
         tm["chain_begin_s"] = time.perf_counter() - t2
       tm["t_gpu_stage_end"] = time.perf_counter()
+      tm["gpu_thread_cpu_s"] = time.thread_time() - c_gpu     # the feeding thread's own CPU time for this pair (polling waits included)
       self._stages_done = getattr(self, "_stages_done", 0) + 1
       if self._stages_done in (1, 4, 16):             # helper threads the runtime started from this (pinned) thread meanwhile
         self._float_others()
@@ -1082,6 +1086,7 @@ class AlignPipeline:
   def _hand_off_copy(self, px, py, vf, af, dims, tm, fname, done):
     try:
       tm["t_handoff"] = time.perf_counter()           # path collected, copy about to start (interval stamps: where a pair waits)
+      c_hand = time.thread_time()
       n = len(px)
       state = {}
       lay, size = _block_layout(n, *dims)
@@ -1105,6 +1110,7 @@ class AlignPipeline:
         dst[:] = src
       mm.flush()
       tm["t_copied"] = time.perf_counter()
+      tm["handoff_cpu_s"] = time.thread_time() - c_hand
       self._stagger_start(n)
       tm["t_submitted"] = time.perf_counter()
       try:
@@ -1161,6 +1167,7 @@ class AlignPipeline:
 
   def _refine_stage(self, mid_result, state, dims, tm):
     tm["t_refine_start"] = time.perf_counter()
+    c_ref = time.thread_time()
     clusters, med, wtm = mid_result
     busy = wtm.get("worker_s")
     if busy is not None:
@@ -1173,6 +1180,7 @@ class AlignPipeline:
     _, _, _, _, a_s, v_s = _block_views(state["mm"], state["lay"], *dims)
     out = _stage_refine(ctx, dict(median_slope=med), a_s, v_s, dims[0], dims[2], tm, clusters=clusters)
     tm["done_t"] = time.perf_counter()          # completion time (results are DELIVERED in submission order, later)
+    tm["refine_cpu_s"] = time.thread_time() - c_ref
     del a_s, v_s
     mm = state.pop("mm")
     del mm
