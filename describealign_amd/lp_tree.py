@@ -108,7 +108,11 @@ def estimate_slope(x, y):
   (|dy - dx| of every segment small).  Only the pivot count of the root depends on how good it is."""
   n = len(x)
   g = max(8, min(64, n // 8))
-  dev = np.abs(np.diff(y) - np.diff(x))
+  dx, dy = np.diff(x), np.diff(y)
+  s0 = float(np.median(dy / dx))                       # crude: most segments are a few frames long; good enough to tell a jump from a rate
+  if not (0.1 < s0 < 10.0):
+    s0 = 1.0
+  dev = np.abs(dy - s0 * dx)
   bad = np.concatenate([[0], np.cumsum(dev > 8.0)])
   i = np.arange(0, n - g)
   ok = (bad[i + g] - bad[i]) == 0
