@@ -1,8 +1,8 @@
 """GPU-box script (not a pytest): the host LP through the tree of warm starts (describealign_amd/lp_tree.py) against the reference's
 own scipy.optimize.linprog call, on the LPs of random synthetic pairs as the device stages deliver them -- lengths 5 min .. 80 min,
 mono / stereo, 0-14 offset jumps, with and without a rate difference between the files -- and what the difference does downstream:
-both LP results go through clustering, the banded extension and the second DP, and the nodes / similarity / pass-2 path must be
-identical.
+both LP results go through clustering, the banded extension and the second DP, and the nodes (to 1e-9 s), the similarity and the
+pass-2 path (same rows, audio frames and clusters; video positions to 1e-7 s) must agree.
 
   python tests/gpu_stress_lp_tree.py [pairs] [seed]
 
@@ -49,15 +49,27 @@ def main():
         outs.append(A._stage_refine(ctx, lp, a_s.copy(), v_s.copy(), n_ve, n_ae, t))
       except RuntimeError as e:
         outs.append(str(e))
-    same_nodes = (isinstance(outs[0], str) and outs[0] == outs[1]) or (not isinstance(outs[0], str) and not isinstance(outs[1], str) and
-                  np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2])
-    same_path = same_nodes and (isinstance(outs[0], str) or (outs[0][3].shape == outs[1][3].shape and np.array_equal(outs[0][3][:, :3], outs[1][3][:, :3])))
+    # the LP solutions agree to the solver's tolerance, not bit for bit, and a path row's video position is computed from the
+    # cluster's fitted line: compared to 1e-9 s (nodes) / 1e-7 s (video position of a path row); rows, audio frames and
+    # cluster numbers exactly
+    node_err, path_err, same_rows = float("nan"), float("nan"), False
+    if isinstance(outs[0], str) or isinstance(outs[1], str):
+      same_nodes = same_path = (outs[0] == outs[1]) if (isinstance(outs[0], str) and isinstance(outs[1], str)) else False
+    else:
+      (x0, y0, s0, p0, _), (x1, y1, s1, p1, _) = outs
+      same_len = len(x0) == len(x1)
+      node_err = float(max(np.max(np.abs(x0 - x1)), np.max(np.abs(y0 - y1)))) if same_len else float("inf")
+      same_nodes = same_len and node_err <= 1e-9 and abs(s0 - s1) <= 1e-9
+      same_rows = p0.shape == p1.shape and np.array_equal(p0[:, 1], p1[:, 1]) and np.array_equal(p0[:, 2], p1[:, 2])
+      path_err = float(np.max(np.abs(p0[:, 0] - p1[:, 0]))) if same_rows else float("inf")
+      same_path = same_rows and path_err <= 1e-7
     worst_diff = max(worst_diff, diff)
     n_tree += got["method"] == "tree"; n_nodes_equal += bool(same_nodes); n_path_equal += bool(same_path)
     t_ref += t1 - t0; t_tree += t2 - t1
     print(json.dumps(dict(pair=k, seconds=round(sec, 1), rate=rate, channels=int(pair.video.shape[0]), fit_points=len(fx), method=got["method"],
                           reference_s=round(t1 - t0, 3), tree_s=round(t2 - t1, 3), max_diff=diff, refactored=bool(got["tree"].get("refactored", False)),
-                          median_slope=ref["median_slope"], nodes_equal=bool(same_nodes), path_equal=bool(same_path))), flush=True)
+                          median_slope=ref["median_slope"], nodes_equal=bool(same_nodes), path_equal=bool(same_path),
+                          max_node_difference_s=node_err, max_path_video_difference_s=path_err)), flush=True)
   print(json.dumps(dict(summary=True, pairs=n_pairs, solved_by_tree=int(n_tree), nodes_equal=int(n_nodes_equal), path_equal=int(n_path_equal),
                         worst_solution_difference=worst_diff, reference_seconds=round(t_ref, 1), tree_seconds=round(t_tree, 1))), flush=True)
   ctx.close()
