@@ -606,10 +606,19 @@ def tiled_long_pair(bench):
   secs = float(os.environ.get("DALIGN_BENCH_TILED_SECONDS", min(28800.0, 3600.0 * grp.world)))
   ctx = _native.Context(bench.device, _native.PREC_BF16)
   t0 = time.perf_counter()
-  pair = synth.make_pair(13, secs, n_jumps=max(2, int(round(secs / 720.0))), first_gap=min(300.0, secs / 6.0), channels=1)
+  # rank 0 alone synthesises the pair and runs the feature kernel; every rank gets the ten feature rows (120 MB a side at 8 h):
+  # eight ranks synthesising 5 GB of PCM each, on a host whose CPU time they share, would take minutes for nothing
+  rows, meta = None, None
+  if grp.rank == 0:
+    full = synth.make_pair(13, secs, n_jumps=max(2, int(round(secs / 720.0))), first_gap=min(300.0, secs / 6.0), channels=1)
+    vf = ctx.features(full.video, _native.SIDE_VIDEO); af = ctx.features(full.audio, _native.SIDE_AUDIO)
+    rows = [np.array(r) for r in list(vf) + list(af)]
+    meta = (full.jump_video_times, full.jump_lengths)
+    del full, vf, af
+  rows, meta = grp.broadcast_rows(rows, meta)
+  vf, af = rows[:5], rows[5:]
+  pair = synth.SynthPair(video=np.empty((1, 0), np.int16), audio=np.empty((1, 0), np.int16), jump_video_times=meta[0], jump_lengths=meta[1], seed=13)
   t_gen = time.perf_counter() - t0
-  vf = ctx.features(pair.video, _native.SIDE_VIDEO); af = ctx.features(pair.audio, _native.SIDE_AUDIO)
-  meta_err = None
   lock = None
   if grp.backend != "nccl" and grp.world > 1:
     lock = _FileLock(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dalign_bench_tiled_{os.environ.get('MASTER_PORT', '0')}.lock"))
@@ -635,7 +644,7 @@ def tiled_long_pair(bench):
           "matches": int(total), "gathered_bytes": moved, "gather_GBps": round(moved / max(tm.get("gather_s", 0.0), 1e-9) / 1e9, 2),
           "nodes": int(len(x)), "segments_expected": len(pair.jump_lengths),
           "max_offset_err_vs_injected_ms": round(_offset_error_ms(pair, x, y), 3), "similarity": round(float(sim), 2),
-          "untimed": {"synthesis_s": round(t_gen, 1)},
+          "untimed": {"synthesis_features_and_broadcast_s": round(t_gen, 1)},
           "note": "the exchange: all-gather of the per-rank match counts, then exact-size point-to-point transfers that land in rank 0's "
                   "context (RCCL: device to device over xGMI; gloo, launch tests only: staged through the host).  The LP of one long pair is ONE "
                   "scipy.optimize.linprog solve on one core (time ~ fit_points^1.8): it, not the GPUs, sets this figure"}

@@ -219,6 +219,31 @@ class Group:
     flat = body.cpu().numpy()
     return flat[:nx].copy(), flat[nx:2 * nx].copy(), float(head[2].item()), flat[2 * nx:].reshape(rows, 5).copy(), float(head[3].item())
 
+  def broadcast_rows(self, rows, meta=None):
+    """Rank 0's list of float32 feature rows (and a small picklable `meta`) on every rank: two broadcasts (lengths + meta, then
+    one flat tensor).  For a tiled pair's callers that have the PCM on rank 0 only: every rank needs all feature rows of both
+    sides (120 MB a side for 8 h), none needs the PCM."""
+    import numpy as np
+    import torch
+    if self.dist is None:
+      return rows, meta
+    head = [None]
+    if self.rank == 0:
+      head = [([len(r) for r in rows], meta)]
+    self.dist.broadcast_object_list(head, src=0)
+    lens, meta = head[0]
+    flat = torch.empty(int(sum(lens)), dtype=torch.float32, device=self.device)
+    if self.rank == 0:
+      flat.copy_(torch.from_numpy(np.concatenate([np.asarray(r, dtype=np.float32) for r in rows])))
+    self.dist.broadcast(flat, src=0)
+    if self.rank == 0:
+      return rows, meta
+    host = flat.cpu().numpy()
+    out, at = [], 0
+    for n in lens:
+      out.append(host[at:at + n].copy()); at += n
+    return out, meta
+
   def close(self):
     if self.dist is not None:
       self.dist.destroy_process_group()

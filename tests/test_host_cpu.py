@@ -420,6 +420,11 @@ if g.rank == 0:
   assert np.array_equal(gv[3:], np.arange(7) * 4) and np.array_equal(gq[3:], np.linspace(0.5, 50.0, 7) + 1)
 else:
   assert total is None and ctx._gathered is None
+# feature rows of a pair that only rank 0 holds (bench.py's tiled workload: rank 0 synthesises, everyone matches)
+rows = [np.arange(7, dtype=np.float32) * 0.5, np.arange(3, dtype=np.float32) - 1.0, np.zeros(0, dtype=np.float32)] if g.rank == 0 else None
+got, meta = g.broadcast_rows(rows, ([0.0, 2.5], [1.0, 3.0]) if g.rank == 0 else None)
+assert len(got) == 3 and got[0].dtype == np.float32 and np.array_equal(got[0], np.arange(7) * 0.5) and np.array_equal(got[1], [-1.0, 0.0, 1.0]) and len(got[2]) == 0
+assert meta == ([0.0, 2.5], [1.0, 3.0])
 # rank 0 finishes the pair alone and broadcasts the result; failures are raised everywhere
 res = (np.array([0.0, 1.5, 9.25]), np.array([0.5, 2.0, 9.0]), 87.5, np.arange(20.0).reshape(4, 5), 1.0001) if g.rank == 0 else None
 x, y, sim, path, med = g.broadcast_result(res)
