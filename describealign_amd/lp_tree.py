@@ -27,6 +27,7 @@ caller; any failure, any status other than optimal, any exception -> None, and t
 from __future__ import annotations
 
 import os
+import time
 
 import numpy as np
 import scipy.sparse
@@ -239,7 +240,6 @@ def solve(x, y, jump_cost, leaf_points=None, stats=None):
   m_c = estimate_slope(x, y)
   cuts = [int(round(i * n / k)) for i in range(k)] + [n]
   pivots = []
-  import time
   t_begin = time.perf_counter()
 
   recentre = os.environ.get("DALIGN_LP_RECENTRE", "1") != "0"
@@ -307,7 +307,6 @@ def solve(x, y, jump_cost, leaf_points=None, stats=None):
   sol[-1] += m_c
   if stats is not None:
     stats["_basis"] = (top.col_status, top.row_status, m_c)      # for refactor()
-  if stats is not None:
     stats.update(leaves=k, slope_held=m_c, pivots_per_level=pivots, recentre_pivots=recentred, seconds_per_level=[round(t, 3) for t in seconds])
   return sol, top.row_dual, top.col_dual
 
