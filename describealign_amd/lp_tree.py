@@ -127,7 +127,7 @@ def estimate_slope(x, y):
 # ---- HiGHS through scipy's binding -----------------------------------------------------------------------------------------
 class _Node:
   """One solved sub-LP: the run of fit points [a, e), its solution and its basis (lists of HighsBasisStatus, per block)."""
-  __slots__ = ("a", "e", "x", "col_status", "row_status", "row_dual", "col_dual", "pivots")
+  __slots__ = ("a", "e", "x", "col_status", "row_status", "row_dual", "col_dual", "pivots", "solver")
 
 
 def _split(seq, sizes):
@@ -139,21 +139,13 @@ def _split(seq, sizes):
 
 def _run(c, A, b, lb, ub, basis, free_slope):
   """One HiGHS dual-simplex solve with scipy.optimize.linprog(method='highs-ds')'s settings.  Returns (x, col_status,
-  row_status, row_dual, col_dual, pivots) or None unless HiGHS reports the model optimal."""
+  row_status, row_dual, col_dual, pivots, the solver object) or None unless HiGHS reports the model optimal."""
   H = _core
-  lp = H.HighsLp()
   n_col, n_row = len(c), len(b)
-  lp.num_col_ = n_col; lp.num_row_ = n_row
-  lp.a_matrix_.num_col_ = n_col; lp.a_matrix_.num_row_ = n_row
-  lp.a_matrix_.format_ = H.MatrixFormat.kColwise
   inf = H.kHighsInf
   if not free_slope:
     lb = lb.copy(); ub = ub.copy()
     lb[-1] = ub[-1] = 0.0
-  lp.col_cost_ = c
-  lp.col_lower_ = np.where(np.isinf(lb), -inf, lb); lp.col_upper_ = np.where(np.isinf(ub), inf, ub)
-  lp.row_lower_ = b; lp.row_upper_ = b
-  lp.a_matrix_.start_ = A.indptr; lp.a_matrix_.index_ = A.indices; lp.a_matrix_.value_ = A.data
   h = H._Highs()
   o = H.HighsOptions()
   o.output_flag = False; o.log_to_console = False
@@ -163,18 +155,40 @@ def _run(c, A, b, lb, ub, basis, free_slope):
   # devex pricing at every level: steepest-edge weights of a user basis have to be computed from scratch (the same merges take
   # 3-4 x the pivots with them), and in the cold leaves devex saves a fifth of the pivots too
   o.simplex_dual_edge_weight_strategy = int(H.simplex_constants.SimplexEdgeWeightStrategy.kSimplexEdgeWeightStrategyDevex)
-  if h.passOptions(o) == H.HighsStatus.kError or h.passModel(lp) == H.HighsStatus.kError:
+  if h.passOptions(o) == H.HighsStatus.kError:
+    return None
+  # the model goes in as arrays (the overload that takes numpy buffers: a HighsLp's vector members are filled element by element)
+  st = h.passModel(n_col, n_row, int(A.nnz), int(H.MatrixFormat.kColwise), int(H.ObjSense.kMinimize), 0.0,
+                   np.ascontiguousarray(c, dtype=np.float64), np.where(np.isinf(lb), -inf, lb), np.where(np.isinf(ub), inf, ub),
+                   np.ascontiguousarray(b, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64),
+                   np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32),
+                   np.ascontiguousarray(A.data, dtype=np.float64), np.zeros(n_col, dtype=np.int32))          # integrality: all continuous
+  if st == H.HighsStatus.kError:
     return None
   if basis is not None:
     hb = H.HighsBasis()
     hb.col_status = basis[0]; hb.row_status = basis[1]
     if h.setBasis(hb) != H.HighsStatus.kOk:
       return None
+  return _finish(h)
+
+
+def _finish(h, pivots_before=0):
+  """Run the solver `h` as it stands and read the result: (x, col_status, row_status, row_dual, col_dual, pivots, h) or None."""
+  H = _core
   if h.run() == H.HighsStatus.kError or h.getModelStatus() != H.HighsModelStatus.kOptimal:
     return None
   sol = h.getSolution(); bas = h.getBasis(); info = h.getInfo()
   return (np.asarray(sol.col_value, dtype=np.float64), list(bas.col_status), list(bas.row_status),
-          np.asarray(sol.row_dual, dtype=np.float64), np.asarray(sol.col_dual, dtype=np.float64), int(info.simplex_iteration_count))
+          np.asarray(sol.row_dual, dtype=np.float64), np.asarray(sol.col_dual, dtype=np.float64),
+          int(info.simplex_iteration_count) - pivots_before, h)
+
+
+def _shift_slope_rows(h, slope_rows_rhs):
+  """New right-hand sides for the slope rows (the first len(slope_rows_rhs) rows) of a solver that holds an optimal basis:
+  the basis and its factorisation stay, the next run() is a hot start in the dual simplex's second phase."""
+  for i, v in enumerate(slope_rows_rhs.tolist()):
+    h.changeRowBounds(i, v, v)
 
 
 def _merge_basis(children, root):
@@ -261,10 +275,13 @@ def solve(x, y, jump_cost, leaf_points=None, stats=None):
     m_c = m_new
     spent = 0
     for nd in level:
-      got = solve_range(nd.a, nd.e, (nd.col_status, nd.row_status), False)
+      # same solver object, same basis and factorisation: only the slope rows' right-hand sides move
+      dxs = np.diff(x[nd.a:nd.e])
+      _shift_slope_rows(nd.solver, np.diff(y[nd.a:nd.e]) / dxs - m_c)
+      got = _finish(nd.solver, pivots_before=int(nd.solver.getInfo().simplex_iteration_count))
       if got is None:
         return False
-      nd.x, nd.col_status, nd.row_status, nd.row_dual, nd.col_dual, piv = got
+      nd.x, nd.col_status, nd.row_status, nd.row_dual, nd.col_dual, piv, nd.solver = got
       spent += piv
     recentred.append(spent)
     return True
@@ -276,7 +293,7 @@ def solve(x, y, jump_cost, leaf_points=None, stats=None):
       return None
     nd = _Node()
     nd.a, nd.e = a, e
-    nd.x, nd.col_status, nd.row_status, nd.row_dual, nd.col_dual, nd.pivots = got
+    nd.x, nd.col_status, nd.row_status, nd.row_dual, nd.col_dual, nd.pivots, nd.solver = got
     level.append(nd)
   pivots.append(sum(nd.pivots for nd in level))
   seconds = [time.perf_counter() - t_begin]
@@ -296,7 +313,7 @@ def solve(x, y, jump_cost, leaf_points=None, stats=None):
         return None
       nd = _Node()
       nd.a, nd.e = group[0].a, group[-1].e
-      nd.x, nd.col_status, nd.row_status, nd.row_dual, nd.col_dual, nd.pivots = got
+      nd.x, nd.col_status, nd.row_status, nd.row_dual, nd.col_dual, nd.pivots, nd.solver = got
       spent += nd.pivots
       nxt.append(nd)
     pivots.append(spent)
