@@ -693,7 +693,7 @@ def launch_ranks(n):
 SECONDARY_KEYS = ("value", "unit", "steps", "warmup", "lead_in_pairs_actual", "whole_stream_value", "ms_per_step", "dtype", "config",
                   "realtime_factor", "roofline", "feature_stage", "stage_ms_per_step", "host_s_per_step", "counts", "bound",
                   "gpu_stage_pairs_per_s", "lp_solves_per_s_host", "measured_pairs_per_s", "single_pair_latency_s",
-                  "max_offset_err_vs_injected_ms", "timed_region", "host_lp", "lp_worker_utilisation", "lp_method", "cpu_baseline", "warmup_effective")
+                  "max_offset_err_vs_injected_ms", "timed_region", "host_lp", "lp_worker_utilisation", "lp_method", "cpu_baseline", "warmup_effective", "host_cpu_budget")
 
 
 def main():
