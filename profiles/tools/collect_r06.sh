@@ -1,5 +1,16 @@
 #!/bin/bash
-# round-6 evidence, one call on the GPU box: kernel trace + stats of the configs[2] batch (the headline's command with the auxiliary
+# Round-6 evidence.  This script is the last step; the other files of profiles/r06_* came from these commands (each run on a lease box
+# from the repo root, outputs under gpurun_out/):
+#   python profiles/tools/host_cpu_quota_probe.py                         -> profiles/r06_host_cpu_quota_probe.txt   (cgroup cpu.max = 16 CPUs)
+#   python profiles/tools/lp_host_scaling.py tests/golden/lp/e7200s.npz 20 -> profiles/r06_lp_host_scaling.jsonl      (LP throughput vs workers, by LP size)
+#   python tests/gpu_dump_fit_points.py gpurun_out/lp <cases>             -> tests/golden/lp/*.npz                   (the LP instances of the synthetic pairs)
+#   build container: gpurun_out/scratch experiments (windows, stitched bases, merge trees, dual form, IPM, scalings)
+#                                                                         -> profiles/r06_lp_decomposition.txt
+#   python tests/gpu_stress_lp_tree.py 60 [seed]                          -> profiles/r06_stress_lp_tree*.jsonl      (tree vs reference call through pass 2)
+#   DALIGN_DIST_BACKEND=gloo python tests/gpu_tiled_long_pair.py 28800 8  -> profiles/r06_tiled_8h_8ranks.json
+#   python bench.py                                                       -> profiles/r06_bench_default*.json        (five runs on different lease boxes)
+#   python bench.py --workload cfg2 --steps 24 ... --gpu-streams 1|2|3    -> DESIGN.md 9.6 (two feeding contexts: +4 %)
+# This script, one call on the GPU box: kernel trace + stats of the configs[2] batch (the headline's command with the auxiliary
 # measurements off), the FETCH_SIZE / WRITE_SIZE passes of the similarity GEMM, then the driver's command (python3 bench.py, no flags)
 set -u
 R=$GRAFT_REPO_ROOT
