@@ -448,9 +448,11 @@ class Bench:
           res["host_lp"] = {"solve_s_alone": round(tm1["lp_s"], 3), "solve_s_under_load": round(acc["lp_s"] / k, 3), "workers": workers,
                             "solves_per_s_one_worker_alone": round(1.0 / tm1["lp_s"], 3), "solves_per_s_under_load_all_workers": round(lp_rate, 3),
                             "fit_points": int(tm1["n_fit_points"]), "sequential_pair_s_idle_host": round(tm1["total_s"], 3),
+                            "helper_processes_of_the_lone_solve": int(tm1.get("lp_helper_processes", 0)),
                             "note": "one sequential align() of this rank's pair after the pipeline has drained (host and GPU otherwise idle): its "
-                                    "scipy.optimize.linprog solve beside the mean solve time of the timed pairs inside the worker pool (more workers "
-                                    "than quota CPUs: the difference is time spent throttled, not slower solves)"}
+                                    "LP solve beside the mean solve time of the timed pairs inside the worker pool (more workers than quota CPUs: part of "
+                                    "the difference is time spent throttled).  A pair aligned on its own spreads the tree's sub-LPs over helper "
+                                    "processes (helper_processes_of_the_lone_solve); inside the pool every solve is one process"}
         except Exception as e:
           res["host_lp"] = {"error": str(e)}
       if with_stretch:

@@ -176,7 +176,7 @@ def _solve_without_rate_terms(c, A, b, bounds, n, dx):
   return sol
 
 
-def solve_trend_lp(x, y, pricing=None, reduce=None, tree=None):
+def solve_trend_lp(x, y, pricing=None, reduce=None, tree=None, procs=0):
   """The reference's scipy.optimize.linprog call (:841-858): HiGHS dual simplex, IPM retry on
   status 4.
 
@@ -204,7 +204,7 @@ def solve_trend_lp(x, y, pricing=None, reduce=None, tree=None):
     tree = os.environ.get("DALIGN_LP_TREE", "1") != "0"
   s, how, tree_stats = None, "reference", {}
   if tree and pricing in (None, "reference") and not reduce:
-    s = _solve_by_tree(x, y, c, A, b, tree_stats)
+    s = _solve_by_tree(x, y, c, A, b, tree_stats, procs)
     how = "tree" if s is not None else ("reference (tree: " + tree_stats.get("declined", "unavailable") + ")")
   if s is None and reduce and n >= 4:
     s = _solve_without_rate_terms(c, A, b, bounds, n, np.diff(x))
@@ -218,7 +218,7 @@ def solve_trend_lp(x, y, pricing=None, reduce=None, tree=None):
               smooth_x=np.asarray(x, dtype=np.float64), smooth_y=np.asarray(y) - fit_err, method=how, tree=tree_stats)
 
 
-def _solve_by_tree(x, y, c, A, b, stats):
+def _solve_by_tree(x, y, c, A, b, stats, procs=0):
   """The same LP -- the reference's, whole -- solved by the same HiGHS dual simplex, started from the bases of sub-LPs instead
   of from the slack basis (lp_tree: leaves of ~300 fit points solved cold, merged four at a time, the last merge is the full LP).
   A 2 h pair's solve takes a third of the CPU time, an 8 h pair's a tenth.  What HiGHS returns at the root is accepted only if
@@ -234,7 +234,15 @@ def _solve_by_tree(x, y, c, A, b, stats):
     stats["declined"] = "scipy.optimize._highspy._core not usable"
     return None
   try:
-    got = lp_tree.solve(x, y, c[2 * n:3 * n - 1], stats=stats)
+    got = None
+    if procs >= 2 and n >= lp_tree.PARALLEL_MIN_POINTS:
+      # one long pair on its own: the independent sub-LPs of every level on helper processes (lp_tree.solve_parallel)
+      try:
+        got = lp_tree.solve_parallel(x, y, c[2 * n:3 * n - 1], procs, stats=stats)
+      except Exception as e:                                # noqa: BLE001 -- helpers gone: the same tree in this process
+        stats["helpers_failed"] = f"{type(e).__name__}: {e}"
+    if got is None:
+      got = lp_tree.solve(x, y, c[2 * n:3 * n - 1], stats=stats)
     if got is None:
       stats["declined"] = "a sub-LP did not end optimal"
       return None
@@ -365,6 +373,37 @@ def default_context(device: int = 0, precision: int = _native.PREC_F32) -> "_nat
   return _default_ctx
 
 
+def lp_helper_procs(n_video_frames):
+  """Helper processes for the LP of ONE pair aligned on its own (align(), rank 0 of align_tiled()): none for pairs under
+  80 minutes (their LP takes a second) and none inside a batch pipeline (its worker processes keep every CPU busy with other
+  pairs' LPs); otherwise half the CPUs this process may use, at most 8.  DALIGN_LP_PROCS overrides (0: never)."""
+  env = os.environ.get("DALIGN_LP_PROCS", "")
+  if env != "":
+    return max(0, int(env))
+  if n_video_frames < FRAMES_PER_SECOND * 4800:
+    return 0
+  budget = cpu_quota()
+  if budget is None:
+    budget = len(_cpu_topology()[0])
+  return int(max(2, min(8, budget // 2)))
+
+
+def _warm_lp_helpers(procs):
+  """Start the helper processes (imports: ~1 s) beside the GPU stages, not in front of the LP."""
+  if procs < 2:
+    return
+  import threading
+  from . import lp_tree
+
+  def start():
+    try:
+      if lp_tree.available():
+        lp_tree.helper_pool(procs).wait_ready()
+    except Exception:
+      pass
+  threading.Thread(target=start, daemon=True).start()
+
+
 def _stage_gpu_match(ctx, video_features, audio_desc_features, mode, tm, rows=None):
   """Stages 1+2 on the GPU: prep, similarity GEMM, exact verification, sort.  The verified
   matches stay on the device; returns their number."""
@@ -425,14 +464,17 @@ def align(video_features, audio_desc_features, video_energy, audio_desc_energy, 
   tm = timings if timings is not None else {}
   t0 = time.perf_counter()
   n_ve, n_ae = len(video_energy), len(audio_desc_energy)
+  procs = lp_helper_procs(n_ve)
+  _warm_lp_helpers(procs)
   print("  memorizing video...        \r", end='')
   print("  matching audio...  \r", end='')
   fx, fy, a_scaled, v_scaled = _stage_match(ctx, video_features, audio_desc_features, n_ve, n_ae, mode, tm)
   print("  refining match: pass 1 of 2...\r", end='')
   t1 = time.perf_counter()
-  lp = solve_trend_lp(fx, fy)
+  lp = solve_trend_lp(fx, fy, procs=procs)
   tm["lp_s"] = time.perf_counter() - t1
   tm["lp_method"] = lp["method"]
+  tm["lp_helper_processes"] = lp["tree"].get("helper_processes", 0)
   print("  refining match: pass 2 of 2...\r", end='')
   out = _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm)
   tm["total_s"] = time.perf_counter() - t0
@@ -453,6 +495,8 @@ def align_tiled(video_features, audio_desc_features, video_energy, audio_desc_en
   ctx = ctx or default_context()
   tm = timings if timings is not None else {}
   n_ve, n_ae = len(video_energy), len(audio_desc_energy)
+  procs = lp_helper_procs(n_ve) if group.rank == 0 else 0
+  _warm_lp_helpers(procs)
   t0 = time.perf_counter()
   # blocks of about equal numbers of non-quiet audio rows (:657-658), the rows that cost anything
   n_rows = max(0, n_ae - (2 * NODE_FRAMES - 1))
@@ -491,9 +535,10 @@ def align_tiled(video_features, audio_desc_features, video_energy, audio_desc_en
       tm["chain_s"] = time.perf_counter() - t2
       fx, fy, a_scaled, v_scaled = _stage_pass1(px, py, video_features, audio_desc_features, tm)
       t3 = time.perf_counter()
-      lp = solve_trend_lp(fx, fy)
+      lp = solve_trend_lp(fx, fy, procs=procs)
       tm["lp_s"] = time.perf_counter() - t3
       tm["lp_method"] = lp["method"]
+      tm["lp_helper_processes"] = lp["tree"].get("helper_processes", 0)
       out = _stage_refine(ctx, lp, a_scaled, v_scaled, n_ve, n_ae, tm)
     except BaseException as e:                               # whatever it is, the other ranks are waiting in the broadcast
       err = f"{type(e).__name__}: {e}" if not isinstance(e, RuntimeError) else str(e)

@@ -27,12 +27,14 @@ caller; any failure, any status other than optimal, any exception -> None, and t
 from __future__ import annotations
 
 import os
+import threading
 import time
 
 import numpy as np
 import scipy.sparse
 
 LEAF_POINTS = int(os.environ.get("DALIGN_LP_LEAF", "280"))           # 240-320 measured best (profiles/r06_lp_decomposition.txt)
+PARALLEL_MIN_POINTS = 6000                                            # fit points from which one LP is worth spreading over helper processes
 MIN_POINTS = int(os.environ.get("DALIGN_LP_TREE_MIN", "1000"))       # below this a solve takes 0.2 s either way (1 588 points: 0.59 -> 0.38 s)
 
 _core = None
@@ -372,3 +374,249 @@ def refactor(x, y, jump_cost, basis):
   sol = got[0].copy()
   sol[-1] += m_c
   return sol, got[3], got[4]
+
+
+# ---- one long pair: the tree's independent sub-LPs on helper processes ---------------------------------------------------------
+# A directory batch keeps every CPU busy with other pairs' LPs (align.AlignPipeline's worker processes call solve()).  ONE long
+# pair on its own -- align() on a 4 h film, rank 0 of a tiled 8 h pair -- leaves them idle while its LP runs for seconds: the
+# leaves (128 at 8 h) and the merges of a level are independent, so solve_parallel() hands them to a small pool of helper
+# processes and only the root runs alone.  Same sub-LPs, same starts, same certificate; nothing else changes.
+_pool = None
+_STATUS = None
+
+
+def _status_table():
+  global _STATUS
+  if _STATUS is None:
+    H = _core
+    _STATUS = [H.HighsBasisStatus(i) for i in range(5)]
+  return _STATUS
+
+
+class HelperPool:
+  """`procs` helper processes (python -m describealign_amd.lp_helper) fed through pipes; run() hands them a list of tasks and returns
+  the results in order.  Started once per process, lazily; ended when the interpreter exits."""
+
+  def __init__(self, procs):
+    import subprocess
+    import sys
+    self.procs = int(procs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    self.children = [subprocess.Popen([sys.executable, "-m", "describealign_amd.lp_helper"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+                     for _ in range(self.procs)]
+    self.ready = None
+    self.lock = threading.Lock()
+
+  def wait_ready(self):
+    with self.lock:
+      if self.ready is None:
+        self.ready = all(ch.stdout.read(1) == b"R" for ch in self.children)
+      return self.ready
+
+  def run(self, tasks):
+    """tasks: argument tuples of _pool_solve.  Results in task order; a helper that died or raised makes the whole call fail
+    (RuntimeError): the caller falls back to the serial tree."""
+    import pickle
+    import struct
+    if not self.wait_ready():
+      raise RuntimeError("lp helper processes did not start")
+    results = [None] * len(tasks)
+    nxt = [0]
+    errors = []
+    take = threading.Lock()
+
+    def feed(ch):
+      while True:
+        with take:
+          k = nxt[0]
+          nxt[0] += 1
+        if k >= len(tasks) or errors:
+          return
+        try:
+          blob = pickle.dumps(tasks[k], protocol=pickle.HIGHEST_PROTOCOL)
+          ch.stdin.write(struct.pack("<Q", len(blob))); ch.stdin.write(blob); ch.stdin.flush()
+          head = ch.stdout.read(8)
+          if len(head) < 8:
+            raise RuntimeError("lp helper process ended")
+          (size,) = struct.unpack("<Q", head)
+          res = pickle.loads(ch.stdout.read(size))
+          if isinstance(res, tuple) and len(res) == 2 and res[0] == "error":
+            raise RuntimeError(res[1])
+          results[k] = res
+        except Exception as e:                   # noqa: BLE001
+          errors.append(e)
+          return
+
+    with self.lock:                              # one run() at a time per pool
+      threads = [threading.Thread(target=feed, args=(ch,), daemon=True) for ch in self.children[:max(1, min(self.procs, len(tasks)))]]
+      for t in threads:
+        t.start()
+      for t in threads:
+        t.join()
+    if errors:
+      self.close()
+      raise RuntimeError(f"lp helper failed: {errors[0]}")
+    return results
+
+  def close(self):
+    global _pool
+    for ch in self.children:
+      try:
+        ch.stdin.close()
+      except Exception:
+        pass
+    for ch in self.children:
+      try:
+        ch.wait(timeout=2)
+      except Exception:
+        ch.kill()
+    self.children = []
+    if _pool is self:
+      _pool = None
+
+
+_pool_guard = threading.Lock()
+
+
+def helper_pool(procs):
+  """This process's pool of helper processes (at least `procs` of them), started on first use."""
+  global _pool
+  import atexit
+  with _pool_guard:
+    if _pool is not None and _pool.procs >= procs and _pool.children:
+      return _pool
+    if _pool is not None:
+      _pool.close()
+    _pool = HelperPool(procs)
+    atexit.register(_pool.close)
+    return _pool
+
+
+def _codes(statuses):
+  return np.fromiter((int(s) for s in statuses), dtype=np.int8, count=len(statuses))
+
+
+def _pool_solve(xs, ys, jcs, m_c, col_codes, row_codes, free_slope):
+  """One sub-LP in a helper process: the bases travel as int8 codes.  Returns (x, col codes, row codes, row duals, col duals,
+  pivots) or None."""
+  if not available():
+    return None
+  basis = None
+  if col_codes is not None:
+    tab = _status_table()
+    basis = ([tab[i] for i in col_codes.tolist()], [tab[i] for i in row_codes.tolist()])
+  c, A, b, lb, ub = assemble(xs, ys, jcs, m_c)
+  got = _run(c, A, b, lb, ub, basis, free_slope=free_slope)
+  if got is None:
+    return None
+  return got[0], _codes(got[1]), _codes(got[2]), got[3], got[4], got[5]
+
+
+class _PNode:
+  __slots__ = ("a", "e", "x", "col", "row", "row_dual", "col_dual")
+
+
+def _merge_codes(children, root):
+  """_merge_basis on int8 codes: children's bases, cut columns at their lower bound, cut rows' logicals basic."""
+  H = _core
+  B, L, Z = int(H.HighsBasisStatus.kBasic), int(H.HighsBasisStatus.kLower), int(H.HighsBasisStatus.kZero)
+  cut_cols = (0, 0, 1, 1, 0, 0, 1, 1, 1, 1, 2, 2)
+  cut_rows = (1, 1, 2)
+  cols = [[] for _ in range(12)]
+  rows = [[] for _ in range(3)]
+  for k, ch in enumerate(children):
+    sizes_c, sizes_r = block_sizes(ch.e - ch.a)
+    at = 0
+    for j in range(12):
+      if k and cut_cols[j]:
+        cols[j].append(np.full(cut_cols[j], L, dtype=np.int8))
+      cols[j].append(ch.col[at:at + sizes_c[j]]); at += sizes_c[j]
+    at = 0
+    for j in range(3):
+      if k:
+        rows[j].append(np.full(cut_rows[j], B, dtype=np.int8))
+      rows[j].append(ch.row[at:at + sizes_r[j]]); at += sizes_r[j]
+  col = np.concatenate([a for blk in cols for a in blk] + [np.array([Z if root else L], dtype=np.int8)])
+  row = np.concatenate([a for blk in rows for a in blk])
+  return col, row
+
+
+def solve_parallel(x, y, jump_cost, procs, leaf_points=None, stats=None):
+  """solve() with the sub-LPs of every level run on `procs` helper processes (the root, and the re-centring of the two halves
+  beside each other, are what is left of the critical path).  Returns what solve() returns, or None."""
+  if not available():
+    return None
+  n = len(x)
+  x = np.asarray(x, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
+  jump_cost = np.asarray(jump_cost, dtype=np.float64)
+  leaf = max(16, int(leaf_points or LEAF_POINTS))
+  fan = max(2, int(os.environ.get("DALIGN_LP_FAN", "4")))
+  k = 2
+  while (n / (k * fan)) * np.sqrt(fan) >= leaf and n // (k * fan) >= 16:
+    k *= fan
+  if n // k < 8:
+    return None
+  pool = helper_pool(procs)
+  m_c = estimate_slope(x, y)
+  cuts = [int(round(i * n / k)) for i in range(k)] + [n]
+  t_begin = time.perf_counter()
+  pivots, seconds, recentred = [], [], []
+
+  def run_all(jobs):
+    """jobs: (a, e, col codes | None, row codes | None, free_slope) -> _PNodes in order, pivots; None if any sub-LP failed."""
+    res = pool.run([(x[a:e], y[a:e], jump_cost[a:e - 1], m_c, cc, rc, fs) for a, e, cc, rc, fs in jobs])
+    out, spent = [], 0
+    for (a, e, _, _, _), got in zip(jobs, res):
+      if got is None:
+        return None, 0
+      nd = _PNode()
+      nd.a, nd.e = a, e
+      nd.x, nd.col, nd.row, nd.row_dual, nd.col_dual, piv = got
+      spent += piv
+      out.append(nd)
+    return out, spent
+
+  level, spent = run_all([(a, e, None, None, False) for a, e in zip(cuts[:-1], cuts[1:])])
+  if level is None:
+    return None
+  pivots.append(spent); seconds.append(time.perf_counter() - t_begin)
+  recentre = os.environ.get("DALIGN_LP_RECENTRE", "1") != "0"
+  while len(level) > 1:
+    t_level = time.perf_counter()
+    if recentre:
+      m_new = _level_slope(level, x, m_c)
+      if m_new != m_c and 0.1 < m_new < 10.0:
+        m_c = m_new
+        level, spent = run_all([(nd.a, nd.e, nd.col, nd.row, False) for nd in level])
+        if level is None:
+          return None
+        recentred.append(spent)
+      else:
+        recentred.append(0)
+    root = len(level) == 2
+    jobs, carried = [], []
+    for i in range(0, len(level), fan):
+      group = level[i:i + fan]
+      if len(group) == 1:
+        carried.append((len(jobs), group[0]))
+        continue
+      col, row = _merge_codes(group, root)
+      jobs.append((group[0].a, group[-1].e, col, row, root))
+    merged, spent = run_all(jobs)
+    if merged is None:
+      return None
+    for at, nd in carried:
+      merged.insert(at, nd)
+    pivots.append(spent); seconds.append(time.perf_counter() - t_level)
+    level = merged
+  top = level[0]
+  sol = top.x.copy()
+  sol[-1] += m_c
+  if stats is not None:
+    tab = _status_table()
+    stats["_basis"] = ([tab[i] for i in top.col.tolist()], [tab[i] for i in top.row.tolist()], m_c)
+    stats.update(leaves=k, slope_held=m_c, pivots_per_level=pivots, recentre_pivots=recentred, seconds_per_level=[round(t, 3) for t in seconds],
+                 helper_processes=procs)
+  return sol, top.row_dual, top.col_dual

@@ -171,3 +171,39 @@ def test_tree_on_a_rate_changed_pair_and_odd_tree_shapes():
     ok, worst = T.kkt_certificate(c, Am, b, lb, ub, sol, row_dual)
     assert ok, (leaf, fan, worst)
     assert st["leaves"] in (2 * fan, 2 * fan * fan, 2 * fan ** 3) and len(st["pivots_per_level"]) >= 3 and "_basis" in st
+
+
+@needs_binding
+def test_one_long_pair_spreads_its_sub_lps_over_helper_processes(tmp_path, monkeypatch):
+  """lp_tree.solve_parallel: the leaves and the merges of a level on helper processes (python -m describealign_amd.lp_helper, fed
+  through pipes) -- same optimum, same certificate; helpers that fail leave the LP to the same tree in this process; and because the
+  helpers are plain subprocesses, a caller's script needs no `if __name__ == "__main__"` guard."""
+  x, y = _instance("e3600")
+  c, Am, b, bounds = A.build_trend_lp(x, y)
+  ref = scipy.optimize.linprog(c, A_eq=Am, b_eq=b, bounds=bounds, method="highs-ds")
+  lp = A.solve_trend_lp(x, y, procs=2)
+  assert lp["method"] == "tree" and lp["tree"]["helper_processes"] == 2 and "helpers_failed" not in lp["tree"]
+  assert np.max(np.abs(lp["solution"] - ref.x)) < 1e-6 and lp["tree"]["certificate"]["relative_gap"] < 1e-6
+  # below PARALLEL_MIN_POINTS nothing is spread
+  xs, ys = _instance("e1320")
+  small = A.solve_trend_lp(xs, ys, procs=2)
+  assert small["method"] == "tree" and "helper_processes" not in small["tree"]
+  # helpers that die: the serial tree, still the optimum
+  monkeypatch.setattr(T.HelperPool, "run", lambda self, tasks: (_ for _ in ()).throw(RuntimeError("lp helper process ended")))
+  lp = A.solve_trend_lp(x, y, procs=2)
+  assert lp["method"] == "tree" and "lp helper process ended" in lp["tree"]["helpers_failed"]
+  assert np.max(np.abs(lp["solution"] - ref.x)) < 1e-6
+  monkeypatch.undo()
+  # a script without a main guard
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  script = tmp_path / "no_guard.py"
+  script.write_text("import sys, numpy as np\nsys.path.insert(0, %r)\nfrom describealign_amd import align as A\n"
+                    "z = np.load(%r)\nlp = A.solve_trend_lp(z['fx'], z['fy'], procs=2)\nprint('RESULT', lp['method'], lp['tree'].get('helper_processes'))\n"
+                    % (root, os.path.join(LP_DIR, "e3600.npz")))
+  import subprocess, sys
+  res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+  assert res.returncode == 0 and res.stdout.count("RESULT") == 1 and "RESULT tree 2" in res.stdout, res.stdout[-500:] + res.stderr[-1500:]
+  # the policy: nothing for pairs under 80 minutes, never more than 8, an override
+  assert A.lp_helper_procs(210 * 1800) == 0 and 2 <= A.lp_helper_procs(210 * 7200) <= 8
+  monkeypatch.setenv("DALIGN_LP_PROCS", "0")
+  assert A.lp_helper_procs(210 * 28800) == 0
