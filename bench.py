@@ -23,7 +23,7 @@ untimed lead-in of max(W, two LP solves per host worker) pairs, K timed pairs an
 the pipeline full are submitted as one stream; the clock runs from the completion of the lead-in's last
 pair to the completion of K more pairs (completion times, not in-order delivery times: one slow LP solve
 holds back the delivery of the finished pairs behind it and then releases them in a burst).  (The lead-in is
-longer than --warmup because a pair spends ~9 s in the host LP but only ~0.3 s on the GPU: the first
+longer than --warmup because a pair spends ~2 s in the host LP but only ~0.17 s on the GPU: the first
 results of a fresh pipeline come out in a burst at the GPU stage's rate, before the LP stage has had
 to sustain anything; `--prime 0` disables it.)  A barrier and a
 device synchronisation bracket the run of the stream (before the first job is submitted, after the
@@ -188,10 +188,10 @@ class Bench:
     tms, outs = [], []
     # tail: pairs submitted behind the timed ones so that every stage is as busy when the clock stops as
     # in the middle of a long batch: the LP solves of the timed pairs must run beside a full set of
-    # other solves (they share the host's caches and memory bandwidth: alone a 2 h pair's LP takes 6 s,
-    # beside 23 others 10 s), so one whole generation of solves follows the last timed pair
+    # other solves (they share the container's CPU-time quota: alone a 2 h pair's LP takes 1.7-2.4 s, beside 19 others
+    # 1.8-3.4 s), so one whole generation of solves follows the last timed pair
     tail = 0 if workers <= 0 else (args.tail if args.tail >= 0 else (workers if not quick else workers // 3))
-    # Priming.  A pair spends seconds in the host LP stage (2 h pair: ~9 s), far longer than the
+    # Priming.  A pair spends seconds in the host LP stage (2 h pair: ~2 s), far longer than the
     # 0.3 s between pairs, so the first results of a fresh pipeline arrive in a burst at the GPU
     # stage's rate: every worker is still on its FIRST solve and the LP stage has not yet had to
     # keep up.  The untimed lead-in is therefore at least `prime` pairs (two solves per worker by
