@@ -684,9 +684,10 @@ def _pin_worker(slot_counter, lock, first_slot, order):
     pass
 
 
-def cpu_quota():
+def cpu_quota(fs_root="/"):
   """CPUs' worth of run time per second that this process's cgroup may use (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us` /
-  `cpu.cfs_period_us`; the tightest limit on the path from the process's cgroup to the root), or None without a limit.
+  `cpu.cfs_period_us`; the tightest limit on the path from the process's cgroup to the root), or None without a limit
+  (`fs_root`: where /proc and /sys are found -- tests point it at a directory of their own).
   The GPU box is a 2 x 64-core host, but its container runs under `cpu.max = 1600000 100000`: 16 CPUs' worth of time however
   many of the 256 hardware threads it spreads over (profiles/r06_host_cpu_quota_probe.txt: a pure register loop on 32 pinned
   processes already takes 1.8 x as long as on 16, on 128 10 x).  That quota -- not the L3 domains rounds 2-5 blamed -- is
@@ -715,7 +716,7 @@ def cpu_quota():
 
   rel2, rel1 = "", ""
   try:
-    for line in open("/proc/self/cgroup"):
+    for line in open(os.path.join(fs_root, "proc/self/cgroup")):
       _, ctrl, path = line.strip().split(":", 2)
       if ctrl == "":
         rel2 = path
@@ -723,7 +724,8 @@ def cpu_quota():
         rel1 = path
   except Exception:
     pass
-  for root, rel, read in (("/sys/fs/cgroup", rel2, v2), ("/sys/fs/cgroup/cpu", rel1, v1), ("/sys/fs/cgroup/cpu,cpuacct", rel1, v1)):
+  for root, rel, read in ((os.path.join(fs_root, "sys/fs/cgroup"), rel2, v2), (os.path.join(fs_root, "sys/fs/cgroup/cpu"), rel1, v1),
+                          (os.path.join(fs_root, "sys/fs/cgroup/cpu,cpuacct"), rel1, v1)):
     parts = [p for p in rel.split("/") if p]
     for k in range(len(parts), -1, -1):
       take(read(os.path.join(root, *parts[:k])))

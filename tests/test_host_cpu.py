@@ -731,11 +731,32 @@ def test_worker_count_follows_the_cpu_time_budget(monkeypatch, tmp_path):
   assert A.default_worker_count(1) == 3 and A.default_worker_count(4) == 2
 
 
-def test_cpu_quota_reads_the_cgroup_files():
-  """cpu_quota() returns None or a positive number of CPUs, whatever cgroup layout the test host has."""
+def test_cpu_quota_reads_the_cgroup_files(tmp_path):
+  """cpu_quota(): cgroup v2 `cpu.max` (the GPU box: "1600000 100000" at the container's root), the tightest limit up the path,
+  "max" = none; cgroup v1 quota / period; nothing readable = None.  And whatever layout the test host has: None or positive."""
   from describealign_amd import align as A
   q = A.cpu_quota()
   assert q is None or q > 0
+
+  def tree(files):
+    root = tmp_path / f"fs{len(list(tmp_path.iterdir()))}"
+    for name, text in files.items():
+      f = root / name
+      f.parent.mkdir(parents=True, exist_ok=True)
+      f.write_text(text)
+    return str(root)
+
+  assert A.cpu_quota(tree({"proc/self/cgroup": "0::/\n", "sys/fs/cgroup/cpu.max": "1600000 100000\n"})) == 16.0
+  assert A.cpu_quota(tree({"proc/self/cgroup": "0::/\n", "sys/fs/cgroup/cpu.max": "max 100000\n"})) is None
+  nested = tree({"proc/self/cgroup": "0::/pods/job7\n", "sys/fs/cgroup/cpu.max": "max 100000\n", "sys/fs/cgroup/pods/cpu.max": "3200000 100000\n",
+                 "sys/fs/cgroup/pods/job7/cpu.max": "800000 100000\n"})
+  assert A.cpu_quota(nested) == 8.0
+  v1 = tree({"proc/self/cgroup": "3:cpu,cpuacct:/batch\n2:memory:/x\n", "sys/fs/cgroup/cpu,cpuacct/batch/cpu.cfs_quota_us": "250000\n",
+             "sys/fs/cgroup/cpu,cpuacct/batch/cpu.cfs_period_us": "100000\n"})
+  assert A.cpu_quota(v1) == 2.5
+  unlimited_v1 = tree({"proc/self/cgroup": "3:cpu:/\n", "sys/fs/cgroup/cpu/cpu.cfs_quota_us": "-1\n", "sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000\n"})
+  assert A.cpu_quota(unlimited_v1) is None
+  assert A.cpu_quota(tree({"proc/self/cgroup": "0::/\n"})) is None
 
 
 def test_cpu_order_is_a_permutation_with_physical_cores_first():
