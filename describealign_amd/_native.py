@@ -27,7 +27,7 @@ ERR_CAPACITY = -3
 ERR_MISMATCH = -4
 
 EXPORTS = ["da_create", "da_destroy", "da_last_error", "da_abi_version", "da_pcm_upload", "da_pcm_upload_async", "da_host_alloc", "da_host_free",
-           "da_pcm_stream_open", "da_pcm_stream_piece", "da_pcm_stream_sync", "da_pcm_stream_frames", "da_pcm_stream_error", "da_pcm_adopt",
+           "da_pcm_stream_open", "da_pcm_stream_piece", "da_pcm_stream_sync", "da_pcm_stream_frames", "da_pcm_stream_error", "da_pcm_adopt", "da_pcm_exchange",
            "da_pcm_stream_close",
            "da_features_resident", "da_features", "da_match", "da_match_begin", "da_match_finish", "da_match_fetch",
            "da_match_corr", "da_trim", "da_match_dump_tile", "da_match_export_device", "da_match_import_device", "da_match_import_reserve", "da_match_import_commit", "da_chain", "da_chain_begin", "da_chain_begin_exclusive", "da_pair_stage", "da_chain_finish", "da_chain_resident", "da_chain_poll", "da_chain_masked",
@@ -92,6 +92,7 @@ def load():
     lib.da_pcm_stream_frames.argtypes = [vp]; lib.da_pcm_stream_frames.restype = i64
     lib.da_pcm_stream_error.argtypes = [vp]; lib.da_pcm_stream_error.restype = C.c_char_p
     lib.da_pcm_adopt.argtypes = [vp, i32, vp]
+    lib.da_pcm_exchange.argtypes = [vp, i32, vp]
     lib.da_pcm_stream_close.argtypes = [vp]; lib.da_pcm_stream_close.restype = None
     lib.da_features_resident.argtypes = [vp, i32, vp, i64, P(i64)]
     lib.da_features.argtypes = [vp, vp, i64, i32, i32, vp, i64, P(i64)]
@@ -303,6 +304,18 @@ class Context:
     n, channels = stream.frames, stream.channels
     self._check(self._lib.da_pcm_adopt(self._h, side, stream._h))
     self._inflight[side] = list(stream._keep)        # pieces still in flight stay alive until the features call
+    stream._keep.clear()
+    self._n[side] = n
+    self._channels[side] = channels
+    self._rows.pop(side, None)
+    return n, channels
+
+  def pcm_exchange(self, side: int, stream: "PcmStream"):
+    """pcm_adopt that leaves `stream` holding what this side held (buffer and frame count): resident files rotate through one
+    context without a copy.  The side must be empty or have come from a stream itself (interleaved)."""
+    n, channels = stream.frames, stream.channels
+    self._check(self._lib.da_pcm_exchange(self._h, side, stream._h))
+    self._inflight[side] = list(stream._keep)
     stream._keep.clear()
     self._n[side] = n
     self._channels[side] = channels

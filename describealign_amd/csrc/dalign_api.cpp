@@ -578,6 +578,21 @@ int da_pcm_adopt(da_ctx* c, int side, da_pcm_stream* st) {
   return DA_OK;
 }
 
+// da_pcm_adopt that gives the stream what the context held -- buffer AND frame count -- instead of leaving it empty: a set of
+// resident files (one in the context, the others in streams) can be rotated through one context with nothing copied.
+int da_pcm_exchange(da_ctx* c, int side, da_pcm_stream* st) {
+  if (!c) return DA_ERR_ARG;
+  if (side < 0 || side > 1 || !st) return fail(c, DA_ERR_ARG, "da_pcm_exchange: bad argument");
+  Side& s = c->side[side];
+  if (s.channels != 0 && (s.planar != 0 || s.channels != st->channels))
+    return fail(c, DA_ERR_STATE, "da_pcm_exchange: the context's PCM must be interleaved with the stream's channel count (adopt a stream first)");
+  const int64_t held = s.channels != 0 ? s.n : 0;
+  const int rc = da_pcm_adopt(c, side, st);
+  if (rc != DA_OK) return rc;
+  st->frames = held; st->started = held > 0;        // its events (the context's former upload bracket) were recorded when that PCM landed
+  return DA_OK;
+}
+
 // ------------------------------------------------------------------------------------- features
 namespace {
 // the fused feature kernel + the download of its rows, enqueued on the context's stream; nothing is waited for.  e0 / e1: the

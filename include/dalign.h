@@ -82,6 +82,11 @@ int da_pcm_stream_sync(da_pcm_stream* st);
 int64_t da_pcm_stream_frames(const da_pcm_stream* st);
 const char* da_pcm_stream_error(const da_pcm_stream* st);
 int da_pcm_adopt(da_ctx* ctx, int side, da_pcm_stream* st);
+/* da_pcm_adopt that leaves the stream holding what the context held (device buffer and frame count) instead of empty: several
+ * resident files -- one in the context, the others in streams -- rotate through one context without a copy (bench.py's stream of
+ * distinct pairs).  The context's side must be empty or hold interleaved PCM of the stream's channel count (i.e. have come from a
+ * stream itself), else DA_ERR_STATE. */
+int da_pcm_exchange(da_ctx* ctx, int side, da_pcm_stream* st);
 void da_pcm_stream_close(da_pcm_stream* st);
 
 /* ---- features -------------------------------------------------------------------------------

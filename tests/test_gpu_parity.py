@@ -1056,6 +1056,44 @@ def test_async_pinned_upload_equals_blocking_upload(ctx, native):
   del pv, pa                                            # frees the page-locked memory with the last view
 
 
+def test_resident_clips_rotate_through_one_context_without_a_copy(native):
+  """da_pcm_exchange (bench.py's stream of distinct pairs): three clips of different lengths, one in the context and two in
+  streams, rotate through the context side for three rounds -- each time the feature rows equal those of a plain upload of that
+  clip, and a stream that received the context's PCM knows its length.  A planar upload cannot be exchanged (like swaps with like)."""
+  c = native.Context(0, native.PREC_F32)
+  clips = [cases.feature_clip(n) for n in ("stereo", "stereo_anti")] + [np.ascontiguousarray(cases.feature_clip("stereo")[:, 5000:150000])]
+  want = [[r.copy() for r in c.features(p, 0)] for p in clips]
+
+  def as_stream(p):
+    st = native.PcmStream(0, 2, p.shape[1])
+    st.piece(np.ascontiguousarray(p.T)); st.sync()
+    return st
+
+  c.pcm_upload(0, clips[0])                                  # planar: cannot take part
+  probe = as_stream(clips[1])
+  with pytest.raises(RuntimeError, match="interleaved"):
+    c.pcm_exchange(0, probe)
+  probe.close()
+  first = as_stream(clips[0])
+  c.pcm_adopt(0, first); first.close()
+  slots = [as_stream(clips[1]), as_stream(clips[2])]
+  held = {"ctx": 0, "slots": [1, 2]}
+  for step in range(1, 10):
+    p = step % 3
+    if held["ctx"] != p:
+      k = held["slots"].index(p)
+      n_before = slots[k].frames
+      assert n_before == clips[p].shape[1]
+      c.pcm_exchange(0, slots[k])
+      held["ctx"], held["slots"][k] = p, held["ctx"]
+      assert slots[k].frames == clips[held["slots"][k]].shape[1]          # the stream now holds the clip the context held
+    got = c.features_resident(0)
+    assert all(np.array_equal(got[r], want[p][r]) for r in range(5)), (step, p)
+  for st in slots:
+    st.close()
+  c.close()
+
+
 def test_streaming_ingest_pipe_to_hbm_equals_blocking_upload(ctx, native, tmp_path, monkeypatch):
   """SURVEY section 8(f) item 1 / describealign.py:149-157: decoder pipe -> ring of page-locked pieces -> HBM
   (media.stream_file_to_device + da_pcm_stream_* + da_pcm_adopt).  The feature rows of the adopted buffer equal those
