@@ -7,8 +7,10 @@ One step = one pass of the hot path over one (video, AD) pair whose PCM is alrea
 HBM: feature kernel (both sides) -> similarity GEMM + verification -> chain DP (device) -> host
 LP -> banded extension + second DP -> nodes.  metric = aligned audio-hours/s (video-side duration
 of the pairs processed / wall time), whole job over all ranks.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank aligns its own pair: a directory batch shards
-with no data-path collective (weak scaling).
+torch.distributed.run, one rank per GPU) every rank aligns its own pairs: a directory batch shards
+with no data-path collective (weak scaling).  The stream rotates through --distinct (4) different pairs
+of the workload's shape per rank (seeds 5 + rank, ...), all resident in HBM: consecutive steps never
+align the same pair, the LP and the survivor counts are means over the rotation.
 
 Workloads (BASELINE.json configs):
   cfg2  configs[2]: 7200 s stereo pair, 10 jumps, bf16 MFMA GEMM -- the largest single-GPU
