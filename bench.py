@@ -565,7 +565,9 @@ def finite_batch(bench, workload, seeds):
   ctx = _native.Context(bench.device, prec)
   streams, metas = [], []
   t_gen = time.perf_counter()
-  for sd in mine:
+  # every collective below (the two synchronisations, the reductions) is reached by every rank whatever fails on one of them:
+  # a rank that cannot build its share says so (all_ok) instead of leaving the others in a barrier
+  def build(sd):
     pair = synth.make_pair(sd, wl["seconds"], n_jumps=wl["n_jumps"], first_gap=wl["first_gap"], channels=wl["channels"])
     sides = []
     for pcm in (pair.video, pair.audio):
@@ -578,8 +580,26 @@ def finite_batch(bench, workload, seeds):
     streams.append(sides)
     metas.append(synth.SynthPair(video=np.empty((wl["channels"], 0), np.int16), audio=np.empty((wl["channels"], 0), np.int16),
                                  jump_video_times=pair.jump_video_times, jump_lengths=pair.jump_lengths, seed=sd))
-    del pair, frames
+
+  setup_err = None
+  try:
+    if os.environ.get("DALIGN_BENCH_FAIL_FINITE_SETUP") == str(grp.rank):          # test hook: this rank's share cannot be built
+      raise RuntimeError("forced by DALIGN_BENCH_FAIL_FINITE_SETUP")
+    for sd in mine:
+      build(sd)
+  except Exception as e:                         # noqa: BLE001
+    setup_err = e
   t_gen = time.perf_counter() - t_gen
+
+  def cleanup():
+    for sides in streams:
+      for st in sides:
+        st.close()
+    ctx.close()
+
+  if not grp.all_ok(setup_err is None):
+    cleanup()
+    raise RuntimeError(f"finite batch: setup failed on {'this' if setup_err is not None else 'another'} rank" + (f": {setup_err}" if setup_err is not None else ""))
 
   def make_job(k):
     def job(c):
@@ -595,18 +615,23 @@ def finite_batch(bench, workload, seeds):
   t_p = time.perf_counter() - t_p
   bench.sync()
   t0 = time.perf_counter()
-  with contextlib.redirect_stdout(io.StringIO()):
-    for k, out in enumerate(pipe.run((make_job(k) for k in range(len(mine))), timings=tms)):
-      errs.append(_offset_error_ms(metas[k], out[0], out[1])); lens.append(len(out[0]))
+  run_err = None
+  try:
+    with contextlib.redirect_stdout(io.StringIO()):
+      for k, out in enumerate(pipe.run((make_job(k) for k in range(len(mine))), timings=tms)):
+        errs.append(_offset_error_ms(metas[k], out[0], out[1])); lens.append(len(out[0]))
+  except Exception as e:                         # noqa: BLE001
+    run_err = e
   t1 = time.perf_counter()
   bench.sync()
-  pipe.__exit__()
-  for sides in streams:
-    for st in sides:
-      st.close()
-  ctx.close()
+  try:
+    pipe.__exit__()
+  finally:
+    cleanup()
   elapsed = grp.max_over_ranks(t1 - t0)
   worst = grp.max_over_ranks(max(errs) if errs else 0.0)
+  if not grp.all_ok(run_err is None):
+    raise RuntimeError(f"finite batch: failed on {'this' if run_err is not None else 'another'} rank" + (f": {run_err}" if run_err is not None else ""))
   n_all = len(list(seeds))
   if grp.rank != 0:
     return None
@@ -657,13 +682,19 @@ def tiled_long_pair(bench):
   t0 = time.perf_counter()
   # rank 0 alone synthesises the pair and runs the feature kernel; every rank gets the ten feature rows (120 MB a side at 8 h):
   # eight ranks synthesising 5 GB of PCM each, on a host whose CPU time they share, would take minutes for nothing
-  rows, meta = None, None
+  rows, meta, setup_err = None, None, None
   if grp.rank == 0:
-    full = synth.make_pair(13, secs, n_jumps=max(2, int(round(secs / 720.0))), first_gap=min(300.0, secs / 6.0), channels=1)
-    vf = ctx.features(full.video, _native.SIDE_VIDEO); af = ctx.features(full.audio, _native.SIDE_AUDIO)
-    rows = [np.array(r) for r in list(vf) + list(af)]
-    meta = (full.jump_video_times, full.jump_lengths)
-    del full, vf, af
+    try:
+      full = synth.make_pair(13, secs, n_jumps=max(2, int(round(secs / 720.0))), first_gap=min(300.0, secs / 6.0), channels=1)
+      vf = ctx.features(full.video, _native.SIDE_VIDEO); af = ctx.features(full.audio, _native.SIDE_AUDIO)
+      rows = [np.array(r) for r in list(vf) + list(af)]
+      meta = (full.jump_video_times, full.jump_lengths)
+      del full, vf, af
+    except Exception as e:                       # noqa: BLE001 -- the other ranks are about to wait for the broadcast
+      setup_err = e
+  if not grp.all_ok(setup_err is None):
+    ctx.close()
+    raise RuntimeError("tiled long pair: rank 0 could not build the pair" + (f": {setup_err}" if setup_err is not None else ""))
   rows, meta = grp.broadcast_rows(rows, meta)
   vf, af = rows[:5], rows[5:]
   pair = synth.SynthPair(video=np.empty((1, 0), np.int16), audio=np.empty((1, 0), np.int16), jump_video_times=meta[0], jump_lengths=meta[1], seed=13)
