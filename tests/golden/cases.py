@@ -59,6 +59,7 @@ ALIGN_CASES = {
   # reference time, > 10 GB of Python objects for the 2 h pair): the fixtures hold nodes / similarity / slope only
   "e1800":  dict(seed=0, video_seconds=1800.0, n_jumps=10, first_gap=120.0),                # = seed 0 of configs[3] (the batch of 32 half-hour pairs)
   "rate1800": dict(seed=41, video_seconds=1800.0, n_jumps=10, first_gap=120.0, rate_change=0.003),   # configs[3] size with a 0.3 % rate difference between the files
+  "j1800":  dict(seed=43, video_seconds=1800.0, n_jumps=25, first_gap=30.0, channels=2),                # many short segments (a jump every ~70 s), stereo
   "e3600":  dict(seed=6, video_seconds=3600.0, n_jumps=10, first_gap=200.0),
   "e7200s": dict(seed=5, video_seconds=7200.0, n_jumps=10, first_gap=200.0, channels=2),   # = bench.py's configs[2] pair (rank 0)
 }

@@ -476,7 +476,7 @@ def test_align_from_reference_features(ctx, a40):
 
 
 @pytest.mark.parametrize("name,prec", [("e180", "f32"), ("e180", "bf16"), ("e180s", "f32"), ("rate2", "f32"),
-                                       ("e600", "bf16"), ("e1320", "f32"), ("e1800", "bf16"), ("rate1800", "bf16"), ("e3600", "bf16"), ("e7200s", "bf16")])
+                                       ("e600", "bf16"), ("e1320", "f32"), ("e1800", "bf16"), ("rate1800", "bf16"), ("j1800", "f32"), ("e3600", "bf16"), ("e7200s", "bf16")])
 def test_end_to_end_from_pcm(ctx, ctx_bf16, name, prec):
   """PCM -> features -> align on the GPU vs the reference's recorded nodes: every node time
   within +-23 ms (north_star), similarity within 0.5 points.  e1320 is the configs[1] stand-in, e1800 is seed 0 of
