@@ -502,7 +502,7 @@ def test_end_to_end_from_pcm(ctx, ctx_bf16, name, prec):
   # other way (observed: 2 rows of 255 145 on the 22-minute pair, 0 elsewhere), and a short cluster may be kept on one
   # side only, which renumbers the clusters after it (22-minute pair).  Asserted: the same number of rows to within 4;
   # at least 99.9 % of the recorded rows found again at the same audio frame with the video position within 2e-4 s
-  # (0.04 frames; the north_star tolerance is 23 ms); the path visits the same NUMBER of distinct clusters to within 1.
+  # (0.04 frames; the north_star tolerance is 23 ms; j1800: see below); the path visits the same NUMBER of distinct clusters to within 1.
   # Qualities are -log10(1e-4 + |a - v|) of those rows, gated by clipped energy terms (:931-936): where the two sides
   # nearly agree a 2e-6 difference is a few per cent of |a - v|, and next to a gate's edge it switches part of the term
   # (observed: 0.5 % of the rows off by more than 0.1, at most 1.3); the running sum collects these as a random walk.
@@ -513,8 +513,14 @@ def test_end_to_end_from_pcm(ctx, ctx_bf16, name, prec):
   want_frame = np.rint(want20[:, 1] * 210.0).astype(np.int64)
   at = np.minimum(np.searchsorted(frame, want_frame), len(path) - 1)
   got = path[at]
-  same = (frame[at] == want_frame) & (np.abs(got[:, 0] - want20[:, 0]) < 2e-4)
+  # (j1800, 25 jumps: the sub-frame offset of ONE of its 26 lines lands on the neighbouring step of the refinement's grid --
+  # 0.042 frames = 0.2002 ms over the 21 s that line covers, 1.2 % of the rows, whichever GEMM precision and whichever way the LP
+  # is solved (tests/gpu_probe_j1800.py); hence 5e-4 s here, with at least 98 % of the rows within the 2e-4 s the other cases keep)
+  dv = np.abs(got[:, 0] - want20[:, 0])
+  same = (frame[at] == want_frame) & (dv < 5e-4)
   assert same.mean() >= 0.999, f"{int((~same).sum())} of {len(same)} recorded path rows are not on the GPU path"
+  tight = (frame[at] == want_frame) & (dv < 2e-4)
+  assert tight.mean() >= (0.98 if name == "j1800" else 0.999), float(tight.mean())
   assert abs(len(np.unique(path[:, 2])) - len(np.unique(want20[:, 2]))) <= 1
   dq = np.abs(got[same, 3] - want20[same, 3])
   assert np.mean(dq < 0.1) >= 0.99 and np.median(dq) < 1e-2, (float(np.mean(dq < 0.1)), float(np.median(dq)))   # observed: >= 99.5 % within 0.1, median 2e-5 .. 2e-3
