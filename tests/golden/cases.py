@@ -54,6 +54,8 @@ ALIGN_CASES = {
   "e180s":  dict(seed=2, video_seconds=180.0, jumps=([0.0, 90.0], [12.5, 3.0]), channels=2),
   "e600":   dict(seed=3, video_seconds=600.0, n_jumps=5, first_gap=60.0),
   "rate2":  dict(seed=4, video_seconds=300.0, jumps=([0.0], [20.0]), rate_change=0.02),
+  "rateneg600": dict(seed=44, video_seconds=600.0, n_jumps=4, first_gap=30.0, rate_change=-0.015),       # the AD copy runs 1.5 % slow
+  "j600s":  dict(seed=45, video_seconds=600.0, n_jumps=12, first_gap=8.0, channels=2),                 # a jump every ~45 s, stereo, short intro
   "e1320":  dict(seed=5, video_seconds=1320.0, n_jumps=10, first_gap=200.0),
   # BASELINE configs at their stated sizes, recorded from the reference itself (436 s and ~40 min of
   # reference time, > 10 GB of Python objects for the 2 h pair): the fixtures hold nodes / similarity / slope only

@@ -409,7 +409,7 @@ def gen_commands():
 def main(argv):
   idx_path = os.path.join(HERE, "index.json")
   index = json.load(open(idx_path)) if os.path.exists(idx_path) else {}
-  want = argv or (["features", "a40", "e180", "e180s", "e600", "rate2", "mismatch", "e1320", "e1800", "rate1800", "j1800"] +
+  want = argv or (["features", "a40", "e180", "e180s", "e600", "rate2", "rateneg600", "j600s", "mismatch", "e1320", "e1800", "rate1800", "j1800"] +
                   ["stretch:" + n for n in cases.STRETCH_CASES] +
                   ["combine_stretch:" + n for n in cases.COMBINE_STRETCH_CASES])
   index["reference_version"] = ref.__version__

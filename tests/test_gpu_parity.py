@@ -475,7 +475,7 @@ def test_align_from_reference_features(ctx, a40):
   assert path.shape == g["path2"].shape
 
 
-@pytest.mark.parametrize("name,prec", [("e180", "f32"), ("e180", "bf16"), ("e180s", "f32"), ("rate2", "f32"),
+@pytest.mark.parametrize("name,prec", [("e180", "f32"), ("e180", "bf16"), ("e180s", "f32"), ("rate2", "f32"), ("rateneg600", "bf16"), ("j600s", "f32"),
                                        ("e600", "bf16"), ("e1320", "f32"), ("e1800", "bf16"), ("rate1800", "bf16"), ("j1800", "f32"), ("e3600", "bf16"), ("e7200s", "bf16")])
 def test_end_to_end_from_pcm(ctx, ctx_bf16, name, prec):
   """PCM -> features -> align on the GPU vs the reference's recorded nodes: every node time
