@@ -98,7 +98,7 @@ def test_stage4_clusters_points_dp(a40):
   assert abs(sim - g["sim"]) < 1e-9
 
 
-E2E = ["e180", "e180s", "rate2", "e600"]
+E2E = ["e180", "e180s", "rate2", "e600", "rateneg600", "j600s"]
 
 
 @pytest.mark.parametrize("name", E2E)
